@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+TEST INFRASTRUCTURE ONLY - runs in the build container (where /root/reference is
+mounted) and nowhere else.  The fixtures are plain arrays: seeded synthetic inputs
+and the reference's outputs / gradients for them.  Weights are NOT stored for the
+large configurations; they are regenerated from the same seed by
+``ruart_amd.synth`` on whichever box runs the tests (a float64 checksum of every
+weight tensor is stored so drift is detected).
+
+    python oracle/gen_golden.py            # writes all fixtures
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e
+
+Reference entry points exercised (file:line in /root/reference):
+    Models/Bert/modeling.py:585-614   BertModel.forward
+    Models/Bert/Bert.py:130-176       Bert.combine_forward
+    Models/Layers.py:124-180,182-295,320-341,352-468,471-534
+    Models/SDNet.py:253-437           SDNet.forward
+    Models/SDNetTrainer.py:510-518    instance_bce_with_logits
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import _refshim  # noqa: E402
+
+_refshim.install()
+from ruart_amd import synth  # noqa: E402
+from ruart_amd.arguments import default_opt  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def checksum(wdict):
+    return np.array([float(np.sum(v.astype(np.float64))) for _, v in sorted(wdict.items())])
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB, %d arrays)" % (path, os.path.getsize(path) / 1024, len(arrays)))
+
+
+# ----------------------------------------------------------------------------------
+def gen_layers():
+    """Per-op vectors from Models/Layers.py with small random modules."""
+    import Models.Layers as L
+    L.set_dropout_prob(0.0)
+    L.set_seq_dropout(True)
+    g = np.random.default_rng(11)
+    out = {}
+
+    def rnd(*s, scale=1.0):
+        return (g.standard_normal(s) * scale).astype(np.float32)
+
+    # ---- Attention, four variants -------------------------------------------------
+    for tag, (B, L1, L2, D, Hh, D3, sim) in {
+        "attn_a": (3, 9, 7, 20, 12, 20, False),      # x3 is None
+        "attn_b": (2, 17, 5, 24, 16, 10, False),     # x3 given
+        "attn_c": (2, 6, 11, 8, 5, 14, True),        # do_similarity (fixed scalar diagonal)
+        "attn_d": (2, 100, 36, 48, 25, 30, False),   # conf-like lengths
+    }.items():
+        m = L.Attention(D, Hh, correlation_func=3, do_similarity=sim)
+        W = rnd(Hh, D, scale=0.4)
+        m.scoring.linear.weight.data = T(W)
+        if not sim:
+            m.scoring.diagonal.data = T(1.0 + 0.3 * rnd(1, 1, Hh))
+        x1 = T(rnd(B, L1, D)).requires_grad_()
+        x2 = T(rnd(B, L2, D)).requires_grad_()
+        mask = np.ones((B, L2), dtype=np.uint8)
+        for b in range(B):
+            mask[b, int(g.integers(1, L2 + 1)):] = 0
+        x3 = None if tag == "attn_a" else T(rnd(B, L2, D3)).requires_grad_()
+        y = m(x1, x2, T(mask), x3=x3)
+        gy = T(rnd(*y.shape))
+        y.backward(gy)
+        out.update({tag + "_W": W, tag + "_diag": m.scoring.diagonal.detach().numpy().copy(),
+                    tag + "_x1": x1.detach().numpy(), tag + "_x2": x2.detach().numpy(),
+                    tag + "_mask": mask, tag + "_y": y.detach().numpy(), tag + "_gy": gy.numpy(),
+                    tag + "_gx1": x1.grad.numpy(), tag + "_gx2": x2.grad.numpy(),
+                    tag + "_gW": m.scoring.linear.weight.grad.numpy()})
+        if x3 is not None:
+            out[tag + "_x3"] = x3.detach().numpy()
+            out[tag + "_gx3"] = x3.grad.numpy()
+        if not sim:
+            out[tag + "_gdiag"] = m.scoring.diagonal.grad.numpy()
+
+    # ---- StackedBRNN: 2-layer BiLSTM with whole-tensor layer norm -----------------
+    for tag, (B, Tn, Din, Hh, nl, bid, ln) in {
+        "rnn_a": (3, 11, 10, 6, 2, True, True),
+        "rnn_b": (5, 4, 14, 9, 1, False, False),
+    }.items():
+        m = L.StackedBRNN(Din, Hh, nl, bidirectional=bid)
+        for n_, p in m.named_parameters():
+            a = (g.uniform(-0.5, 0.5, tuple(p.shape))).astype(np.float32)
+            p.data = T(a)
+            out[tag + "_w_" + n_] = a
+        x = T(rnd(B, Tn, Din)).requires_grad_()
+        y, ys = m(x, None, return_list=True, LN=ln)
+        gy = T(rnd(*y.shape))
+        gy0 = T(rnd(*ys[0].shape))
+        (y * gy).sum().add((ys[0] * gy0).sum()).backward()
+        out.update({tag + "_x": x.detach().numpy(), tag + "_y": y.detach().numpy(),
+                    tag + "_y0": ys[0].detach().numpy(), tag + "_gy": gy.numpy(), tag + "_gy0": gy0.numpy(),
+                    tag + "_gx": x.grad.numpy()})
+        for n_, p in m.named_parameters():
+            out[tag + "_g_" + n_] = p.grad.numpy()
+
+    # ---- LinearSelfAttn + weighted_avg --------------------------------------------
+    B, Ln, D = 4, 13, 10
+    m = L.LinearSelfAttn(D)
+    m.linear.weight.data = T(rnd(1, D, scale=0.5))
+    m.linear.bias.data = T(rnd(1))
+    x = T(rnd(B, Ln, D)).requires_grad_()
+    mask = np.ones((B, Ln), dtype=np.uint8)
+    mask[1, 5:] = 0
+    mask[3, 1:] = 0
+    alpha = m(x, T(mask))
+    y = L.weighted_avg(x, alpha)
+    gy = T(rnd(*y.shape))
+    y.backward(gy)
+    out.update(dict(merge_w=m.linear.weight.detach().numpy(), merge_b=m.linear.bias.detach().numpy(),
+                    merge_x=x.detach().numpy(), merge_mask=mask, merge_alpha=alpha.detach().numpy(),
+                    merge_y=y.detach().numpy(), merge_gy=gy.numpy(), merge_gx=x.grad.numpy(),
+                    merge_gw=m.linear.weight.grad.numpy(), merge_gb=m.linear.bias.grad.numpy()))
+
+    # ---- GetFinalScores (useES, no_answer, mask_flag) -------------------------------
+    B, Ln, X, Hh, ES = 3, 16, 12, 7, 4
+    m = L.GetFinalScores(X, Hh, yesno=False, no_answer=True, useES=True)
+    for n_, p in m.named_parameters():
+        a = g.uniform(-0.4, 0.4, tuple(p.shape)).astype(np.float32)
+        p.data = T(a)
+        out["score_w_" + n_] = a
+    x = T(rnd(B, Ln, X)).requires_grad_()
+    h0 = T(rnd(B, Hh)).requires_grad_()
+    mask = np.ones((B, Ln), dtype=np.uint8)
+    mask[0, 9:] = 0
+    mask[2, 6:] = 0
+    y = m(x, h0, T(mask), ES, mask_flag=True)
+    gy = T(rnd(*y.shape))
+    y.backward(gy)
+    out.update(dict(score_x=x.detach().numpy(), score_h0=h0.detach().numpy(), score_mask=mask,
+                    score_y=y.detach().numpy(), score_gy=gy.numpy(), score_gx=x.grad.numpy(),
+                    score_gh0=h0.grad.numpy(), score_ES=np.array(ES)))
+    for n_, p in m.named_parameters():
+        if p.grad is not None:
+            out["score_g_" + n_] = p.grad.numpy()
+    out["score_nograd"] = np.array([n_ for n_, p in m.named_parameters() if p.grad is None])
+
+    # ---- whole-tensor layer norm and the loss -------------------------------------
+    x = T(rnd(4, 9, 6) * 3 + 0.7).requires_grad_()
+    y = torch.nn.functional.layer_norm(x, x.size())
+    gy = T(rnd(4, 9, 6))
+    y.backward(gy)
+    out.update(dict(wln_x=x.detach().numpy(), wln_y=y.detach().numpy(), wln_gy=gy.numpy(), wln_gx=x.grad.numpy()))
+    save("layers", **out)
+
+
+# ----------------------------------------------------------------------------------
+def gen_bert():
+    """BertModel.forward: a small config stored with weights, and bert-base dims
+    (weights regenerated from seed; selected layers/rows stored)."""
+    from Models.Bert.modeling import BertModel, BertConfig
+    g = np.random.default_rng(23)
+
+    def run(cfg, seed, ids, mask):
+        w = synth.make_bert_weights(cfg, seed=seed)
+        d = _refshim.write_bert_dir(cfg, w)
+        model = BertModel.from_pretrained(d)
+        model.eval()
+        with torch.no_grad():
+            layers, _ = model(T(ids), token_type_ids=None, attention_mask=T(mask))
+        return w, [l.numpy() for l in layers]
+
+    def make_ids(N, Lmax, vocab, lens):
+        ids = np.zeros((N, Lmax), dtype=np.int64)
+        for i, l in enumerate(lens):
+            ids[i, :l] = g.integers(1, vocab, size=l)
+        return ids, (ids != 0)
+
+    # small: 3 layers, hidden 128 (2 heads x 64), ragged lengths incl. 1 and full
+    cfg = synth.bert_config(vocab_size=500, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+                            intermediate_size=256, max_position_embeddings=64)
+    lens = [1, 2, 3, 5, 8, 13, 21, 30, 30, 4, 50, 17]
+    ids, mask = make_ids(len(lens), 50, 500, lens)
+    w, layers = run(cfg, 5, ids, mask)
+    arrays = dict(ids=ids, mask=mask, seed=np.array(5), wsum=checksum(w),
+                  cfg=np.array([cfg["vocab_size"], cfg["hidden_size"], cfg["num_hidden_layers"],
+                                cfg["num_attention_heads"], cfg["intermediate_size"], cfg["max_position_embeddings"]]))
+    for i, l in enumerate(layers):
+        arrays["layer%d" % i] = l
+    save("bert_small", **arrays)
+
+    # bert-base dims (12 x 768, 12 heads, FFN 3072), small vocab table
+    cfg = synth.bert_config(vocab_size=2000)
+    lens = [30, 4, 7, 12, 3, 9]
+    ids, mask = make_ids(len(lens), 30, 2000, lens)
+    w, layers = run(cfg, 1033, ids, mask)
+    arrays = dict(ids=ids, mask=mask, seed=np.array(1033), wsum=checksum(w),
+                  cfg=np.array([cfg["vocab_size"], 768, 12, 12, 3072, 512]))
+    for i in (0, 5, 11):
+        arrays["layer%d" % i] = layers[i]
+    save("bert_base", **arrays)
+
+
+# ----------------------------------------------------------------------------------
+def build_reference_sdnet(opt, bert_cfg, seed):
+    from Models.SDNet import SDNet
+    import Models.Layers as L
+    bw = synth.make_bert_weights(bert_cfg, seed=seed)
+    opt = dict(opt)
+    opt["BERT_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]).clone(),
+           "fast_embedding": T(sw["fast_embed.weight"]).clone()}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing), (missing, unexpected)
+    return net, opt, bw, sw, L
+
+
+def gen_e2e():
+    """SDNet.forward + loss + backward at the shipped conf sizes, bert-base dims."""
+    opt = default_opt(vocab_size=1500)
+    bert_cfg = synth.bert_config(vocab_size=2000)
+    seed = 1033
+    net, opt, bw, sw, L = build_reference_sdnet(opt, bert_cfg, seed)
+    B = 2
+    batch = synth.synthetic_batch(opt, B, seed=7, n_q=30, n_ocr=100, n_od=30, bert_vocab=2000, ragged=True)
+    # one sample at the maximum item counts, one small
+    q, ocr, od, gt, extra = batch
+    print("num_cnt ocr", ocr["num_cnt"], "od", od["num_cnt"])
+
+    caps = {}
+
+    def put(key, t):
+        i = 0
+        while "%s#%d" % (key, i) in caps:
+            i += 1
+        caps["%s#%d" % (key, i)] = t.detach().numpy().copy()
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            if name in ("context_rnn", "ques_rnn"):      # (output, [per-layer outputs])
+                put(name, torch.stack(list(outp[1]), 0))
+            elif name == "deep_attn":                    # (rnn output, pre-rnn concat)
+                put(name, outp[0])
+                put(name + "_pre", outp[1])
+            else:
+                put(name, outp)
+        return fn
+
+    for name in ["multi2one", "context_rnn", "ques_rnn", "high_lvl_ques_rnn", "deep_attn", "highlvl_self_att",
+                 "high_lvl_context_rnn", "od_ocr_attn", "position_attn", "ques_self_attn", "ques_merger",
+                 "get_answer", "pre_align"]:
+        getattr(net, name).register_forward_hook(hook(name))
+    orig_emb = net.get_embedding_from_list
+
+    def emb_wrap(item_list, names, initial):
+        r = orig_emb(item_list, names, initial)
+        i = 0
+        while "embed#%d" % i in caps:
+            i += 1
+        caps["embed#%d" % i] = r.detach().numpy().copy()
+        return r
+    net.get_embedding_from_list = emb_wrap
+
+    # dropout off everywhere (quirk 3 of SURVEY.md: train() would re-enable BERT dropout)
+    L.set_dropout_prob(0.0)
+    net.train()
+    net.Bert.bert_model.eval()
+    net.drop_emb = False
+    scores, _ = net(q, ocr, od)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
+    loss.backward()
+
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(7), B=np.array(B), vocab_size=np.array(1500),
+                  bert_wsum=checksum(bw), sdnet_wsum=checksum(sw),
+                  scores=scores.detach().numpy(), loss=np.array(loss.item()), gt=gt.numpy(),
+                  ocr_num_cnt=np.array(ocr["num_cnt"]), od_num_cnt=np.array(od["num_cnt"]))
+    names, norms = [], []
+    for n_, p in net.named_parameters():
+        if n_.startswith("Bert."):
+            continue
+        names.append(n_)
+        norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+        if p.grad is not None and p.numel() <= 4096:
+            arrays["grad:" + n_] = p.grad.numpy().copy()
+    arrays["grad_names"] = np.array(names)
+    arrays["grad_norms"] = np.array(norms)
+    arrays["grad:fast_embed.weight[:64]"] = net.fast_embed.weight.grad[:64].numpy().copy()
+    # keep the intermediates compact (strided views; the strides are part of the key)
+    for k, v in caps.items():
+        if k.startswith("embed#") and v.shape[1] != opt["max_q_len"]:
+            arrays["cap:" + k + "[:,:4,::8]"] = v[:, :4, ::8].copy()
+        elif k.startswith("embed#"):
+            arrays["cap:" + k + "[:,:,::8]"] = v[..., ::8].copy()
+        elif k.startswith("multi2one#"):      # only the state at each item's last word is consumed
+            lens = np.concatenate([np.array(l) for l in (ocr if k.endswith("#0") else od)["len_cnt"]])
+            arrays["cap:" + k + "[last]"] = v[np.arange(v.shape[0]), lens - 1].copy()
+        elif k.startswith("deep_attn_pre#"):
+            arrays["cap:" + k + "[:,:,::5]"] = v[..., ::5].copy()
+        elif k.startswith("pre_align#"):
+            arrays["cap:" + k + "[:,:,::4]"] = v[..., ::4].copy()
+        else:
+            arrays["cap:" + k] = v
+    save("sdnet_e2e", **arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["layers", "bert", "e2e"]
+    if "layers" in which:
+        gen_layers()
+    if "bert" in which:
+        gen_bert()
+    if "e2e" in which:
+        gen_e2e()
