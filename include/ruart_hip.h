@@ -1,0 +1,147 @@
+/* ruart_hip.h - C ABI of libruart_hip.so (gfx950 / MI355X).
+ *
+ * The reference (xiaojino/RUArt) has no FFI: its hot path is stock PyTorch ops called from Python
+ * (SURVEY.md section 8b).  This header is the boundary one level below the Python drop-in classes
+ * (ruart_amd.SDNet / SDNetTrainer / VQA_collate): one extern "C" launcher per kernel family, each
+ * citing the reference op site it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add to call them from Models/Bert/Bert.py and Models/Layers.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - no allocation, no synchronisation, no host<->device copy inside any entry point: the caller owns
+ *     all buffers and workspaces and passes the hipStream_t (as void*) to launch on; launches are
+ *     graph-capturable;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed check/launch
+ *     (hipErrorInvalidValue = 1 for shape/alignment contract violations);
+ *   - dtype codes: RUART_DT_F32 = 0 (exact fp32 validation path), RUART_DT_BF16 = 1 (production path,
+ *     bf16 storage, fp32 accumulation and fp32 softmax / layer-norm / GELU internals);
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ */
+#ifndef RUART_HIP_H
+#define RUART_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUART_DT_F32 0
+#define RUART_DT_BF16 1
+#define RUART_ACT_NONE 0
+#define RUART_ACT_GELU 1
+#define RUART_ACT_RELU 2
+
+/* library / build info: returns a static string such as "ruart_hip 0.1 gfx950" */
+const char* ruart_version(void);
+
+/* ---- dense projections (reference: nn.Linear sites, Models/Bert/modeling.py:225-227, 261, 287-288, 300;
+ *      Models/Layers.py:226-227 for the fp32 form) --------------------------------------------------------
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
+ * bf16 form: M % 128 == 0, N % 128 == 0, K % 64 == 0 (the caller pads M; BERT's N, K always qualify);
+ *            residual_dtype / out_dtype select bf16 or fp32 storage; GELU and residual are exclusive. */
+int ruart_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
+                       int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, void* stream);
+/* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
+int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
+                      float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* ---- BERT row kernels ------------------------------------------------------------------------------------ */
+/* Models/Bert/modeling.py:185-199: out[r] = LN(word[ids[r]] + pos[pos_ids[r]] + type[0]). */
+int ruart_bert_embed_ln(const int* ids, const int* pos_ids, const float* word_emb, const float* pos_emb, const float* type_emb,
+                        const float* gamma, const float* beta, float eps, void* out, int ldo, int out_dtype, int rows, int H,
+                        void* stream);
+/* Models/Bert/modeling.py:164-168: TF-style layer norm (eps inside the sqrt) of fp32 rows. H % 4 == 0, H <= 1024. */
+int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
+                         int out_dtype, int rows, int H, void* stream);
+/* Models/Bert/modeling.py:234-250 on a packed token stream.  qkv rows are [Q | K | V] (3H wide), Q already
+ * scaled by 1/sqrt(64).  Query block b covers tokens [blk_q0[b], blk_q1[b]) (<= 64) and stages keys
+ * [blk_k0[b], blk_k1[b]); token t attends to keys [tok_lo[t], tok_hi[t]) (its own sequence).  key_bias (may be
+ * NULL) is added to every score of key j (the reference's -10000 for kept-but-masked positions). */
+int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype, int H, int n_heads, int n_blocks,
+                         const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
+                         const int* tok_hi, const float* key_bias, void* stream);
+/* Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: out[dst_row[w]] = sum_l layer_w[l] *
+ * mean(layer_l[span_start[w] .. +span_len[w])).  layers = n_layers matrices [rows, H], layer_stride elements apart.
+ * Rows of `out` that no word maps to are left untouched (the caller zero-fills: masked words are zeros). */
+int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
+                        const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H,
+                        void* stream);
+/* d(loss)/d(layer_w[l]) for the op above; partial_ws holds ceil(n_words/4) * n_layers floats. Deterministic. */
+int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
+                            const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial_ws,
+                            float* grad_layer_w, int n_words, int H, void* stream);
+int ruart_cast_f32_to_bf16(const float* in, void* out, long long n, float scale, void* stream);
+
+/* ---- whole BERT encoder (Models/Bert/modeling.py:585-614, all layer outputs kept as Bert.py:137 needs) ---- */
+typedef struct {
+  int hidden, n_heads, n_layers, intermediate, dtype;
+  float ln_eps;
+  const float *word_emb, *pos_emb, *type_emb, *emb_ln_g, *emb_ln_b;
+  /* host arrays of n_layers device pointers; GEMM weights are [out, in] in `dtype`, biases / LN params fp32 */
+  const void* const* w_qkv;   /* [3H, H], rows = Q (pre-scaled by 1/8) | K | V */
+  const float* const* b_qkv;  /* [3H] (Q part pre-scaled) */
+  const void* const* w_ao;    const float* const* b_ao;
+  const float* const* ln1_g;  const float* const* ln1_b;
+  const void* const* w_ff1;   const float* const* b_ff1;
+  const void* const* w_ff2;   const float* const* b_ff2;
+  const float* const* ln2_g;  const float* const* ln2_b;
+} ruart_bert_model;
+
+typedef struct {
+  int n_tokens;        /* real packed tokens T */
+  int n_rows;          /* padded row count Tp >= T, multiple of 128; ids/pos have Tp entries (pad with 0) */
+  const int* ids;
+  const int* pos_ids;
+  int n_blocks;
+  const int *blk_q0, *blk_q1, *blk_k0, *blk_k1, *tok_lo, *tok_hi;
+  const float* key_bias; /* NULL when every kept token is attendable */
+} ruart_bert_batch;
+
+size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows);
+/* layers_out: [n_layers][n_rows][hidden] in m->dtype.  `m` and `b` are HOST structs. */
+int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---- SDNet kernels (Models/Layers.py) ---------------------------------------------------------------------- */
+/* Layers.py:244 + :275-288 (after the ReLU projections): for each batch b
+ *   S = a[b] (L1 x h) . k[b]^T (L2 x h);  S[:, j] = -inf where mask[b][j] == 0;  P = softmax_j(S);  out = P . v[b]
+ * a = ReLU(x1 W^T) * diag, k = ReLU(x2 W^T) are produced by the caller.  P (B, L1, L2) is saved for backward
+ * when probs != NULL.  fp32. */
+int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, float* out, float* probs, int B,
+                   int L1, int L2, int h, int D3, void* stream);
+/* gradients of the op above: given grad_out (B,L1,D3) and saved P: grad_a (B,L1,h), grad_k (B,L2,h), grad_v (B,L2,D3). */
+int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out, float* grad_a,
+                   float* grad_k, float* grad_v, float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3,
+                   void* stream);
+
+/* Layers.py:167-168: F.layer_norm over the WHOLE tensor of n elements, no affine.  stats[0] = mean, stats[1] = rstd.
+ * ws: 2 * 1024 floats of scratch. */
+int ruart_whole_ln_fwd(const float* x, float* y, float* stats, float* ws, long long n, float eps, void* stream);
+int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, float* grad_x, float* ws, long long n,
+                       void* stream);
+
+/* LSTM recurrence (what Layers.py:166 delegates to nn.LSTM), BOTH directions of one layer per call
+ * (grid = B x ndir), gate order i,f,g,o, zero initial state, padding not masked.
+ *   xproj : (B, T, ndir*4h)  x W_ih^T + b_ih + b_hh, direction d at column offset d*4h (one GEMM by the caller)
+ *   w_hh  : (ndir, 4h, h)
+ *   y     : (B, T, ndir*h)   direction d at column offset d*h; direction 1 runs t = T-1 .. 0
+ *   gates : (B, T, ndir*4h)  post-activation i,f,g,o   } saved for backward when non-NULL
+ *   cells : (B, T, ndir*h)   c_t                       }
+ * h <= 128, ndir in {1, 2}. */
+int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, int B, int T, int h, int ndir,
+                   void* stream);
+/* BPTT for the op above: grad_y (B,T,ndir*h) -> grad_xproj (B,T,ndir*4h) (gradient w.r.t. the gate pre-activations).
+ * grad_W_hh = grad_xproj^T . h_prev, grad_W_ih = grad_xproj^T . x, grad_x = grad_xproj . W_ih are plain GEMMs done
+ * by the caller. */
+int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const float* gates, const float* cells, float* grad_xproj, int B,
+                   int T, int h, int ndir, void* stream);
+
+/* NaN contract of the reference (assert torch.sum(torch.isnan(x)) == 0, Layers.py:169,290,430,462,467): after this
+ * call every SDNet kernel ORs 1 into *flag (a device int) when it writes a NaN; the Python layer checks and clears it
+ * once per step instead of one device->host sync per op.  Pass NULL to disable. */
+int ruart_set_nan_flag(int* flag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,335 @@
+"""BERT contextual encoder on MI355X: packing, C-ABI launch, sub-word pooling + layer mix.
+
+Host-side mirror of the reference's ``Models/Bert/Bert.py`` (class ``Bert``: ``forward`` :56-90,
+``combine_forward`` :130-176) and of the encoder it wraps (``Models/Bert/modeling.py:585-614``).
+Everything numeric happens in libruart_hip.so (include/ruart_hip.h); this file only
+  * fuses / casts the HF-0.x checkpoint tensors once (Q rows pre-scaled by 1/sqrt(64), exact),
+  * packs the valid word pieces of ALL sequences of a step (question + OCR items + object items)
+    into one token stream, so padded slots are never computed (the reference computes 30 slots for
+    items that hold 3-8 pieces),
+  * builds the int32 descriptors the attention and pooling kernels consume.
+
+MI355X-first differences from the reference, all result-preserving:
+  * one encoder pass per training step instead of three (sequences are independent);
+  * the -10000 additive mask becomes "the key does not exist" (exp underflows to exactly 0 in fp32);
+  * the O(items x words) Python pooling loop with a device sync per word is one kernel that also applies
+    the softmax(alpha) * gamma layer mix of ``SDNet.linear_sum`` (Models/SDNet.py:573-581).
+"""
+import ctypes
+from ctypes import c_void_p
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+
+ROW_PAD = 128          # GEMM row granularity (ruart_gemm_bf16_nt: M % 128 == 0)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class BertEncoderWeights:
+    """Device-resident encoder weights in the layout ruart_bert_forward expects."""
+
+    def __init__(self, state, cfg, device, dtype="bf16"):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.dtype = hip.DT_BF16 if dtype in ("bf16", torch.bfloat16) else hip.DT_F32
+        self.tdtype = torch.bfloat16 if self.dtype == hip.DT_BF16 else torch.float32
+        H = cfg["hidden_size"]
+        nh = cfg["num_attention_heads"]
+        if H % nh or H // nh != 64:
+            raise ValueError("ruart_amd BERT kernels are built for head_dim 64 (got hidden %d, heads %d)" % (H, nh))
+        pre = "bert." if any(k.startswith("bert.") for k in state) else ""
+
+        def f32(name):
+            return torch.as_tensor(_np(state[pre + name]), dtype=torch.float32).to(self.device).contiguous()
+
+        def gemm_w(t):
+            return t.to(self.tdtype).contiguous()
+
+        e = "embeddings."
+        self.word_emb = f32(e + "word_embeddings.weight")
+        self.pos_emb = f32(e + "position_embeddings.weight")
+        self.type_emb = f32(e + "token_type_embeddings.weight")
+        self.emb_ln_g = f32(e + "LayerNorm.gamma")
+        self.emb_ln_b = f32(e + "LayerNorm.beta")
+        keys = ["w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2", "ln2_g", "ln2_b"]
+        self.layers = {k: [] for k in keys}
+        scale = 1.0 / 8.0                      # 1/sqrt(head_dim = 64): a power of two, exact in fp32 and bf16
+        for l in range(cfg["num_hidden_layers"]):
+            p = "encoder.layer.%d." % l
+            wq, wk, wv = f32(p + "attention.self.query.weight"), f32(p + "attention.self.key.weight"), f32(p + "attention.self.value.weight")
+            bq, bk, bv = f32(p + "attention.self.query.bias"), f32(p + "attention.self.key.bias"), f32(p + "attention.self.value.bias")
+            L = self.layers
+            L["w_qkv"].append(gemm_w(torch.cat([wq * scale, wk, wv], 0)))
+            L["b_qkv"].append(torch.cat([bq * scale, bk, bv], 0).contiguous())
+            L["w_ao"].append(gemm_w(f32(p + "attention.output.dense.weight")))
+            L["b_ao"].append(f32(p + "attention.output.dense.bias"))
+            L["ln1_g"].append(f32(p + "attention.output.LayerNorm.gamma"))
+            L["ln1_b"].append(f32(p + "attention.output.LayerNorm.beta"))
+            L["w_ff1"].append(gemm_w(f32(p + "intermediate.dense.weight")))
+            L["b_ff1"].append(f32(p + "intermediate.dense.bias"))
+            L["w_ff2"].append(gemm_w(f32(p + "output.dense.weight")))
+            L["b_ff2"].append(f32(p + "output.dense.bias"))
+            L["ln2_g"].append(f32(p + "output.LayerNorm.gamma"))
+            L["ln2_b"].append(f32(p + "output.LayerNorm.beta"))
+        nl = cfg["num_hidden_layers"]
+        self._arrays = {}
+        m = hip.BertModelC()
+        m.hidden, m.n_heads, m.n_layers, m.intermediate = H, nh, nl, cfg["intermediate_size"]
+        m.dtype, m.ln_eps = self.dtype, 1e-12
+        for k in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"):
+            setattr(m, k, getattr(self, k).data_ptr())
+        for k in keys:
+            arr = (c_void_p * nl)(*[t.data_ptr() for t in self.layers[k]])
+            self._arrays[k] = arr
+            setattr(m, k, ctypes.cast(arr, ctypes.POINTER(c_void_p)))
+        self.c_model = m
+
+    @property
+    def hidden(self):
+        return self.cfg["hidden_size"]
+
+    @property
+    def n_layers(self):
+        return self.cfg["num_hidden_layers"]
+
+
+class PackedTokens:
+    """One step's word pieces as a packed stream + the descriptors the kernels need.
+
+    ``groups``: list of (ids (N, L) int64, mask (N, L) bool) CPU tensors - e.g. question, OCR items, object items.
+    ``pack=True`` keeps only mask==1 positions; ``pack=False`` keeps every position and turns the mask into the
+    reference's additive -10000 key bias (exact reference semantics for arbitrary masks)."""
+
+    def __init__(self, groups, device, pack=True):
+        ids_l, pos_l, len_l, bias_l = [], [], [], []
+        self.group_index = []            # per group: (N, L) int32 packed index of each kept position, -1 if dropped
+        base = 0
+        for ids, mask in groups:
+            ids = _np(ids).astype(np.int64)
+            mask = _np(mask).astype(bool)
+            N, L = ids.shape
+            keep = mask if pack else np.ones_like(mask)
+            lens = keep.sum(1).astype(np.int64)
+            if (lens == 0).any():
+                raise ValueError("a BERT input row has no attendable token")
+            flat = keep.reshape(-1)
+            idx = np.full(N * L, -1, dtype=np.int64)
+            idx[flat] = base + np.arange(int(flat.sum()))
+            self.group_index.append(idx.reshape(N, L))
+            ids_l.append(ids.reshape(-1)[flat])
+            pos_l.append(np.broadcast_to(np.arange(L), (N, L)).reshape(-1)[flat])
+            len_l.append(lens)
+            if not pack:
+                bias_l.append(np.where(mask.reshape(-1), 0.0, -10000.0).astype(np.float32))
+            base += int(flat.sum())
+        lens = np.concatenate(len_l)
+        T = int(lens.sum())
+        Tp = (T + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+        cu = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=cu[1:])
+        seq_of = np.repeat(np.arange(len(lens)), lens)
+        blk = self._plan_blocks(lens, cu)
+        nb = blk.shape[1]
+        # one int32 host buffer -> one H2D copy
+        host = np.zeros(2 * Tp + 2 * T + 4 * nb, dtype=np.int32)
+        host[0:T] = np.concatenate(ids_l)
+        host[Tp:Tp + T] = np.concatenate(pos_l)
+        host[2 * Tp:2 * Tp + T] = cu[seq_of]
+        host[2 * Tp + T:2 * Tp + 2 * T] = cu[seq_of + 1]
+        host[2 * Tp + 2 * T:] = blk.reshape(-1)
+        self.T, self.Tp, self.n_blocks = T, Tp, nb
+        self.n_seq = len(lens)
+        self.max_len = int(lens.max())
+        self.sum_len_sq = float((lens.astype(np.float64) ** 2).sum())
+        dev = torch.from_numpy(host).to(device, non_blocking=True)
+        self.buf = dev
+        o = 0
+        self.ids = dev[o:o + Tp]; o += Tp
+        self.pos = dev[o:o + Tp]; o += Tp
+        self.tok_lo = dev[o:o + T]; o += T
+        self.tok_hi = dev[o:o + T]; o += T
+        self.blk = [dev[o + i * nb:o + (i + 1) * nb] for i in range(4)]
+        self.key_bias = None
+        if not pack:
+            self.key_bias = torch.from_numpy(np.concatenate(bias_l)).to(device)
+        b = hip.BertBatchC()
+        b.n_tokens, b.n_rows, b.n_blocks = T, Tp, nb
+        b.ids, b.pos_ids = self.ids.data_ptr(), self.pos.data_ptr()
+        b.blk_q0, b.blk_q1, b.blk_k0, b.blk_k1 = [t.data_ptr() for t in self.blk]
+        b.tok_lo, b.tok_hi = self.tok_lo.data_ptr(), self.tok_hi.data_ptr()
+        b.key_bias = self.key_bias.data_ptr() if self.key_bias is not None else None
+        self.c_batch = b
+
+    @staticmethod
+    def _plan_blocks(lens, cu):
+        """Query blocks of <= 64 tokens made of whole sequences; a sequence longer than 64 is split into
+        64-query chunks that each see the whole sequence as keys.  Returns int array (4, n_blocks):
+        q0, q1, k0, k1."""
+        S = len(lens)
+        out = []
+        s = 0
+        while s < S:
+            if lens[s] > 64:
+                for q0 in range(int(cu[s]), int(cu[s + 1]), 64):
+                    out.append((q0, min(q0 + 64, int(cu[s + 1])), int(cu[s]), int(cu[s + 1])))
+                s += 1
+                continue
+            e = int(np.searchsorted(cu, cu[s] + 64, side="right")) - 1      # last boundary within 64 tokens
+            out.append((int(cu[s]), int(cu[e]), int(cu[s]), int(cu[e])))
+            s = e
+        return np.array(out, dtype=np.int32).T.copy()
+
+
+class _Buffers:
+    """Grow-only device buffers for the encoder (layer outputs + workspace)."""
+
+    def __init__(self):
+        self.layers = None
+        self.ws = None
+
+    def get(self, w, Tp):
+        lib = hip.load()
+        es = 2 if w.dtype == hip.DT_BF16 else 4
+        need_l = w.n_layers * Tp * w.hidden
+        if self.layers is None or self.layers.numel() < need_l:
+            self.layers = torch.zeros(need_l, dtype=w.tdtype, device=w.device)
+        need_w = int(lib.ruart_bert_workspace_bytes(ctypes.byref(w.c_model), Tp))
+        if self.ws is None or self.ws.numel() < need_w:
+            self.ws = torch.zeros(need_w, dtype=torch.uint8, device=w.device)
+        return self.layers[:need_l].view(w.n_layers, Tp, w.hidden), self.ws, need_w
+
+
+_buffers = _Buffers()
+
+
+def bert_encode(weights, packed, buffers=None):
+    """Run the encoder; returns all layer outputs as one (n_layers, Tp, H) tensor in the weights' dtype.
+    The tensor aliases a reusable buffer: consume it before the next call."""
+    lib = hip.load()
+    buffers = buffers or _buffers
+    layers, ws, ws_bytes = buffers.get(weights, packed.Tp)
+    rc = lib.ruart_bert_forward(ctypes.byref(weights.c_model), ctypes.byref(packed.c_batch), hip.ptr(layers), hip.ptr(ws),
+                                ws_bytes, hip.stream_ptr())
+    hip.check(rc, "ruart_bert_forward")
+    return layers
+
+
+class _PoolMix(torch.autograd.Function):
+    """out[dst_row[w]] = sum_l layer_w[l] * mean(layer_l[span]) ; gradient only w.r.t. layer_w (BERT is locked,
+    Models/SDNet.py:91-94)."""
+
+    @staticmethod
+    def forward(ctx, layer_w, layers, span_start, span_len, dst_row, n_rows, dtype_code):
+        lib = hip.load()
+        NL, Tp, H = layers.shape
+        W = span_start.numel()
+        out = torch.zeros(n_rows, H, dtype=torch.float32, device=layers.device)
+        lw = layer_w.detach().to(torch.float32).contiguous()
+        if W > 0:
+            rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_len),
+                                         hip.ptr(dst_row), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
+            hip.check(rc, "ruart_bert_pool_mix")
+        ctx.save_for_backward(layers, span_start, span_len, dst_row)
+        ctx.dtype_code = dtype_code
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = hip.load()
+        layers, span_start, span_len, dst_row = ctx.saved_tensors
+        NL, Tp, H = layers.shape
+        W = span_start.numel()
+        g = torch.zeros(NL, dtype=torch.float32, device=layers.device)
+        if W > 0:
+            grad_out = grad_out.contiguous()
+            partial = torch.empty(((W + 3) // 4) * NL, dtype=torch.float32, device=layers.device)
+            rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_len),
+                                             hip.ptr(dst_row), hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H,
+                                             hip.stream_ptr())
+            hip.check(rc, "ruart_bert_pool_mix_bwd")
+        return g, None, None, None, None, None, None
+
+
+def word_spans(packed, group, offsets, word_mask, offsets_arr=None):
+    """Descriptors for pooling one group: for every (row n, word j) with word_mask[n, j] and a non-empty span
+    [st, ed) (Models/Bert/Bert.py:155-165) -> packed start, length, destination row n * Lw + j.
+    ``offsets`` is the reference's python list [N][words][2]; ``offsets_arr`` an equivalent (N, Lw, 2) int array."""
+    wm = _np(word_mask).astype(bool)
+    N, Lw = wm.shape
+    if offsets_arr is None:
+        offsets_arr = np.zeros((N, Lw, 2), dtype=np.int64)
+        for n, row in enumerate(offsets):
+            if len(row) and not isinstance(row[0], (list, tuple)):
+                continue                                   # the reference's "[1, 1]" for an empty word list
+            k = min(len(row), Lw)
+            if k:
+                offsets_arr[n, :k] = np.asarray(row[:k], dtype=np.int64)
+    offsets_arr = _np(offsets_arr)
+    st, ed = offsets_arr[..., 0], offsets_arr[..., 1]
+    sel = wm & (ed > st)
+    n_idx, j_idx = np.nonzero(sel)
+    gidx = packed.group_index[group]
+    s, e = st[sel], ed[sel]
+    start = gidx[n_idx, s]
+    last = gidx[n_idx, e - 1]
+    if (start < 0).any() or (last - start != e - s - 1).any():
+        raise ValueError("a word's piece span touches a masked BERT position; encode this batch with pack=False")
+    return start.astype(np.int32), (e - s).astype(np.int32), (n_idx * Lw + j_idx).astype(np.int32), N * Lw
+
+
+class Bert(nn.Module):
+    """Drop-in for the reference's ``Bert`` module (Models/Bert/Bert.py:14-45).  ``opt`` keys used:
+    BERT_LARGE, BERT_model_file / BERT_large_model_file, datadir, plus ruart extensions
+    ``bert_precision`` ('bf16' default | 'fp32') and ``bert_state`` / ``bert_config`` to pass weights in memory."""
+
+    def __init__(self, opt, device=None):
+        super().__init__()
+        import json
+        import os
+        self.opt = opt
+        self.linear_combine = "BERT_LINEAR_COMBINE" in opt
+        self.bert_dim, self.bert_layer = (1024, 24) if "BERT_LARGE" in opt else (768, 12)
+        self._device = torch.device(device if device is not None else "cuda")
+        if "bert_state" in opt:
+            state, cfg = opt["bert_state"], opt["bert_config"]
+        else:
+            key = "BERT_large_model_file" if "BERT_LARGE" in opt else "BERT_model_file"
+            d = os.path.join(opt.get("datadir", ""), opt[key])
+            with open(os.path.join(d, "bert_config.json")) as f:
+                cfg = json.load(f)
+            state = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+        if cfg["hidden_size"] != self.bert_dim or cfg["num_hidden_layers"] != self.bert_layer:
+            raise ValueError("BERT checkpoint is %dx%d, conf expects %dx%d" % (cfg["num_hidden_layers"], cfg["hidden_size"],
+                                                                              self.bert_layer, self.bert_dim))
+        self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "bf16"))
+        self.pack = not opt.get("bert_no_pack", False)
+
+    # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
+    def encode(self, groups):
+        packed = PackedTokens(groups, self._device, pack=self.pack)
+        return packed, bert_encode(self.weights, packed)
+
+    def pool_mix(self, packed, layers, group, offsets, word_mask, layer_w, offsets_arr=None):
+        """(N, Lw, H) fp32 = sum_l layer_w[l] * pooled_l  - Bert.py:149-165 + SDNet.py:573-581 in one kernel."""
+        s, n, d, rows = word_spans(packed, group, offsets, word_mask, offsets_arr)
+        dev = self._device
+        desc = torch.from_numpy(np.concatenate([s, n, d])).to(dev)
+        W = len(s)
+        out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, self.weights.dtype)
+        N, Lw = word_mask.shape
+        return out.view(N, Lw, self.weights.hidden)
+
+    # -- reference-compatible call: list of per-layer pooled tensors (Bert.py:56-90, 130-176) -------------
+    def forward(self, x_bert, x_bert_mask, x_bert_offset, x_mask, device=None):
+        packed, layers = self.encode([(x_bert, x_bert_mask)])
+        outs = []
+        eye = torch.eye(self.weights.n_layers, device=self._device)
+        for l in range(self.weights.n_layers):
+            outs.append(self.pool_mix(packed, layers, 0, x_bert_offset, x_mask, eye[l]))
+        return outs

@@ -1,0 +1,77 @@
+// Host-side orchestration of the BERT encoder forward over a packed token stream.
+// Reference path: Models/Bert/modeling.py:585-614 (BertModel.forward) -> :326-334 (all layer outputs kept,
+// because Models/Bert/Bert.py:137 concatenates every layer).  Seven launches per layer, no host sync,
+// no allocation: capturable into a hipGraph by the caller.
+#include "common.h"
+#include "ruart_hip.h"
+
+extern "C" const char* ruart_version(void) { return "ruart_hip 0.1 gfx950"; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+namespace {
+struct Carve {
+  char* base;
+  size_t off;
+  void* take(size_t bytes) {
+    void* p = base + off;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+}  // namespace
+
+extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows) {
+  const size_t es = m->dtype == RUART_DT_BF16 ? 2 : 4;
+  const size_t R = (size_t)n_rows, H = (size_t)m->hidden, I = (size_t)m->intermediate;
+  size_t t = 0;
+  t += align_up(R * H * es, 256);       // x0   embedding output
+  t += align_up(R * 3 * H * es, 256);   // qkv
+  t += align_up(R * H * es, 256);       // ctx
+  t += align_up(R * H * 4, 256);        // pre-LN rows (fp32)
+  t += align_up(R * H * es, 256);       // mid  (post-attention LN)
+  t += align_up(R * I * es, 256);       // ffn
+  return t;
+}
+
+extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  const int H = m->hidden, I = m->intermediate, R = b->n_rows, dt = m->dtype;
+  if (R % 128 || b->n_tokens > R || b->n_tokens <= 0 || H % 64 || m->n_heads * 64 != H) return (int)hipErrorInvalidValue;
+  if (dt == RUART_DT_BF16 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < ruart_bert_workspace_bytes(m, R)) return (int)hipErrorInvalidValue;
+  const size_t es = dt == RUART_DT_BF16 ? 2 : 4;
+  Carve c{(char*)workspace, 0};
+  void* x0 = c.take((size_t)R * H * es);
+  void* qkv = c.take((size_t)R * 3 * H * es);
+  void* ctx = c.take((size_t)R * H * es);
+  float* pre = (float*)c.take((size_t)R * H * 4);
+  void* mid = c.take((size_t)R * H * es);
+  void* ffn = c.take((size_t)R * I * es);
+
+  int rc = ruart_bert_embed_ln(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, m->ln_eps, x0, H,
+                               dt, R, H, stream);
+  if (rc) return rc;
+
+  auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act) {
+    if (dt == RUART_DT_BF16)
+      return ruart_gemm_bf16_nt(A, K, W, K, bias, res, N, RUART_DT_BF16, C, N, out_dt, R, N, K, act, stream);
+    return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, R, N, K, act, stream);
+  };
+
+  const void* in = x0;
+  for (int l = 0; l < m->n_layers; ++l) {
+    void* out = (char*)layers_out + (size_t)l * R * H * es;
+    if ((rc = gemm(in, H, m->w_qkv[l], m->b_qkv[l], nullptr, qkv, dt, 3 * H, RUART_ACT_NONE))) return rc;
+    if ((rc = ruart_bert_attention(qkv, 3 * H, ctx, H, dt, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
+                                   b->tok_lo, b->tok_hi, b->key_bias, stream)))
+      return rc;
+    if ((rc = gemm(ctx, H, m->w_ao[l], m->b_ao[l], in, pre, RUART_DT_F32, H, RUART_ACT_NONE))) return rc;
+    if ((rc = ruart_rows_layernorm(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid, H, dt, R, H, stream))) return rc;
+    if ((rc = gemm(mid, H, m->w_ff1[l], m->b_ff1[l], nullptr, ffn, dt, I, RUART_ACT_GELU))) return rc;
+    if ((rc = gemm(ffn, I, m->w_ff2[l], m->b_ff2[l], mid, pre, RUART_DT_F32, H, RUART_ACT_NONE))) return rc;
+    if ((rc = ruart_rows_layernorm(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, H, dt, R, H, stream))) return rc;
+    in = out;
+  }
+  return 0;
+}

@@ -1,0 +1,373 @@
+// Row-wise (HBM-bound) kernels of the BERT encoder path.
+//
+//   ruart_bert_embed_ln      Models/Bert/modeling.py:185-199  word+position+type gather, sum, LayerNorm
+//   ruart_rows_layernorm     Models/Bert/modeling.py:164-168  TF-style LN (eps inside sqrt) of the fp32
+//                            "dense + bias + residual" rows written by the GEMM epilogue (:263, :302)
+//   ruart_bert_attention     Models/Bert/modeling.py:234-250  scores/sqrt(d) + mask, softmax, P.V per head,
+//                            variable-length: padded tokens do not exist in the packed stream
+//   ruart_bert_pool_mix      Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: per-word mean over its
+//                            word-piece span of ALL layers, mixed with softmax(alpha)*gamma, in one pass
+//   ruart_bert_pool_mix_bwd  gradient of that mix w.r.t. the per-layer weights (alpha/gamma are trainable)
+//
+// All math is fp32; storage type T of activations is float (validation mode) or bf16.
+#include "common.h"
+#include "ruart_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// one wave per row; lane owns float4 groups at columns (i*64 + lane)*4, i < H/256 (H % 4 == 0, H <= 1024)
+// ---------------------------------------------------------------------------------------------
+#define MAXG 4
+
+template <typename TOut>
+__device__ __forceinline__ void ln_row_finish(f32x4_t (&v)[MAXG], int H, int lane, const float* gamma, const float* beta,
+                                              float eps, TOut* out) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[i][r] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const f32x4_t g = load4(gamma + c), b = load4(beta + c);
+      f32x4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = g[r] * ((v[i][r] - mean) * rstd) + b[r];
+      store4(out + c, o);
+    }
+  }
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void rows_layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, TOut* __restrict__ out,
+                                                             int ldo, int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4_t v[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = (c < H) ? load4(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  ln_row_finish<TOut>(v, H, lane, gamma, beta, eps, out + (size_t)row * ldo);
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
+                                                       const float* __restrict__ word, const float* __restrict__ ptab,
+                                                       const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, TOut* __restrict__ out, int ldo,
+                                                       int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t wi = (size_t)ids[row] * H, pi = (size_t)pos[row] * H;
+  f32x4_t v[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      // (word + position) + type, in the reference's order (modeling.py:196)
+      v[i] = (load4(word + wi + c) + load4(ptab + pi + c)) + load4(type0 + c);
+    } else {
+      v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  ln_row_finish<TOut>(v, H, lane, gamma, beta, eps, out + (size_t)row * ldo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variable-length self-attention, head_dim 64.  One wave per (query block, head); lane = one query token.
+// A query block is <= 64 consecutive packed tokens [q0, q1) and a key range [k0, k1) that covers every
+// sequence touching the block (host-built, sequence-aligned).  Each lane walks only the keys of ITS
+// sequence [tok_lo, tok_hi): trip count = longest sequence in the block, not the block width, so tiny
+// OCR items (3-8 word pieces) cost 3-8 iterations.  K/V rows live in LDS, row stride padded by 16 B so
+// that lanes reading different rows at the same column hit different banks; lanes of one sequence read
+// the same row (broadcast).  Online softmax in registers; Q is pre-scaled by 1/sqrt(64) (folded into
+// the Q projection weights, exact in binary).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct KVRow {
+  static constexpr int kStride = 64 * (int)sizeof(T) + 16;   // bytes
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ ctx, int ldc, int H,
+                                                         const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                         const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                         const int* __restrict__ tok_lo, const int* __restrict__ tok_hi,
+                                                         const float* __restrict__ key_bias) {
+  constexpr int RS = KVRow<T>::kStride;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * RS];
+  const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
+  const int t = q0 + lane;
+  const bool active = t < q1;
+  float q[64];
+  {
+    const T* qp = qkv + (size_t)(active ? t : q0) * ld + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4_t v = load4(qp + d);
+      q[d] = v[0]; q[d + 1] = v[1]; q[d + 2] = v[2]; q[d + 3] = v[3];
+    }
+  }
+  const int lo = active ? tok_lo[t] : 0, hi = active ? tok_hi[t] : 0;
+  float m = -1e30f, l = 0.f;
+  float acc[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+
+  for (int kt = k0; kt < k1; kt += 64) {
+    const int tn = min(64, k1 - kt);
+    __syncthreads();
+    if (lane < tn) {
+      const T* kp = qkv + (size_t)(kt + lane) * ld + H + h * 64;
+      const T* vp = kp + H;
+      constexpr int CH = 16 / (int)sizeof(T);     // elements per 16-byte chunk
+#pragma unroll
+      for (int c = 0; c < 64 / CH; ++c) {
+        *reinterpret_cast<uint4*>(Ks + lane * RS + c * 16) = *reinterpret_cast<const uint4*>(kp + c * CH);
+        *reinterpret_cast<uint4*>(Vs + lane * RS + c * 16) = *reinterpret_cast<const uint4*>(vp + c * CH);
+      }
+    }
+    __syncthreads();
+    const int jlo = max(lo, kt), jhi = min(hi, kt + tn);
+    const int mine = max(0, jhi - jlo);
+    int n_it = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_it = max(n_it, __shfl_xor(n_it, o, 64));
+    for (int it = 0; it < n_it; ++it) {
+      const bool valid = it < mine;
+      const int j = valid ? (jlo + it) : kt;
+      const T* kr = reinterpret_cast<const T*>(Ks + (j - kt) * RS);
+      const T* vr = reinterpret_cast<const T*>(Vs + (j - kt) * RS);
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; d += 4) {
+        const f32x4_t kv = load4(kr + d);
+        s = fmaf(q[d], kv[0], s); s = fmaf(q[d + 1], kv[1], s); s = fmaf(q[d + 2], kv[2], s); s = fmaf(q[d + 3], kv[3], s);
+      }
+      if (key_bias) s += key_bias[j];
+      const float mn = valid ? fmaxf(m, s) : m;
+      const float sc = __expf(m - mn);
+      const float p = valid ? __expf(s - mn) : 0.f;
+      m = mn;
+      l = l * sc + p;
+#pragma unroll
+      for (int d = 0; d < 64; d += 4) {
+        const f32x4_t vv = load4(vr + d);
+        acc[d] = fmaf(p, vv[0], acc[d] * sc); acc[d + 1] = fmaf(p, vv[1], acc[d + 1] * sc);
+        acc[d + 2] = fmaf(p, vv[2], acc[d + 2] * sc); acc[d + 3] = fmaf(p, vv[3], acc[d + 3] * sc);
+      }
+    }
+  }
+  if (active) {
+    const float inv = 1.0f / l;
+    T* op = ctx + (size_t)t * ldc + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4_t o = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
+      store4(op + d, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sub-word pooling fused with the layer mix.  One wave per word.
+//   out[dst_row[w]][:] = sum_l wl[l] * mean_{p in [start, start+len)} layer_l[p][:]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
+                                                       const int* __restrict__ span_start, const int* __restrict__ span_len,
+                                                       const int* __restrict__ dst_row, const float* __restrict__ wl,
+                                                       float* __restrict__ out, int ldo, int W, int H) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= W) return;
+  const int st = span_start[w], n = span_len[w];
+  f32x4_t acc[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float fn = (float)n;
+  for (int l = 0; l < NL; ++l) {
+    const float wgt = wl[l];
+    const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        f32x4_t s = load4(base + c);
+        for (int p = 1; p < n; ++p) s += load4(base + (size_t)p * ldl + c);
+        if (n > 1) s = s / fn;
+        acc[i] += s * wgt;
+      }
+    }
+  }
+  float* o = out + (size_t)dst_row[w] * ldo;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) store4(o + c, acc[i]);
+  }
+}
+
+#define POOL_MAX_LAYERS 32
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
+                                                           const int* __restrict__ span_start, const int* __restrict__ span_len,
+                                                           const int* __restrict__ dst_row, const float* __restrict__ gout, int ldg,
+                                                           float* __restrict__ partial, int W, int H) {
+  __shared__ float red[4][POOL_MAX_LAYERS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * 4 + wv;
+  float mine[POOL_MAX_LAYERS];
+#pragma unroll
+  for (int l = 0; l < POOL_MAX_LAYERS; ++l) mine[l] = 0.f;
+  if (w < W) {
+    const int st = span_start[w], n = span_len[w];
+    const float fn = (float)n;
+    const float* g = gout + (size_t)dst_row[w] * ldg;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        const f32x4_t gv = load4(g + c);
+#pragma unroll
+        for (int l = 0; l < POOL_MAX_LAYERS; ++l) {
+          if (l < NL) {
+            const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+            f32x4_t s = load4(base + c);
+            for (int p = 1; p < n; ++p) s += load4(base + (size_t)p * ldl + c);
+            if (n > 1) s = s / fn;
+            mine[l] += s[0] * gv[0] + s[1] * gv[1] + s[2] * gv[2] + s[3] * gv[3];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < POOL_MAX_LAYERS; ++l) {
+    if (l < NL) {
+      const float s = wave_sum(mine[l]);
+      if (lane == 0) red[wv][l] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NL) partial[(size_t)blockIdx.x * NL + threadIdx.x] =
+      red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int NL, float* __restrict__ out) {
+  // one wave per layer weight; fixed summation order => bitwise reproducible
+  const int l = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * NL + l];
+  s = wave_sum(s);
+  if (lane == 0) out[l] = s;
+}
+
+template <typename TIn, typename TOut>
+__global__ void cast_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n4, float scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t v = load4(in + i * 4);
+    store4(out + i * 4, v * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
+                                    int out_dtype, int rows, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldx & 3) || (ldo & 3)) return (int)hipErrorInvalidValue;
+  const dim3 grid(ceil_div(rows, 4)), block(256);
+  if (out_dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL(rows_layernorm_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (bf16_t*)out, ldo, rows, H);
+  else
+    hipLaunchKernelGGL(rows_layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (float*)out, ldo, rows, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_embed_ln(const int* ids, const int* pos, const float* word_emb, const float* pos_emb,
+                                   const float* type_emb, const float* gamma, const float* beta, float eps, void* out, int ldo,
+                                   int out_dtype, int rows, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldo & 3)) return (int)hipErrorInvalidValue;
+  const dim3 grid(ceil_div(rows, 4)), block(256);
+  if (out_dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb, gamma, beta, eps, (bf16_t*)out, ldo, rows, H);
+  else
+    hipLaunchKernelGGL(embed_ln_kernel<float>, grid, block, 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb, gamma, beta, eps, (float*)out, ldo, rows, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype, int H, int n_heads, int n_blocks,
+                                    const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1,
+                                    const int* tok_lo, const int* tok_hi, const float* key_bias, void* stream) {
+  if (n_heads * 64 != H || n_blocks <= 0) return (int)hipErrorInvalidValue;
+  const dim3 grid(n_blocks, n_heads), block(64);
+  if (dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL(attn_varlen_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+  else
+    hipLaunchKernelGGL(attn_varlen_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
+                                   const int* span_start, const int* span_len, const int* dst_row, const float* layer_w,
+                                   float* out, int ldo, int n_words, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
+  const dim3 grid(ceil_div(n_words, 4)), block(256);
+  if (dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL(pool_mix_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+  else
+    hipLaunchKernelGGL(pool_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
+                                       const int* span_start, const int* span_len, const int* dst_row, const float* grad_out,
+                                       int ldg, float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
+  const int nb = ceil_div(n_words, 4);
+  const dim3 grid(nb), block(256);
+  if (dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL(pool_mix_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+  else
+    hipLaunchKernelGGL(pool_mix_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+  RUART_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(64), 0, (hipStream_t)stream, partial_ws, nb, n_layers, grad_layer_w);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_cast_f32_to_bf16(const float* in, void* out, long long n, float scale, void* stream) {
+  if (n % 4) return (int)hipErrorInvalidValue;
+  const size_t n4 = (size_t)n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n4, scale);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  Wave width is 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define RUART_DT_F32 0
+#define RUART_DT_BF16 1
+
+#define RUART_CHECK_LAUNCH() \
+  do {                       \
+    hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) return (int)e_; \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 64 * NW; `red` is NW floats of LDS.  All threads get the result.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  if (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---- typed 4-element row access (float or bf16 storage, fp32 math) ----
+__device__ __forceinline__ f32x4_t load4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
+  bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4_t v) {
+  bf16x4_t r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  *reinterpret_cast<bf16x4_t*>(p) = r;
+}
+
+// XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 T1, bijective form):
+// ids that share `id % 8` run on one XCD; give each XCD a contiguous chunk of the logical grid
+// so that neighbouring tiles (which share an operand panel) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,267 @@
+// Dense projections  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]) [+ residual[M,N]]
+//
+// Replaces the nn.Linear sites of the reference's BERT encoder
+//   Models/Bert/modeling.py:225-227 (Q,K,V), :261 (attention output dense),
+//   :287-288 (intermediate dense + erf-GELU), :300 (output dense)
+// with fused bias / GELU / residual epilogues (the residual add of :263 / :302 is folded in;
+// the layer-norm itself is ruart_rows_layernorm).  Both operands are K-contiguous ("NT"),
+// which is exactly the torch nn.Linear weight layout, so checkpoints load without a transpose.
+//
+//  * gemm_bf16_nt_128: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//    128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
+//    LDS tiles are [128 rows][64 k] bf16 with the 16-byte chunk index XOR-swizzled by (row & 7),
+//    which makes every ds_read_b128 fragment read conflict-free (cdna_hip_programming.md T2).
+//    Register-staged double buffering: global loads for tile t+1 are issued before the MFMAs of
+//    tile t and written to the other LDS buffer after them (T14 issue-early / write-late).
+//    The MFMA is issued with W as the "A" operand and the activations as "B", so each lane ends
+//    up with 4 consecutive output columns of one row -> 8/16-byte epilogue stores.
+//    Workgroup ids are remapped XCD-aware with the N tile fastest, so the workgroups that share an
+//    activation panel run on one XCD's L2.
+//  * gemm_f32_nt_64: exact-fp32 path on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), any M,N,K,
+//    used for the fp32 validation mode and the small SDNet projections.
+#include "common.h"
+#include "ruart_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+template <bool OUT_F32, int RES /*0 none, 1 bf16, 2 f32*/, int ACT /*0 none 1 gelu*/>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_128(const bf16_t* __restrict__ A, int lda,
+                                                        const bf16_t* __restrict__ W, int ldw,
+                                                        const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                        void* __restrict__ C, int ldc, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int nwg = gridDim.x;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  constexpr int kStage = (BM + BN) * BK * 2;     // bytes per pipeline stage: A tile then W tile
+
+  // staging assignment: 1024 chunks of 16 B per operand tile, 4 per thread
+  int srow[4], sch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i;
+    srow[i] = q >> 3;
+    sch[i] = q & 7;
+  }
+  const bf16_t* Ag = A + (size_t)m0 * lda;
+  const bf16_t* Wg = W + (size_t)n0 * ldw;
+
+  uint4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const uint4*>(Ag + (size_t)srow[i] * lda + k0 + sch[i] * 8);
+      rb[i] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[i] * ldw + k0 + sch[i] * 8);
+    }
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(smem + buf * kStage + lds_off(srow[i], sch[i])) = ra[i];
+      *reinterpret_cast<uint4*>(smem + buf * kStage + BM * BK * 2 + lds_off(srow[i], sch[i])) = rb[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / BK;
+  gload(0);
+  lwrite(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) gload((t + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const bf16x8_t*>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        af[i] = *reinterpret_cast<const bf16x8_t*>(smem + cur * kStage + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) lwrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][r] = C[m = m0+wm*64+j*16+fr][n = n0+wn*64+i*16+fq*4+r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      f32x4_t v = acc[i][j] + bv;
+      if (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      }
+      if (RES == 1) v += load4(reinterpret_cast<const bf16_t*>(R) + (size_t)m * ldr + n);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
+      else
+        store4(reinterpret_cast<bf16_t*>(C) + (size_t)m * ldc + n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32 path: 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
+// ------------------------------------------------------------------------------------------------
+#define FBM 64
+#define FBN 64
+#define FBK 16
+#define FLD 17   // padded LDS row stride (floats): (17 r + k) mod 32 is conflict-free for ds_read_b32
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_nt_64(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                                      float* __restrict__ C, int ldc, int M, int N, int K, int act) {
+  __shared__ float As[FBM * FLD];
+  __shared__ float Bs[FBN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (N + FBN - 1) / FBN;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (id / ntn) * FBM, n0 = (id % ntn) * FBN;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;       // staging: row 0..63, k 0/4/8/12
+
+  auto gload = [&](const float* P, int ld, int row, int rows, int k0, float (&v)[4]) {
+    const int kk = k0 + lk;
+    if (row < rows) {
+      const float* p = P + (size_t)row * ld + kk;
+      if (VEC && kk + 3 < K) {
+        f32x4_t t = *reinterpret_cast<const f32x4_t*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (kk + i < K) ? p[i] : 0.f;
+      }
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+    }
+  };
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  float ra[4], rb[4];
+  gload(A, lda, m0 + lr, M, 0, ra);
+  gload(W, ldw, n0 + lr, N, 0, rb);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nt = (K + FBK - 1) / FBK;
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[lr * FLD + lk + i] = ra[i];
+      Bs[lr * FLD + lk + i] = rb[i];
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      gload(A, lda, m0 + lr, M, (t + 1) * FBK, ra);
+      gload(W, ldw, n0 + lr, N, (t + 1) * FBK, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float wf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i] = Bs[(wn * 32 + i * 16 + fr) * FLD + kk * 4 + fq];
+        af[i] = As[(wm * 32 + i * 16 + fr) * FLD + kk * 4 + fq];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wn * 32 + i * 16 + fq * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 32 + j * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= N) continue;
+        float v = acc[i][j][r];
+        if (bias) v += bias[n + r];
+        if (act == 1) v = gelu_erf(v);
+        else if (act == 2) v = fmaxf(v, 0.f);
+        if (R) v += R[(size_t)m * ldr + n + r];
+        C[(size_t)m * ldc + n + r] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ruart_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
+                                  int ldr, int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
+                                  void* stream) {
+  if (M % BM || N % BN || K % BK || (lda & 7) || (ldw & 7) || (ldc & 3)) return (int)hipErrorInvalidValue;
+  if (act != RUART_ACT_NONE && act != RUART_ACT_GELU) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((M / BM) * (N / BN)), block(256);
+  const int res = residual ? (residual_dtype == RUART_DT_BF16 ? 1 : 2) : 0;
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+#define LAUNCH(OF, RS, AC) \
+  hipLaunchKernelGGL((gemm_bf16_nt_128<OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K)
+  const bool of = out_dtype == RUART_DT_F32;
+  if (act == RUART_ACT_GELU) {
+    if (res != 0) return (int)hipErrorInvalidValue;
+    if (of) LAUNCH(true, 0, 1); else LAUNCH(false, 0, 1);
+  } else if (res == 0) {
+    if (of) LAUNCH(true, 0, 0); else LAUNCH(false, 0, 0);
+  } else if (res == 1) {
+    if (of) LAUNCH(true, 1, 0); else LAUNCH(false, 1, 0);
+  } else {
+    if (of) LAUNCH(true, 2, 0); else LAUNCH(false, 2, 0);
+  }
+#undef LAUNCH
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,
+                                 int ldr, float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ceil_div(M, FBM) * ceil_div(N, FBN)), block(256);
+  const bool vec = (lda % 4 == 0) && (ldw % 4 == 0) && ((((uintptr_t)A) | ((uintptr_t)W)) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((gemm_f32_nt_64<true>), grid, block, 0, s, A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act);
+  else
+    hipLaunchKernelGGL((gemm_f32_nt_64<false>), grid, block, 0, s, A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,374 @@
+// Fused masked cross-attention of the SDNet trunk (fp32, exact-fp32 MFMA).
+//
+// Reference: Models/Layers.py:244 (scores = x1_rep.bmm(x2_rep^T)), :275-276 (masked_fill -inf on keys),
+// :284-288 (softmax over keys, alpha.bmm(x3)).  10 call sites per forward:
+// pre-align x2, deep_attn 3x2, self-attention x2, od_ocr_attn, position_attn, ques_self_attn.
+// The ReLU projections a = ReLU(x1 W^T) * diag and k = ReLU(x2 W^T) (Layers.py:226-231) are plain GEMMs done
+// by the caller; this file is score / softmax / context and their gradients.
+//
+// Forward: one workgroup (4 waves) per (batch, 16 query rows).  The 16 x h query tile and the L2 x h key panel are
+// staged through LDS in 64-wide chunks of h and multiplied with v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain);
+// the 16 x L2 score tile never leaves LDS: masked softmax with 16 lanes per row (shuffle reductions), then the
+// probabilities are the A operand of the context product against the value panel staged in LDS.
+// LDS row strides are chosen so every MFMA operand read is bank-conflict free:
+//   A-type reads  [(lane&15) * ld + 4*kk + (lane>>4)]  want ld % 32 == 2,
+//   B-type reads  [(4*kk + (lane>>4)) * ld + (lane&15)] want ld % 32 == 16.
+// Backward: kernel A per (batch, 16 query rows): dP = gO . v^T, dS = P * (dP - rowsum(dP * P)), grad_a = dS . k;
+// kernel B per (batch, 16 key rows): grad_k = dS^T . a, grad_v = P^T . gO.  No atomics, deterministic.
+#include "common.h"
+#include "ruart_hip.h"
+
+#define CH 64          // chunk of the contraction / output dimension staged per pass
+#define LDA_ 66        // A-type stride for a 64-wide chunk   (66 % 32 == 2)
+#define LDB_ 80        // B-type stride for a 64-wide chunk   (80 % 32 == 16)
+
+int* ruart_nan_flag_ptr = nullptr;   // host copy of the device flag address, passed to kernels as an argument
+
+__device__ __forceinline__ f32x4_t mma16(const float* As, int lda, const float* Bs, int sbk, int sbj, int Kc, f32x4_t acc) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  for (int kk = 0; kk < Kc; kk += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[r * lda + kk + q], Bs[(kk + q) * sbk + r * sbj], acc, 0, 0, 0);
+  return acc;
+}
+
+// stage rows [r0, r0+nr) x cols [c0, c0+CH) of a row-major (rows x cols, ld) matrix into dst[nr_pad][ldd], zero-filled
+__device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols) {
+  for (int e = threadIdx.x; e < nr_pad * CH; e += blockDim.x) {
+    const int r = e / CH, c = e % CH;
+    const int gr = r0 + r, gc = c0 + c;
+    dst[r * ldd + c] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+  }
+}
+// same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
+__device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols) {
+  for (int e = threadIdx.x; e < 16 * CH; e += blockDim.x) {
+    const int c = e & 15, r = e >> 4;          // c: 16 source columns (fast), r: 64 source rows
+    const int gr = r0 + r, gc = c0 + c;
+    dst[c * ldd + r] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+  }
+}
+
+__device__ __forceinline__ int lds_probs_stride(int L2p) { return ((L2p + 31) / 32) * 32 + 2; }
+
+// ------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) float dsm[];
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                       float* __restrict__ out, float* __restrict__ probs, int L1, int L2, int h,
+                                                       int D3, int* __restrict__ nan_flag) {
+  const int b = blockIdx.y, i0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
+  float* a_s = dsm;                       // [16][LDA_]
+  float* S_s = a_s + 16 * LDA_;           // [16][ldS]
+  float* kv_s = S_s + 16 * ldS;           // [L2p][LDB_]  (keys use stride LDA_, values LDB_)
+  const float* ab = a + (size_t)b * L1 * h;
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  const int ntile = L2p / 16;
+
+  // ---- scores: S[16][L2p] = a_tile . k^T, accumulated over chunks of h
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < h; c0 += CH) {
+    __syncthreads();
+    stage(a_s, LDA_, 16, ab, h, i0, L1, c0, h);
+    stage(kv_s, LDA_, L2p, kb, h, 0, L2, c0, h);
+    __syncthreads();
+    const int kc = min(CH, (h - c0 + 3) & ~3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jt = wave + 4 * t;
+      if (jt < ntile) acc[t] = mma16(a_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S_s[((lane >> 4) * 4 + r) * ldS + jt * 16 + (lane & 15)] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  // ---- masked softmax: 16 lanes per row
+  {
+    const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const unsigned char* mb = mask + (size_t)b * L2;
+    float* Sr = S_s + row * ldS;
+    float mx = -INFINITY;
+    for (int j = c; j < L2; j += 16) {
+      const float s = mb[j] ? Sr[j] : -INFINITY;
+      Sr[j] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = c; j < L2; j += 16) {
+      const float e = expf(Sr[j] - mx);     // all keys masked => -inf - -inf = NaN, as the reference (Layers.py:290 asserts)
+      Sr[j] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    const bool live = (i0 + row) < L1;
+    bool bad = false;
+    for (int j = c; j < L2p; j += 16) {
+      const float p = (j < L2) ? Sr[j] * inv : 0.f;
+      Sr[j] = live ? p : 0.f;
+      bad |= live && !(p == p);
+      if (probs && live && j < L2) probs[((size_t)b * L1 + i0 + row) * L2 + j] = p;
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+  }
+  // ---- context: out[16][D3] = P . v, 64 output columns per pass (one 16-col tile per wave)
+  for (int d0 = 0; d0 < D3; d0 += CH) {
+    __syncthreads();
+    stage(kv_s, LDB_, L2p, vb, D3, 0, L2, d0, D3);
+    __syncthreads();
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    o = mma16(S_s, ldS, kv_s + wave * 16, LDB_, 1, L2p, o);
+    const int d = d0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + (lane >> 4) * 4 + r;
+      if (i < L1 && d < D3) out[((size_t)b * L1 + i) * D3 + d] = o[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward A: per (batch, 16 query rows)
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                         const float* __restrict__ probs, const float* __restrict__ gout,
+                                                         float* __restrict__ grad_a, float* __restrict__ dS, int L1, int L2, int h,
+                                                         int D3) {
+  const int b = blockIdx.y, i0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
+  float* g_s = dsm;                       // [16][LDA_]   grad_out chunk
+  float* S_s = g_s + 16 * LDA_;           // [16][ldS]    dP then dS
+  float* kv_s = S_s + 16 * ldS;           // [L2p][LDB_]
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  const float* gb = gout + (size_t)b * L1 * D3;
+  const int ntile = L2p / 16;
+
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < D3; c0 += CH) {     // dP = gO . v^T
+    __syncthreads();
+    stage(g_s, LDA_, 16, gb, D3, i0, L1, c0, D3);
+    stage(kv_s, LDA_, L2p, vb, D3, 0, L2, c0, D3);
+    __syncthreads();
+    const int kc = min(CH, (D3 - c0 + 3) & ~3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int jt = wave + 4 * t;
+      if (jt < ntile) acc[t] = mma16(g_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S_s[((lane >> 4) * 4 + r) * ldS + jt * 16 + (lane & 15)] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const bool live = (i0 + row) < L1;
+    const float* Pr = probs + ((size_t)b * L1 + (live ? i0 + row : 0)) * L2;
+    float* Sr = S_s + row * ldS;
+    float dot = 0.f;
+    for (int j = c; j < L2; j += 16) dot += Sr[j] * Pr[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    for (int j = c; j < L2p; j += 16) {
+      float d = 0.f;
+      if (live && j < L2) {
+        const float p = Pr[j];
+        d = p * (Sr[j] - dot);
+        dS[((size_t)b * L1 + i0 + row) * L2 + j] = d;
+      }
+      Sr[j] = d;
+    }
+  }
+  for (int d0 = 0; d0 < h; d0 += CH) {      // grad_a = dS . k
+    __syncthreads();
+    stage(kv_s, LDB_, L2p, kb, h, 0, L2, d0, h);
+    __syncthreads();
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    o = mma16(S_s, ldS, kv_s + wave * 16, LDB_, 1, L2p, o);
+    const int d = d0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + (lane >> 4) * 4 + r;
+      if (i < L1 && d < h) grad_a[((size_t)b * L1 + i) * h + d] = o[r];
+    }
+  }
+}
+
+// backward B: per (batch, 16 key rows): C[16 j][N] = X^T . Y with X (L1 x L2) in {dS, P}, Y (L1 x N) in {a, gO}
+__device__ __forceinline__ void tn_product(const float* X, int L1, int L2, int j0, const float* Y, int N, float* C, float* xt_s,
+                                           float* y_s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n0 = 0; n0 < N; n0 += CH) {
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < L1; r0 += CH) {
+      __syncthreads();
+      stage_t16(xt_s, LDA_, X, L2, r0, L1, j0, L2);     // xt_s[j][i]
+      stage(y_s, LDB_, CH, Y, N, r0, L1, n0, N);         // y_s[i][n]
+      __syncthreads();
+      const int kc = min(CH, (L1 - r0 + 3) & ~3);
+      o = mma16(xt_s, LDA_, y_s + wave * 16, LDB_, 1, kc, o);
+    }
+    const int n = n0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + (lane >> 4) * 4 + r;
+      if (j < L2 && n < N) C[(size_t)j * N + n] = o[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ a, const float* __restrict__ probs,
+                                                          const float* __restrict__ dS, const float* __restrict__ gout,
+                                                          float* __restrict__ grad_k, float* __restrict__ grad_v, int L1, int L2, int h,
+                                                          int D3) {
+  const int b = blockIdx.y, j0 = blockIdx.x * 16;
+  float* xt_s = dsm;                   // [16][LDA_]
+  float* y_s = xt_s + 16 * LDA_;       // [CH][LDB_]
+  const size_t pb = (size_t)b * L1 * L2;
+  tn_product(dS + pb, L1, L2, j0, a + (size_t)b * L1 * h, h, grad_k + (size_t)b * L2 * h, xt_s, y_s);
+  tn_product(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-tensor layer norm (Layers.py:167-168): mean / biased variance over ALL n elements, no affine.
+// Two-pass (mean, then centred sum of squares) with fixed-order partials => deterministic.
+// ------------------------------------------------------------------------------------------------
+#define WLN_BLOCKS 256
+__device__ __forceinline__ float grid_partial_total(const float* part, float* red) {
+  // every block re-reduces the WLN_BLOCKS partials in the same order
+  float s = (threadIdx.x < WLN_BLOCKS) ? part[threadIdx.x] : 0.f;
+  return block_sum<4>(s, red);
+}
+
+__global__ __launch_bounds__(256) void wln_sum_kernel(const float* __restrict__ x, const float* __restrict__ x2, long long n,
+                                                      float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f, t = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+    const float a = x[i];
+    s += a;
+    if (x2) t += a * x2[i];
+  }
+  s = block_sum<4>(s, red);
+  if (x2) t = block_sum<4>(t, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    if (x2) part[WLN_BLOCKS + blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(256) void wln_var_kernel(const float* __restrict__ x, long long n, const float* __restrict__ part,
+                                                      float* __restrict__ part2) {
+  __shared__ float red[4];
+  const float mean = grid_partial_total(part, red) / (float)n;
+  float q = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+    const float d = x[i] - mean;
+    q += d * d;
+  }
+  q = block_sum<4>(q, red);
+  if (threadIdx.x == 0) part2[blockIdx.x] = q;
+}
+__global__ __launch_bounds__(256) void wln_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float eps,
+                                                        const float* __restrict__ part, const float* __restrict__ part2,
+                                                        float* __restrict__ stats, int* __restrict__ nan_flag) {
+  __shared__ float red[4];
+  const float mean = grid_partial_total(part, red) / (float)n;
+  const float var = grid_partial_total(part2, red) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[0] = mean;
+    stats[1] = rstd;
+  }
+  bool bad = false;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+    const float o = (x[i] - mean) * rstd;
+    y[i] = o;
+    bad |= !(o == o);
+  }
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+__global__ __launch_bounds__(256) void wln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                      const float* __restrict__ stats, float* __restrict__ gx, long long n,
+                                                      const float* __restrict__ part) {
+  __shared__ float red[4];
+  const float mg = grid_partial_total(part, red) / (float)n;                 // mean(gy)
+  const float mgy = grid_partial_total(part + WLN_BLOCKS, red) / (float)n;   // mean(gy * y)
+  const float rstd = stats[1];
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) gx[i] = rstd * (gy[i] - mg - y[i] * mgy);
+}
+
+// ------------------------------------------------------------------------------------------------
+static size_t attn_lds_bytes(int L2) {
+  const int L2p = (L2 + 15) & ~15;
+  const int ldS = ((L2p + 31) / 32) * 32 + 2;
+  return sizeof(float) * (size_t)(16 * LDA_ + 16 * ldS + L2p * LDB_);
+}
+
+extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, float* out, float* probs,
+                              int B, int L1, int L2, int h, int D3, void* stream) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  const dim3 grid(ceil_div(L1, 16), B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3, ruart_nan_flag_ptr);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
+                              float* grad_a, float* grad_k, float* grad_v, float* ds_ws, int B, int L1, int L2, int h, int D3,
+                              void* stream) {
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
+                     grad_out, grad_a, ds_ws, L1, L2, h, D3);
+  RUART_CHECK_LAUNCH();
+  const size_t lds = sizeof(float) * (16 * LDA_ + CH * LDB_);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
+                     grad_k, grad_v, L1, L2, h, D3);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_whole_ln_fwd(const float* x, float* y, float* stats, float* ws, long long n, float eps, void* stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wln_sum_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, x, (const float*)nullptr, n, ws);
+  hipLaunchKernelGGL(wln_var_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, x, n, ws, ws + 2 * WLN_BLOCKS);
+  hipLaunchKernelGGL(wln_apply_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, x, y, n, eps, ws, ws + 2 * WLN_BLOCKS, stats, ruart_nan_flag_ptr);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, float* grad_x, float* ws, long long n,
+                                  void* stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wln_sum_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, grad_y, y, n, ws);
+  hipLaunchKernelGGL(wln_bwd_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, y, grad_y, stats, grad_x, n, ws);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_set_nan_flag(int* flag) {
+  ruart_nan_flag_ptr = flag;
+  return 0;
+}

@@ -1,0 +1,145 @@
+// Persistent LSTM recurrence for the SDNet trunk (fp32).
+//
+// Reference: Models/Layers.py:166 `self.rnns[i](rnn_input)[0]` -> torch nn.LSTM(batch_first, 1 layer, (bi)directional),
+// gate order i, f, g, o, zero initial state, padding NOT masked.  Seven instances, hidden 125
+// (Models/SDNet.py:147, 150, 172, 188; Models/Layers.py:489), T up to 100 sequential steps: latency-bound.
+//
+// The input projection x W_ih^T + b_ih + b_hh for all time steps and both directions is ONE plain GEMM done by the
+// caller (xproj).  This file is the sequential part: one workgroup per (batch row, direction) keeps its direction's
+// W_hh (4h x h, <= 512 x 128 fp32 = 256 KB) entirely in VGPRs - 128 weights per thread - for the whole sequence, the
+// running h in LDS (broadcast reads), c in a register.  Two barriers per step, no global traffic for weights.
+// Backward (BPTT) is the mirror image with W_hh^T columns in VGPRs; it emits grad_xproj, from which the caller gets
+// grad_W_ih, grad_b, grad_x and grad_W_hh with three plain GEMMs.
+#include "common.h"
+#include "ruart_hip.h"
+
+#define HP 128      // padded hidden size (h <= 128)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(512) void lstm_fwd_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                       float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cells,
+                                                       int T, int h, int ndir, int* __restrict__ nan_flag) {
+  __shared__ __attribute__((aligned(16))) float h_s[HP];
+  __shared__ float pre_s[4 * HP];
+  const int b = blockIdx.x, d = blockIdx.y, g = threadIdx.x;
+  const int G = 4 * h;
+  const bool row = g < G;
+  float w[HP];
+  {
+    const float* wr = w_hh + ((size_t)d * G + (row ? g : 0)) * h;
+#pragma unroll
+    for (int j = 0; j < HP; ++j) w[j] = (row && j < h) ? wr[j] : 0.f;
+  }
+  if (g < HP) h_s[g] = 0.f;
+  float c = 0.f;
+  const size_t ldx = (size_t)ndir * G, ldy = (size_t)ndir * h;
+  const float* xp = xproj + (size_t)b * T * ldx + (size_t)d * G + (row ? g : 0);
+  const int t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
+  float xnext = row ? xp[(size_t)t0 * ldx] : 0.f;
+  __syncthreads();
+  bool bad = false;
+  for (int s = 0, t = t0; s < T; ++s, t += dt) {
+    float pre = xnext;
+    if (s + 1 < T && row) xnext = xp[(size_t)(t + dt) * ldx];
+#pragma unroll
+    for (int j = 0; j < HP; j += 4) {
+      const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(h_s + j);
+      pre = fmaf(w[j], hv[0], pre); pre = fmaf(w[j + 1], hv[1], pre);
+      pre = fmaf(w[j + 2], hv[2], pre); pre = fmaf(w[j + 3], hv[3], pre);
+    }
+    if (row) pre_s[g] = pre;
+    __syncthreads();
+    if (g < h) {
+      const float ig = sigmoidf_(pre_s[g]), fg = sigmoidf_(pre_s[h + g]);
+      const float gg = tanhf(pre_s[2 * h + g]), og = sigmoidf_(pre_s[3 * h + g]);
+      c = fg * c + ig * gg;
+      const float hh = og * tanhf(c);
+      h_s[g] = hh;
+      const size_t o = ((size_t)b * T + t);
+      y[o * ldy + (size_t)d * h + g] = hh;
+      bad |= !(hh == hh);
+      if (gates) {
+        float* gp = gates + o * ldx + (size_t)d * G + g;
+        gp[0] = ig; gp[h] = fg; gp[2 * h] = gg; gp[3 * h] = og;
+      }
+      if (cells) cells[o * ldy + (size_t)d * h + g] = c;
+    }
+    __syncthreads();
+  }
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ gates, const float* __restrict__ cells,
+                                                       float* __restrict__ grad_xproj, int T, int h, int ndir) {
+  __shared__ __attribute__((aligned(16))) float da_s[4 * HP];
+  __shared__ float part_s[4 * HP];
+  const int b = blockIdx.x, d = blockIdx.y;
+  const int p = threadIdx.x >> 7, j = threadIdx.x & (HP - 1);
+  const int G = 4 * h;
+  const bool live = j < h;
+  float wt[HP];      // wt[r] = W_hh[d][p*h + r][j]
+  {
+    const float* wc = w_hh + (size_t)d * G * h + (size_t)p * h * h + (live ? j : 0);
+#pragma unroll
+    for (int r = 0; r < HP; ++r) wt[r] = (live && r < h) ? wc[(size_t)r * h] : 0.f;
+  }
+  da_s[threadIdx.x] = 0.f;      // pad lanes stay zero for the whole run
+  const size_t ldx = (size_t)ndir * G, ldy = (size_t)ndir * h;
+  // walk the forward order backwards: dir 0 ran t = 0..T-1, dir 1 ran t = T-1..0
+  const int t0 = d ? 0 : T - 1, dt = d ? 1 : -1;
+  float dh_rec = 0.f, dc_next = 0.f;
+  __syncthreads();
+  for (int s = 0, t = t0; s < T; ++s, t += dt) {
+    if (p == 0 && live) {
+      const size_t o = (size_t)b * T + t;
+      const float* gp = gates + o * ldx + (size_t)d * G + j;
+      const float ig = gp[0], fg = gp[h], gg = gp[2 * h], og = gp[3 * h];
+      const float c = cells[o * ldy + (size_t)d * h + j];
+      const float c_prev = (s + 1 < T) ? cells[((size_t)b * T + t + dt) * ldy + (size_t)d * h + j] : 0.f;
+      const float dh = grad_y[o * ldy + (size_t)d * h + j] + dh_rec;
+      const float tc = tanhf(c);
+      const float dc = dc_next + dh * og * (1.f - tc * tc);
+      const float da_i = dc * gg * ig * (1.f - ig);
+      const float da_f = dc * c_prev * fg * (1.f - fg);
+      const float da_g = dc * ig * (1.f - gg * gg);
+      const float da_o = dh * tc * og * (1.f - og);
+      dc_next = dc * fg;
+      da_s[j] = da_i; da_s[HP + j] = da_f; da_s[2 * HP + j] = da_g; da_s[3 * HP + j] = da_o;
+      float* gx = grad_xproj + o * ldx + (size_t)d * G + j;
+      gx[0] = da_i; gx[h] = da_f; gx[2 * h] = da_g; gx[3 * h] = da_o;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < HP; r += 4) {
+      const f32x4_t dv = *reinterpret_cast<const f32x4_t*>(da_s + p * HP + r);
+      acc = fmaf(wt[r], dv[0], acc); acc = fmaf(wt[r + 1], dv[1], acc);
+      acc = fmaf(wt[r + 2], dv[2], acc); acc = fmaf(wt[r + 3], dv[3], acc);
+    }
+    part_s[threadIdx.x] = acc;
+    __syncthreads();
+    if (p == 0 && live) dh_rec = (part_s[j] + part_s[HP + j]) + (part_s[2 * HP + j] + part_s[3 * HP + j]);
+  }
+}
+
+extern int* ruart_nan_flag_ptr;
+
+extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, int B, int T, int h,
+                              int ndir, void* stream) {
+  if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells, T, h, ndir,
+                     ruart_nan_flag_ptr);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const float* gates, const float* cells, float* grad_xproj,
+                              int B, int T, int h, int ndir, void* stream) {
+  if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, grad_y, w_hh, gates, cells, grad_xproj, T, h,
+                     ndir);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,111 @@
+"""ctypes binding of libruart_hip.so (the C ABI declared in include/ruart_hip.h).
+
+The library is plain HIP (no torch types in any signature): tensors cross the boundary as
+``tensor.data_ptr()`` plus explicit sizes, and launches go to ``torch.cuda.current_stream()``.
+There is NO fallback: if the shared object cannot be loaded or built, importing a product module
+that needs it raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libruart_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+class BertModelC(Structure):
+    _fields_ = [("hidden", c_int), ("n_heads", c_int), ("n_layers", c_int), ("intermediate", c_int), ("dtype", c_int),
+                ("ln_eps", c_float),
+                ("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p), ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
+                ("w_qkv", POINTER(c_void_p)), ("b_qkv", POINTER(c_void_p)),
+                ("w_ao", POINTER(c_void_p)), ("b_ao", POINTER(c_void_p)),
+                ("ln1_g", POINTER(c_void_p)), ("ln1_b", POINTER(c_void_p)),
+                ("w_ff1", POINTER(c_void_p)), ("b_ff1", POINTER(c_void_p)),
+                ("w_ff2", POINTER(c_void_p)), ("b_ff2", POINTER(c_void_p)),
+                ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p))]
+
+
+class BertBatchC(Structure):
+    _fields_ = [("n_tokens", c_int), ("n_rows", c_int), ("ids", c_void_p), ("pos_ids", c_void_p), ("n_blocks", c_int),
+                ("blk_q0", c_void_p), ("blk_q1", c_void_p), ("blk_k0", c_void_p), ("blk_k1", c_void_p),
+                ("tok_lo", c_void_p), ("tok_hi", c_void_p), ("key_bias", c_void_p)]
+
+
+_P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
+_SIGNATURES = {
+    "ruart_version": (c_char_p, []),
+    "ruart_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_f32_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
+    "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
+    "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "ruart_cast_f32_to_bf16": (_I, [_P, _P, _LL, _F, _P]),
+    "ruart_bert_workspace_bytes": (c_size_t, [POINTER(BertModelC), _I]),
+    "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),
+    "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_whole_ln_fwd": (_I, [_P, _P, _P, _P, _LL, _F, _P]),
+    "ruart_whole_ln_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
+    "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ruart_set_nan_flag": (_I, [_P]),
+}
+
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise OSError("libruart_hip.so not built: run `python -m ruart_amd.build`")
+        from . import build as _build
+        _build.build(verbose=False)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipError("%s failed with hipError_t %d" % (what, rc))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_gpu(t, dtype=None):
+    if not t.is_cuda:
+        raise HipError("ruart_amd kernels need device tensors; got a CPU tensor (there is no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise HipError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise HipError("tensor must be contiguous")
+    return t

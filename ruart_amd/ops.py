@@ -1,0 +1,179 @@
+"""autograd wrappers around the SDNet kernels of libruart_hip.so (fp32, device tensors only).
+
+Each Function's forward AND backward launch hand-written HIP kernels through the C ABI; only the plain dense
+projections around them (x W^T) go to torch.matmul (rocBLAS), as the design allows for library GEMMs.
+There is no CPU path: a CPU tensor raises ``hip.HipError``.
+"""
+import torch
+
+from . import hip
+
+_WS = {}
+
+
+def _scratch(device, n):
+    key = (device, "f32")
+    t = _WS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 4096), dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+class _NanFlag:
+    """Device-side flag honouring the reference's NaN asserts (Models/Layers.py:169,290,430,462,467) with ONE
+    host sync per step instead of one per op."""
+
+    def __init__(self):
+        self.flag = None
+
+    def ensure(self, device):
+        if self.flag is None or self.flag.device != device:
+            self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+            hip.check(hip.load().ruart_set_nan_flag(hip.ptr(self.flag)), "ruart_set_nan_flag")
+        return self.flag
+
+    def check_and_clear(self):
+        if self.flag is None:
+            return
+        bad = int(self.flag.item())
+        self.flag.zero_()
+        assert bad == 0, "NaN produced inside the SDNet kernels (reference: assert torch.sum(torch.isnan(x)) == 0)"
+
+
+nan_flag = _NanFlag()
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _FusedAttention(torch.autograd.Function):
+    """out = softmax_j(mask(a . k^T)) . v   (Models/Layers.py:244, 275-288)."""
+
+    @staticmethod
+    def forward(ctx, a, k, v, mask):
+        lib = hip.load()
+        for t in (a, k, v):
+            hip.require_gpu(t, torch.float32)
+        nan_flag.ensure(a.device)
+        B, L1, h = a.shape
+        L2, D3 = k.shape[1], v.shape[2]
+        out = torch.empty(B, L1, D3, dtype=torch.float32, device=a.device)
+        probs = torch.empty(B, L1, L2, dtype=torch.float32, device=a.device)
+        rc = lib.ruart_attn_fwd(hip.ptr(a), hip.ptr(k), hip.ptr(v), hip.ptr(mask), hip.ptr(out), hip.ptr(probs), B, L1, L2, h, D3,
+                                hip.stream_ptr())
+        hip.check(rc, "ruart_attn_fwd")
+        ctx.save_for_backward(a, k, v, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = hip.load()
+        a, k, v, probs = ctx.saved_tensors
+        B, L1, h = a.shape
+        L2, D3 = k.shape[1], v.shape[2]
+        gout = gout.contiguous()
+        ga, gk, gv = torch.empty_like(a), torch.empty_like(k), torch.empty_like(v)
+        ds = torch.empty_like(probs)
+        rc = lib.ruart_attn_bwd(hip.ptr(a), hip.ptr(k), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(ga), hip.ptr(gk),
+                                hip.ptr(gv), hip.ptr(ds), B, L1, L2, h, D3, hip.stream_ptr())
+        hip.check(rc, "ruart_attn_bwd")
+        return ga, gk, gv, None
+
+
+def fused_attention(a, k, v, mask):
+    """a (B,L1,h), k (B,L2,h), v (B,L2,D3) fp32; mask (B,L2) uint8/bool (0 = masked key)."""
+    m = mask.to(torch.uint8).contiguous()
+    return _FusedAttention.apply(a.contiguous(), k.contiguous(), v.contiguous(), m)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _WholeLayerNorm(torch.autograd.Function):
+    """F.layer_norm(x, x.size()) - normalisation over the WHOLE tensor, no affine (Models/Layers.py:167-168)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = hip.load()
+        hip.require_gpu(x, torch.float32)
+        nan_flag.ensure(x.device)
+        y = torch.empty_like(x)
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = _scratch(x.device, 2048)
+        hip.check(lib.ruart_whole_ln_fwd(hip.ptr(x), hip.ptr(y), hip.ptr(stats), hip.ptr(ws), x.numel(), eps, hip.stream_ptr()),
+                  "ruart_whole_ln_fwd")
+        ctx.save_for_backward(y, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = hip.load()
+        y, stats = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        ws = _scratch(y.device, 2048)
+        hip.check(lib.ruart_whole_ln_bwd(hip.ptr(y), hip.ptr(gy), hip.ptr(stats), hip.ptr(gx), hip.ptr(ws), y.numel(),
+                                         hip.stream_ptr()), "ruart_whole_ln_bwd")
+        return gx, None
+
+
+def whole_layer_norm(x, eps=1e-5):
+    return _WholeLayerNorm.apply(x.contiguous(), eps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _LstmRecurrence(torch.autograd.Function):
+    """Sequential part of one (Bi)LSTM layer.  xproj (B,T,ndir*4h) already holds x W_ih^T + b_ih + b_hh."""
+
+    @staticmethod
+    def forward(ctx, xproj, w_hh, ndir):
+        lib = hip.load()
+        hip.require_gpu(xproj, torch.float32)
+        hip.require_gpu(w_hh, torch.float32)
+        nan_flag.ensure(xproj.device)
+        B, T, G = xproj.shape
+        h = G // (4 * ndir)
+        y = torch.empty(B, T, ndir * h, dtype=torch.float32, device=xproj.device)
+        need = xproj.requires_grad or w_hh.requires_grad
+        gates = torch.empty_like(xproj) if need else None
+        cells = torch.empty_like(y) if need else None
+        hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), B, T, h, ndir,
+                                     hip.stream_ptr()), "ruart_lstm_fwd")
+        ctx.ndir, ctx.h = ndir, h
+        ctx.save_for_backward(w_hh, gates, cells, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = hip.load()
+        w_hh, gates, cells, y = ctx.saved_tensors
+        ndir, h = ctx.ndir, ctx.h
+        B, T, _ = y.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(gates)
+        hip.check(lib.ruart_lstm_bwd(hip.ptr(gy), hip.ptr(w_hh), hip.ptr(gates), hip.ptr(cells), hip.ptr(gx), B, T, h, ndir,
+                                     hip.stream_ptr()), "ruart_lstm_bwd")
+        # grad_W_hh[d] = sum_{b,t} da[b,t,d] (x) h_prev[b,t,d]  - one plain GEMM per direction
+        gw = torch.empty_like(w_hh)
+        for d in range(ndir):
+            hd = y[:, :, d * h:(d + 1) * h]
+            hprev = torch.zeros_like(hd)
+            if T > 1:
+                if d == 0:
+                    hprev[:, 1:] = hd[:, :-1]
+                else:
+                    hprev[:, :-1] = hd[:, 1:]
+            da = gx[:, :, d * 4 * h:(d + 1) * 4 * h].reshape(B * T, 4 * h)
+            gw[d] = da.t() @ hprev.reshape(B * T, h)
+        return gx, gw, None
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None):
+    """One nn.LSTM layer (batch_first, zero state), uni- or bidirectional, on the persistent HIP recurrence.
+    Parameters use torch's nn.LSTM layout so checkpoints load unchanged."""
+    bidir = w_ih_r is not None
+    if bidir:
+        w = torch.cat([w_ih, w_ih_r], 0)
+        b = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r], 0)
+        whh = torch.stack([w_hh, w_hh_r], 0)
+    else:
+        w, b, whh = w_ih, b_ih + b_hh, w_hh.unsqueeze(0)
+    xproj = torch.addmm(b, x.reshape(-1, x.shape[-1]), w.t()).view(x.shape[0], x.shape[1], -1)
+    return _LstmRecurrence.apply(xproj.contiguous(), whh.contiguous(), 2 if bidir else 1)

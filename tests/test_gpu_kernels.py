@@ -1,0 +1,339 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, through the C ABI, against the CPU oracle
+(oracle/ruart_oracle.py) and the reference-generated golden vectors (tests/golden/*.npz).
+
+Tolerances: fp32 kernels 2e-5 abs (same fmaf-order noise as torch CPU vs the reference);
+bf16 production path 4e-2 abs on O(1) layer-normed activations (bf16 has 8 mantissa bits; the bound that matters,
+1e-3 on the final answer probabilities, is checked end-to-end in test_gpu_sdnet.py)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ruart_oracle as O           # noqa: E402  (checker only)
+from ruart_amd import hip, synth               # noqa: E402
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def maxerr(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (384, 768, 3072), (128, 2304, 768)])
+@pytest.mark.parametrize("mode", ["plain", "gelu", "res_bf16_out_f32", "res_f32_out_bf16"])
+def test_gemm_bf16(M, N, K, mode):
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    res = None
+    res_dt, out_dt, act = hip.DT_BF16, hip.DT_BF16, hip.ACT_NONE
+    if mode == "gelu":
+        act = hip.ACT_GELU
+        ref = O.gelu_erf(ref)
+    elif mode == "res_bf16_out_f32":
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16)
+        ref = ref + res.double()
+        out_dt = hip.DT_F32
+    elif mode == "res_f32_out_bf16":
+        res = torch.randn(M, N, generator=g)
+        ref = ref + res.double()
+        res_dt = hip.DT_F32
+    Ad, Wd, bd = A.to(d), W.to(d), bias.to(d)
+    Rd = res.to(d) if res is not None else None
+    C = torch.empty(M, N, dtype=torch.float32 if out_dt == hip.DT_F32 else torch.bfloat16, device=d)
+    rc = lib.ruart_gemm_bf16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, res_dt, hip.ptr(C), N, out_dt, M, N, K,
+                                act, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    tol = 2e-3 if out_dt == hip.DT_F32 else 3e-2      # fp32 accumulate; bf16 output rounding dominates otherwise
+    assert maxerr(C.float(), ref) < tol * max(1.0, float(ref.abs().max()) / 4)
+
+
+def test_gemm_bf16_rejects_bad_shapes():
+    lib = hip.load()
+    d = dev()
+    x = torch.zeros(128, 64, dtype=torch.bfloat16, device=d)
+    assert lib.ruart_gemm_bf16_nt(hip.ptr(x), 64, hip.ptr(x), 64, None, None, 0, 1, hip.ptr(x), 128, 1, 100, 128, 64, 0,
+                                  hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 53, 29), (64, 64, 16), (200, 250, 1388), (130, 125, 250), (100, 1200, 300)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_f32(M, N, K, act):
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    ref = O.gelu_erf(ref) if act == 1 else (torch.relu(ref) if act == 2 else ref)
+    ref = ref + res.double()
+    Ad, Wd, bd, Rd = A.to(d), W.to(d), bias.to(d), res.to(d)
+    C = torch.empty(M, N, device=d)
+    assert lib.ruart_gemm_f32_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, hip.ptr(C), N, M, N, K, act,
+                                 hip.stream_ptr()) == 0
+    assert maxerr(C, ref) < 1e-5 * max(1.0, float(ref.abs().max())) * max(1.0, K / 64)
+
+
+@pytest.mark.parametrize("H", [128, 768, 1024])
+@pytest.mark.parametrize("out_dt", [hip.DT_F32, hip.DT_BF16])
+def test_rows_layernorm_and_embed(H, out_dt):
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(H)
+    rows = 37
+    x = torch.randn(rows, H, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
+    ref = O.bert_layer_norm(x, gamma, beta)
+    out = torch.empty(rows, H, dtype=torch.float32 if out_dt == hip.DT_F32 else torch.bfloat16, device=d)
+    xd, gd, bd = x.to(d), gamma.to(d), beta.to(d)
+    assert lib.ruart_rows_layernorm(hip.ptr(xd), H, hip.ptr(gd), hip.ptr(bd), 1e-12, hip.ptr(out), H, out_dt, rows, H,
+                                    hip.stream_ptr()) == 0
+    assert maxerr(out.float(), ref) < (3e-6 if out_dt == hip.DT_F32 else 2e-2)
+    V, P = 50, 40
+    word, ptab, ttab = torch.randn(V, H, generator=g), torch.randn(P, H, generator=g), torch.randn(2, H, generator=g)
+    ids = torch.randint(0, V, (rows,), generator=g)
+    pos = torch.randint(0, P, (rows,), generator=g)
+    ref = O.bert_layer_norm(word[ids] + ptab[pos] + ttab[0], gamma, beta)
+    wd, pd, td = word.to(d), ptab.to(d), ttab.to(d)
+    idd, posd = ids.int().to(d), pos.int().to(d)
+    assert lib.ruart_bert_embed_ln(hip.ptr(idd), hip.ptr(posd), hip.ptr(wd), hip.ptr(pd), hip.ptr(td), hip.ptr(gd), hip.ptr(bd),
+                                   1e-12, hip.ptr(out), H, out_dt, rows, H, hip.stream_ptr()) == 0
+    assert maxerr(out.float(), ref) < (3e-6 if out_dt == hip.DT_F32 else 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _bert_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    c = z["cfg"]
+    cfg = synth.bert_config(vocab_size=int(c[0]), hidden_size=int(c[1]), num_hidden_layers=int(c[2]),
+                            num_attention_heads=int(c[3]), intermediate_size=int(c[4]), max_position_embeddings=int(c[5]))
+    return z, cfg, synth.make_bert_weights(cfg, seed=int(z["seed"]))
+
+
+@pytest.mark.parametrize("name", ["bert_small", "bert_base"])
+@pytest.mark.parametrize("precision,pack,tol", [("fp32", True, 5e-5), ("fp32", False, 5e-5), ("bf16", True, 6e-2)])
+def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol):
+    """Whole encoder through ruart_bert_forward vs the reference's own layer outputs (gen_golden.py)."""
+    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
+    z, cfg, w = _bert_case(golden_dir, name)
+    d = dev()
+    W = BertEncoderWeights(w, cfg, d, precision)
+    ids, mask = T(z["ids"]), T(z["mask"])
+    packed = PackedTokens([(ids, mask)], d, pack=pack)
+    layers = bert_encode(W, packed).float().cpu()
+    gi = packed.group_index[0]
+    sel = T(z["mask"]).bool()
+    for k in z.files:
+        if not k.startswith("layer"):
+            continue
+        ref = T(z[k])[sel]                                   # (valid tokens, H) in row-major order
+        got = layers[int(k[5:])][T(gi)[sel]]
+        err = maxerr(got, ref)
+        assert err < tol, "%s %s %s: max abs err %.3e" % (name, precision, k, err)
+
+
+def test_bert_long_sequences_and_split_groups(golden_dir):
+    """Sequences longer than one 64-query block (the (B, 512)-style shape) and several groups in one pass."""
+    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
+    cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                            max_position_embeddings=256)
+    w = synth.make_bert_weights(cfg, seed=3)
+    g = np.random.default_rng(0)
+    lens_a, lens_b = [200, 65, 64, 1, 130], [7, 3, 256]
+    def mk(lens, L):
+        ids = np.zeros((len(lens), L), dtype=np.int64)
+        for i, l in enumerate(lens):
+            ids[i, :l] = g.integers(1, 300, size=l)
+        return T(ids), T(ids != 0)
+    ga, gb = mk(lens_a, 200), mk(lens_b, 256)
+    d = dev()
+    W = BertEncoderWeights(w, cfg, d, "fp32")
+    packed = PackedTokens([ga, gb], d)
+    layers = bert_encode(W, packed).cpu()
+    wt = {k: T(v) for k, v in w.items()}
+    for gi, (ids, mask) in enumerate((ga, gb)):
+        with torch.no_grad():
+            ref = O.bert_forward(wt, cfg, ids, mask)
+        idx = T(packed.group_index[gi])
+        for l in range(2):
+            assert maxerr(layers[l][idx[mask]], ref[l][mask]) < 5e-5
+
+
+def test_pool_mix_fwd_bwd():
+    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode, Bert
+    cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                            max_position_embeddings=64)
+    w = synth.make_bert_weights(cfg, seed=9)
+    d = dev()
+    opt = {"bert_state": w, "bert_config": cfg, "bert_precision": "fp32", "BERT_LINEAR_COMBINE": True}
+    m = Bert.__new__(Bert)
+    torch.nn.Module.__init__(m)
+    m._device, m.pack = d, True
+    m.weights = BertEncoderWeights(w, cfg, d, "fp32")
+    g = np.random.default_rng(4)
+    N, L, Lw = 6, 14, 5
+    ids = np.zeros((N, L), dtype=np.int64)
+    offsets, wmask = [], np.zeros((N, Lw), dtype=bool)
+    for n in range(N):
+        nw = int(g.integers(0, Lw + 1)) if n else Lw
+        cur, offs = 1, []
+        for j in range(nw):
+            c = int(g.integers(1, 3))
+            offs.append([cur, cur + c])
+            cur += c
+            wmask[n, j] = True
+        if nw >= 2:
+            offs[1] = [offs[1][0], offs[1][0]]            # an empty span -> zeros (Bert.py:160-165)
+        ids[n, :cur + 1] = g.integers(1, 300, size=cur + 1)
+        offsets.append(offs if nw else [1, 1])
+    ids_t, mask_t = T(ids), T(ids != 0)
+    packed, layers = m.encode([(ids_t, mask_t)])
+    alpha = torch.tensor([0.3, -0.2, 1.1], device=d, requires_grad=True)
+    gamma = torch.tensor(0.8, device=d, requires_grad=True)
+    lw = torch.softmax(alpha, 0) * gamma
+    out = m.pool_mix(packed, layers, 0, offsets, T(wmask), lw)
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    (out * gy.to(d)).sum().backward()
+    wt = {k: T(v) for k, v in w.items()}
+    a_c = alpha.detach().cpu().requires_grad_()
+    g_c = gamma.detach().cpu().requires_grad_()
+    with torch.no_grad():
+        ref_layers = O.bert_forward(wt, cfg, ids_t, mask_t)
+    pooled = O.pool_subwords(ref_layers, offsets, T(wmask))
+    ref = O.linear_sum(pooled, a_c, g_c.view(1, 1))
+    (ref * gy).sum().backward()
+    assert maxerr(out, ref) < 3e-5
+    assert maxerr(alpha.grad, a_c.grad) < 2e-4 * max(1.0, float(a_c.grad.abs().max()))
+    assert maxerr(gamma.grad, g_c.grad) < 2e-4 * max(1.0, float(g_c.grad.abs().max()))
+    # the reference-compatible API: list of per-layer pooled tensors
+    outs = m.forward(ids_t, mask_t, offsets, T(wmask))
+    for l in range(3):
+        assert maxerr(outs[l], pooled[l]) < 3e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def layers_golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "layers.npz"))
+
+
+@pytest.mark.parametrize("tag", ["attn_a", "attn_b", "attn_c", "attn_d"])
+def test_fused_attention_vs_reference(layers_golden, tag):
+    from ruart_amd import ops
+    z = layers_golden
+    d = dev()
+    x1 = T(z[tag + "_x1"]).to(d).requires_grad_()
+    x2 = T(z[tag + "_x2"]).to(d).requires_grad_()
+    W = T(z[tag + "_W"]).to(d).requires_grad_()
+    diag = T(z[tag + "_diag"]).to(d).requires_grad_()
+    x3 = T(z[tag + "_x3"]).to(d).requires_grad_() if tag + "_x3" in z.files else None
+    a = torch.relu(x1 @ W.t()) * diag
+    k = torch.relu(x2 @ W.t())
+    y = ops.fused_attention(a, k, x2 if x3 is None else x3, T(z[tag + "_mask"]).to(d))
+    assert maxerr(y, T(z[tag + "_y"])) < 1e-5
+    y.backward(T(z[tag + "_gy"]).to(d))
+    ops.nan_flag.check_and_clear()
+    for got, name in ((x1.grad, "_gx1"), (x2.grad, "_gx2"), (W.grad, "_gW")):
+        ref = T(z[tag + name])
+        assert maxerr(got, ref) < 3e-5 * max(1.0, float(ref.abs().max())), name
+    if x3 is not None:
+        assert maxerr(x3.grad, T(z[tag + "_gx3"])) < 3e-5
+    if tag + "_gdiag" in z.files:
+        ref = T(z[tag + "_gdiag"])
+        assert maxerr(diag.grad, ref) < 3e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,L1,L2,h,D3", [(1, 1, 1, 1, 1), (2, 205, 40, 300, 300), (3, 100, 100, 250, 250), (2, 33, 17, 8, 250),
+                                          (2, 40, 256, 37, 5)])
+def test_fused_attention_shapes(B, L1, L2, h, D3):
+    from ruart_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 1000 + L1 + L2)
+    a, k, v = torch.randn(B, L1, h, generator=g), torch.randn(B, L2, h, generator=g), torch.randn(B, L2, D3, generator=g)
+    mask = torch.ones(B, L2, dtype=torch.uint8)
+    for b in range(B):
+        mask[b, int(torch.randint(1, L2 + 1, (1,), generator=g)):] = 0
+    ac, kc, vc = [t.clone().requires_grad_() for t in (a, k, v)]
+    s = torch.bmm(ac, kc.transpose(1, 2)).masked_fill(mask.eq(0).unsqueeze(1), float("-inf"))
+    ref = torch.bmm(torch.softmax(s, 2), vc)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    ad, kd, vd = [t.to(d).requires_grad_() for t in (a, k, v)]
+    y = ops.fused_attention(ad, kd, vd, mask.to(d))
+    y.backward(gy.to(d))
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxerr(y, ref) < 2e-5 * scale
+    for got, want in ((ad.grad, ac.grad), (kd.grad, kc.grad), (vd.grad, vc.grad)):
+        assert maxerr(got, want) < 5e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_whole_layer_norm(layers_golden):
+    from ruart_amd import ops
+    z = layers_golden
+    d = dev()
+    x = T(z["wln_x"]).to(d).requires_grad_()
+    y = ops.whole_layer_norm(x)
+    assert maxerr(y, T(z["wln_y"])) < 3e-6
+    y.backward(T(z["wln_gy"]).to(d))
+    assert maxerr(x.grad, T(z["wln_gx"])) < 3e-6
+    # conf-sized tensor vs torch CPU
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(64, 100, 250, generator=g) * 1.7 - 0.4
+    bc = big.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(bc, bc.size())
+    gy = torch.randn(big.shape, generator=g)
+    ref.backward(gy)
+    bd = big.to(d).requires_grad_()
+    yd = ops.whole_layer_norm(bd)
+    yd.backward(gy.to(d))
+    assert maxerr(yd, ref) < 5e-6 and maxerr(bd.grad, bc.grad) < 5e-6
+
+
+@pytest.mark.parametrize("B,Tn,Din,Hh,bid", [(3, 11, 10, 6, True), (5, 4, 14, 9, False), (64, 100, 300, 125, True), (2, 1, 5, 128, True)])
+def test_lstm_layer(B, Tn, Din, Hh, bid):
+    from ruart_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B + Tn + Hh)
+    k = 1.0 / np.sqrt(Hh)
+    nd = 2 if bid else 1
+    names = ["w_ih", "w_hh", "b_ih", "b_hh"]
+    shapes = [(4 * Hh, Din), (4 * Hh, Hh), (4 * Hh,), (4 * Hh,)]
+    P = [[(torch.rand(s, generator=g) * 2 - 1) * k for s in shapes] for _ in range(nd)]
+    x = torch.randn(B, Tn, Din, generator=g)
+    xc = x.clone().requires_grad_()
+    Pc = [[t.clone().requires_grad_() for t in p] for p in P]
+    ys = [O.lstm_direction(xc, *Pc[0])]
+    if bid:
+        ys.append(O.lstm_direction(xc, *Pc[1], reverse=True))
+    ref = torch.cat(ys, 2)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd = x.to(d).requires_grad_()
+    Pd = [[t.to(d).requires_grad_() for t in p] for p in P]
+    args = list(Pd[0]) + (list(Pd[1]) if bid else [])
+    y = ops.lstm_layer(xd, Pd[0][0], Pd[0][1], Pd[0][2], Pd[0][3], *(Pd[1] if bid else []))
+    y.backward(gy.to(d))
+    ops.nan_flag.check_and_clear()
+    assert maxerr(y, ref) < 2e-5
+    assert maxerr(xd.grad, xc.grad) < 5e-5 * max(1.0, float(xc.grad.abs().max()))
+    for dd in range(nd):
+        for i, n in enumerate(names):
+            want = Pc[dd][i].grad
+            assert maxerr(Pd[dd][i].grad, want) < 1e-4 * max(1.0, float(want.abs().max())), (dd, n)
