@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the RUArt hot path on MI355X (contract: one JSON line on rank 0).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Metric (BASELINE.json): VQA samples/sec, forward + backward training step, B=64 per GPU, question 30 words, 100 OCR
+items, 36 objects, bert-base (12 x 768, 12 heads, FFN 3072), Adamax - every rank runs the full reference step
+(frozen BERT forward, SDNet forward, BCE loss, backward, global-norm clip, optimizer step, embedding re-pin), gradients
+averaged over ranks with RCCL.  A "step" is one such pass over one synthetic batch whose tensors and index vectors are
+already resident in HBM when the timed region starts.  Weak scaling: B per GPU is fixed.
+
+Extra objects on the same line:
+  roofline     - the dominant kernel (gemm_16_nt_128, the 768x768 / 768x3072 BERT projections): algorithmic FLOPs
+                 (2 * real_tokens * N * K per launch) / its HIP-event time measured live on the launch stream over a second
+                 pass of the same K steps, against the 2.5 PFLOP/s dense 16-bit MFMA peak.
+  cpu_baseline - the CPU oracle (oracle/ruart_oracle.py, kind "port": the reference cannot travel) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); sparsity figures are never used
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--n-batches", type=int, default=2, help="distinct pre-staged synthetic batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays alone)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def build_trainer(opt, cfg, device, seed=1033):
+    from ruart_amd import synth
+    from ruart_amd.trainer import SDNetTrainer
+    opt = dict(opt)
+    opt["bert_state"] = synth.make_bert_weights(cfg, seed=seed, w_std=0.02)
+    opt["bert_config"] = cfg
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    tr = SDNetTrainer(opt, device=device)
+    tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    missing, unexpected = tr.network.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not missing and not unexpected
+    del opt["bert_state"]
+    return tr, sw
+
+
+def cpu_baseline(opt, cfg, n_samples, seed=1033):
+    """Time the CPU oracle's forward + loss + backward on `n_samples` samples of the bench workload."""
+    from oracle import ruart_oracle as O          # CPU baseline leg: allowed importer
+    from ruart_amd import synth
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the GPU box gives one-GPU jobs a 16-core share; oversubscribing stalls torch
+    torch.set_num_threads(cores)
+    bw = {k: T(v) for k, v in synth.make_bert_weights(cfg, seed=seed, w_std=0.02).items()}
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    P = {k: T(v).requires_grad_(v.shape != (1, 1, 1)) for k, v in sw.items()}
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, n_samples, seed=99, n_q=30, n_ocr=opt["max_ocr_num"], n_od=opt["max_od_num"])
+    t0 = time.perf_counter()
+    scores = O.sdnet_forward(P, opt, bw, cfg, q, ocr, od)
+    loss = O.instance_bce_with_logits(scores, gt)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_samples / dt, 4), "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d sample(s) of the bench workload (q=30, ocr=100, obj=36, bert-base), fwd+loss+bwd once, %.1f s wall"
+                      % (n_samples, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback of the product path"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from ruart_amd import hip, synth
+    from ruart_amd.arguments import default_opt
+    lib = hip.load()
+    opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
+    cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
+    note("building model")
+    tr, _ = build_trainer(opt, cfg, device)
+    note("model ready; staging %d batches" % a.n_batches)
+
+    # pre-stage synthetic batches (different data per rank), index vectors included
+    batches = []
+    for i in range(a.n_batches):
+        b = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=100, n_od=36)
+        batches.append(tr.ToCUDA(b))
+    bi = batches[0][0]["_ruart_index"]
+    real_tokens = bi.packed.T
+    torch.cuda.synchronize()
+    note("batches staged: %d real word pieces per batch" % real_tokens)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        if a.mode == "train":
+            tr.update(b, i)
+        else:
+            tr.network.eval()
+            tr.network.drop_emb = False
+            with torch.no_grad():
+                tr.network(b[0], b[1], b[2])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        note("warmup step %d done" % i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+
+    note("timed region: %.3f s for %d steps" % (dt, a.steps))
+    # second pass of the same K steps with hipEvent pairs around every GEMM launch (roofline of the dominant kernel)
+    roof = None
+    if not a.no_roofline and a.precision != "fp32":
+        hip.check(lib.ruart_prof_enable(1), "prof_enable")
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        hip.check(lib.ruart_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
+        lib.ruart_prof_enable(0)
+        if n.value:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_16_nt_128", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None, "launches": int(n.value),
+                    "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                    "gemm_share_of_step": round(ms.value / a.steps / (dt / a.steps * 1e3), 3)}
+
+    if rank == 0:
+        out = {"metric": "VQA samples/sec fwd+bwd (B=64, q=30, ocr=100)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=100)",
+               "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+               "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, 100 OCR items, "
+                                      "36 objects, bert-base 12x768 frozen, SDNet trunk fwd+bwd, Adamax" % a.batch,
+                          "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
+                          "parallelism": "dp%d" % world, "mode": a.mode},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            note("cpu baseline (oracle) ...")
+            out["cpu_baseline"] = cpu_baseline(opt, cfg, a.cpu_samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

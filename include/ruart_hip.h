@@ -13,8 +13,9 @@
  *     graph-capturable;
  *   - return value: 0 on success, otherwise the hipError_t of the failed check/launch
  *     (hipErrorInvalidValue = 1 for shape/alignment contract violations);
- *   - dtype codes: RUART_DT_F32 = 0 (exact fp32 validation path), RUART_DT_BF16 = 1 (production path,
- *     bf16 storage, fp32 accumulation and fp32 softmax / layer-norm / GELU internals);
+ *   - dtype codes: RUART_DT_F32 = 0 (exact fp32 validation path), RUART_DT_BF16 = 1 / RUART_DT_F16 = 2 (production
+ *     paths: 16-bit storage and MFMA operands - both forms run at the same MFMA rate - with fp32 accumulation and
+ *     fp32 softmax / layer-norm / GELU internals);
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
  */
 #ifndef RUART_HIP_H
@@ -27,6 +28,7 @@ extern "C" {
 
 #define RUART_DT_F32 0
 #define RUART_DT_BF16 1
+#define RUART_DT_F16 2
 #define RUART_ACT_NONE 0
 #define RUART_ACT_GELU 1
 #define RUART_ACT_RELU 2
@@ -37,13 +39,21 @@ const char* ruart_version(void);
 /* ---- dense projections (reference: nn.Linear sites, Models/Bert/modeling.py:225-227, 261, 287-288, 300;
  *      Models/Layers.py:226-227 for the fp32 form) --------------------------------------------------------
  * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
- * bf16 form: M % 128 == 0, N % 128 == 0, K % 64 == 0 (the caller pads M; BERT's N, K always qualify);
- *            residual_dtype / out_dtype select bf16 or fp32 storage; GELU and residual are exclusive. */
-int ruart_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
-                       int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, void* stream);
+ * 16-bit form (in_dtype = BF16 or F16): M % 128 == 0, N % 128 == 0, K % 64 == 0 (the caller pads M; BERT's N, K always
+ *            qualify); residual_dtype / out_dtype are in_dtype or F32; GELU and residual are exclusive. */
+int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
+                     int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
+                     void* stream);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
                       float* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* Live timing of the dominant kernel for bench.py's roofline: while enabled, every ruart_gemm_16_nt launch is
+ * bracketed by a hipEvent pair on its stream (pool of 8192 launches).  ruart_prof_read synchronises on those events,
+ * returns the summed kernel time, launch count and ALGORITHMIC flops (2 * real_rows * N * K), and resets the pool.
+ * The only entry points that synchronise or allocate; never call them inside a timed or captured region. */
+int ruart_prof_enable(int on);
+int ruart_prof_read(double* total_ms, long long* launches, double* flops);
 
 /* ---- BERT row kernels ------------------------------------------------------------------------------------ */
 /* Models/Bert/modeling.py:185-199: out[r] = LN(word[ids[r]] + pos[pos_ids[r]] + type[0]). */
@@ -70,7 +80,7 @@ int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int
 int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
                             const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial_ws,
                             float* grad_layer_w, int n_words, int H, void* stream);
-int ruart_cast_f32_to_bf16(const float* in, void* out, long long n, float scale, void* stream);
+int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n, float scale, void* stream);
 
 /* ---- whole BERT encoder (Models/Bert/modeling.py:585-614, all layer outputs kept as Bert.py:137 needs) ---- */
 typedef struct {

@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | host
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -319,11 +319,69 @@ def gen_e2e():
     save("sdnet_e2e", **arrays)
 
 
+# ----------------------------------------------------------------------------------
+def synthetic_samples(opt, n, seed):
+    """Per-sample dicts in the layout VQA_Dataset.__getitem__ emits (Utils/VQA_Dataset.py:145-153)."""
+    g = np.random.default_rng(seed)
+
+    def item(nw, nb, sentinel=None):
+        words = [sentinel] if sentinel is not None else g.integers(5, 900, size=nw).tolist()
+        bert = [101] + g.integers(1000, 2000, size=nb).tolist() + [102]
+        offs, cur = [], 1
+        for k in range(len(words)):
+            c = 1 + (k < nb - len(words))
+            offs.append([cur, cur + c])
+            cur += c
+        return {"fasttext": words, "pos": g.integers(0, 51, size=len(words)).tolist(), "ent": g.integers(0, 75, size=len(words)).tolist(),
+                "bert": bert, "bert_offsets": offs, "position": g.random(8).round(4).tolist()}
+
+    out = []
+    for i in range(n):
+        nq = int(g.integers(3, 12))
+        q = {"glove": g.integers(5, 900, size=nq).tolist(), "pos": g.integers(0, 51, size=nq).tolist(),
+             "ent": g.integers(0, 75, size=nq).tolist(), "bert": [101] + g.integers(1000, 2000, size=nq + 2).tolist() + [102],
+             "bert_offsets": [[1 + k, 2 + k] for k in range(nq)]}
+        n_ocr, n_od = int(g.integers(12, 20)), int(g.integers(1, 6))
+        ocr = [item(int(g.integers(1, 4)), int(g.integers(3, 7))) for _ in range(n_ocr - 1)] + [item(1, 1, sentinel=3)]
+        od = [item(int(g.integers(1, 3)), int(g.integers(2, 4))) for _ in range(n_od - 1)] + [item(1, 1, sentinel=4)]
+        gt = torch.zeros(1, opt["max_ocr_num"] + 1)
+        gt[0, int(g.integers(0, n_ocr - 1))] = 1.0
+        out.append({"q": q, "ocr": ocr, "od": od, "gt": gt, "extra_info": {"q_id": i, "answers": None,
+                                                                         "ocr_list": ["w"] * n_ocr, "image_path": "x"}})
+    return out
+
+
+def gen_host():
+    """VQA_collate_fun (Utils/VQA_Dataset.py:448-542) and VQA_Sampler (Utils/VQA_Sampler.py) outputs."""
+    from Utils.VQA_Dataset import VQA_collate
+    from Utils.VQA_Sampler import VQA_Sampler
+    opt = default_opt()
+    samples = synthetic_samples(opt, 3, seed=21)
+    q, ocr, od, gt, extra = VQA_collate(opt).VQA_collate_fun(samples)
+    arrays = {"seed": np.array(21), "gt": gt.numpy()}
+    for name, d in (("q", q), ("ocr", ocr), ("od", od)):
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                arrays["%s:%s" % (name, k)] = v.numpy()
+        if "num_cnt" in d:
+            arrays[name + ":num_cnt"] = np.array(d["num_cnt"])
+            arrays[name + ":len_cnt"] = np.concatenate([np.array(l) for l in d["len_cnt"]])
+        arrays[name + ":n_offsets"] = np.array([len(o) for o in d["bert_offsets"]])
+    data = list(range(23))
+    arrays["sampler_train"] = np.array(list(VQA_Sampler(data, 7, 5, True)))
+    arrays["sampler_train_resume"] = np.array(list(VQA_Sampler(data, 7, 5, True, batch_st=3)))
+    arrays["sampler_epoch"] = np.array(list(VQA_Sampler(data, None, 4, True, epoch=2)))
+    arrays["sampler_eval"] = np.array(list(VQA_Sampler(data, 99, 5, False)))
+    save("host", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "host"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
         gen_bert()
     if "e2e" in which:
         gen_e2e()
+    if "host" in which:
+        gen_host()

@@ -1,0 +1,206 @@
+"""Batch layout of the hot path: the reference's ``VQA_collate`` 5-tuple plus precomputed device index tensors.
+
+``VQA_collate`` mirrors ``Utils/VQA_Dataset.py:439-542`` (same method names, same output layout: dicts of int64 id
+matrices and bool masks, python offset / count lists, ``position (B, max_num, 8)``, ``gt (B, No+1)``).
+
+``prepare`` is new: it turns the python lists the reference walks with per-item Python loops inside ``forward``
+(Models/Bert/Bert.py:153-165, Models/SDNet.py:300-318 and :495-551) into a handful of int64 index vectors, computed
+once per batch on the host and shipped in ONE host-to-device copy.  OCR / object words live in a packed
+(real words, D) matrix from then on - the padded (items, 20, 1388) tensor of the reference is never materialised.
+"""
+import numpy as np
+import torch
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class VQA_collate:
+    def __init__(self, opt):
+        self.opt = opt
+
+    def VQA_collate_fun(self, batch):
+        o = self.opt
+        q_list = self.que_collate([t["q"] for t in batch], o["max_q_len"], o["max_q_bert_len"])
+        ocr_list = self.item_collate([t["ocr"] for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"])
+        od_list = self.item_collate([t["od"] for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"])
+        gt_list = self.gt_collate([t["gt"] for t in batch])
+        return q_list, ocr_list, od_list, gt_list, [t["extra_info"] for t in batch]
+
+    def gt_collate(self, gt_list):
+        return torch.cat(gt_list, dim=0)
+
+    @staticmethod
+    def _pad_rows(rows, width):
+        out = np.zeros((len(rows), width), dtype=np.int64)
+        for i, r in enumerate(rows):
+            out[i, :len(r)] = r
+        return torch.from_numpy(out)
+
+    def item_collate(self, item_list, max_len, max_bert_len, max_num):
+        res = {}
+        B = len(item_list)
+        flat = [it for sample in item_list for it in sample]
+        for k in item_list[0][0].keys():
+            if "offset" in k:
+                res[k] = [it[k] for it in flat]
+            elif k == "position":
+                pos = torch.zeros(B, max_num, 8)
+                for b, sample in enumerate(item_list):
+                    pos[b, :len(sample)] = torch.tensor([it[k] for it in sample], dtype=torch.float32)
+                res[k] = pos
+            else:
+                res[k] = self._pad_rows([it[k] for it in flat], max_bert_len if k in ("bert", "bert_only") else max_len)
+        for k in [k for k in res if k in ("glove", "fasttext", "phoc", "bert", "bert_only")]:
+            res[k + "_mask"] = ~res[k].eq(0)
+        res["num_cnt"] = [len(sample) for sample in item_list]
+        wk = "fasttext" if "FastText" in self.opt else "glove"
+        res["len_cnt"] = [[len(it[wk]) for it in sample] for sample in item_list]
+        return res
+
+    def que_collate(self, q_list, max_len, max_bert_len):
+        res = {}
+        for k in q_list[0].keys():
+            if k in ("img_features", "img_spatials"):
+                res[k] = torch.cat([t[k] for t in q_list], dim=0)
+            elif "offset" in k:
+                res[k] = [t[k] for t in q_list]
+            else:
+                res[k] = self._pad_rows([t[k] for t in q_list], max_bert_len if k in ("bert", "bert_only") else max_len)
+                if k in ("fasttext", "glove", "phoc", "bert", "bert_only"):
+                    res[k + "_mask"] = ~res[k].eq(0)
+        return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+def offsets_to_array(offsets, n_rows, width):
+    """python list [rows][words][2] -> (rows, width, 2) int64, zero padded; tolerates the reference's flat
+    ``[1, 1]`` for an item without words (Utils/VQA_Dataset.py:426-427)."""
+    arr = np.zeros((n_rows, width, 2), dtype=np.int64)
+    for n, row in enumerate(offsets):
+        if len(row) and not isinstance(row[0], (list, tuple)):
+            continue
+        k = min(len(row), width)
+        if k:
+            arr[n, :k] = np.asarray(row[:k], dtype=np.int64)
+    return arr
+
+
+class ItemIndex:
+    """Index vectors for one item group (OCR tokens or detected objects).  Host arrays; ``.dev`` holds the int64
+    device copies after ``to_device``."""
+
+    def __init__(self, items, word_key, max_num):
+        num_cnt = np.asarray(items["num_cnt"], dtype=np.int64)
+        lens = np.concatenate([np.asarray(l, dtype=np.int64) for l in items["len_cnt"]]) if len(num_cnt) else np.zeros(0, np.int64)
+        if (lens < 1).any():
+            raise ValueError("every item must hold at least one word (Utils/VQA_Dataset.py:319-320 drops empty ones)")
+        B, N = len(num_cnt), len(lens)
+        if (num_cnt > max_num).any():
+            raise ValueError("more items than position rows")
+        self.B, self.N, self.max_num = B, N, max_num
+        self.W = int(lens.sum())
+        word_start = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        item_start = np.concatenate([[0], np.cumsum(num_cnt)[:-1]])
+        self.item_of_word = np.repeat(np.arange(N), lens)
+        self.pos_in_item = np.arange(self.W) - word_start[self.item_of_word]
+        sample_of_item = np.repeat(np.arange(B), num_cnt)
+        slot = np.arange(N) - item_start[sample_of_item]
+        self.sample_of_word = sample_of_item[self.item_of_word]
+        wps = np.bincount(self.sample_of_word, minlength=B)
+        tok_start = np.concatenate([[0], np.cumsum(wps)[:-1]])
+        self.tok_in_sample = np.arange(self.W) - tok_start[self.sample_of_word]
+        self.Tmax = int(wps.max()) if B else 0
+        # multi2one schedule: items sorted by word count (descending, stable); at step s the first n_active[s] are alive
+        order = np.argsort(-lens, kind="stable")
+        ls = lens[order]
+        self.maxlen = int(ls[0]) if N else 0
+        self.n_active = [int((ls > s).sum()) for s in range(self.maxlen)]
+        self.step_rows = np.concatenate([word_start[order[:n]] + s for s, n in enumerate(self.n_active)]) if N else np.zeros(0, np.int64)
+        self.sorted_sample = sample_of_item[order]
+        self.sorted_slot = slot[order]
+        self.num_cnt = num_cnt
+        Lw = items[word_key].shape[1]
+        self.Lw = Lw
+        self.flat_word = self.item_of_word * Lw + self.pos_in_item          # index into the flattened (N, Lw) id matrices
+        mask = np.zeros((B, max_num), dtype=np.uint8)
+        mask[np.arange(max_num)[None, :] < num_cnt[:, None]] = 1
+        self.mask = mask
+        self.dev = None
+
+    _FIELDS = ("item_of_word", "sample_of_word", "tok_in_sample", "step_rows", "sorted_sample", "sorted_slot", "flat_word")
+
+    def pack_host(self):
+        return [getattr(self, f).astype(np.int64) for f in self._FIELDS]
+
+    def bind(self, tensors):
+        self.dev = dict(zip(self._FIELDS, tensors))
+
+
+class BatchIndex:
+    """Everything ``SDNet.forward`` needs besides the reference's own batch tensors."""
+
+    def __init__(self, q_list, ocr_list, od_list, opt, device, bert=None):
+        wk_o, wk_q = opt["ocr_emb_initial"], opt["q_emb_initial"]
+        self.ocr = ItemIndex(ocr_list, wk_o, ocr_list["position"].size(1))
+        self.od = ItemIndex(od_list, wk_o, od_list["position"].size(1))
+        self.device = torch.device(device)
+        host = self.ocr.pack_host() + self.od.pack_host()
+        sizes = [len(a) for a in host]
+        buf = torch.from_numpy(np.concatenate(host)).to(self.device, non_blocking=True) if sum(sizes) else torch.zeros(0, dtype=torch.long, device=self.device)
+        parts = list(torch.split(buf, sizes))
+        n = len(ItemIndex._FIELDS)
+        self.ocr.bind(parts[:n])
+        self.od.bind(parts[n:])
+        self.ocr_mask = torch.from_numpy(self.ocr.mask).to(self.device, non_blocking=True)
+        self.od_mask = torch.from_numpy(self.od.mask).to(self.device, non_blocking=True)
+        # BERT: one packed pass over question + OCR items + object items, and the pooling descriptors
+        self.packed = None
+        self.spans = None
+        if bert is not None:
+            from .bert import PackedTokens, word_spans
+            groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
+            self.packed = PackedTokens(groups, self.device, pack=bert.pack)
+            spans = []
+            for g, (items, wk) in enumerate(((q_list, wk_q), (ocr_list, wk_o), (od_list, wk_o))):
+                wm = _np(items[wk + "_mask"])
+                arr = items.get("bert_offsets_arr")
+                if arr is None:
+                    arr = offsets_to_array(items["bert_offsets"], wm.shape[0], wm.shape[1])
+                s, l, d, rows = word_spans(self.packed, g, None, wm, offsets_arr=arr)
+                if g > 0:
+                    # destination = packed word row (item-major), not the padded n * Lw + j slot
+                    idx = self.ocr if g == 1 else self.od
+                    lut = np.full(wm.shape[0] * wm.shape[1], -1, dtype=np.int64)
+                    lut[idx.flat_word] = np.arange(idx.W)
+                    d = lut[d]
+                    keep = d >= 0                      # words beyond len_cnt never reach multi2one's consumed state
+                    s, l, d, rows = s[keep], l[keep], d[keep].astype(np.int32), idx.W
+                spans.append((s, l, d, rows))
+            cat = np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32)
+            dev = torch.from_numpy(cat).to(self.device, non_blocking=True)
+            o = 0
+            self.spans = []
+            for s, l, d, rows in spans:
+                W = len(s)
+                self.spans.append((dev[o:o + W], dev[o + W:o + 2 * W], dev[o + 2 * W:o + 3 * W], rows))
+                o += 3 * W
+
+
+def to_device(batch, device):
+    """The reference's ``SDNetTrainer.ToCUDA`` (Models/SDNetTrainer.py:208-230) without its per-tensor isnan() sync:
+    moves id / mask / position tensors of the three dicts and the targets."""
+    keys = {"bert", "bert_only", "bert_mask", "bert_only_mask", "fasttext", "fasttext_mask", "phoc", "phoc_mask", "glove",
+            "glove_mask", "ent", "pos", "position", "img_features", "img_spatials"}
+    out = []
+    for idx, item in enumerate(batch):
+        if idx < 3:
+            item = dict(item)
+            for k in list(item.keys()):
+                if k in keys and isinstance(item[k], torch.Tensor):
+                    item[k] = item[k].to(device, non_blocking=True)
+        elif idx == 3 and item is not None:
+            item = item.to(device, non_blocking=True)
+        out.append(item)
+    return out

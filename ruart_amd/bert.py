@@ -34,11 +34,11 @@ def _np(x):
 class BertEncoderWeights:
     """Device-resident encoder weights in the layout ruart_bert_forward expects."""
 
-    def __init__(self, state, cfg, device, dtype="bf16"):
+    def __init__(self, state, cfg, device, dtype="fp16"):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
-        self.dtype = hip.DT_BF16 if dtype in ("bf16", torch.bfloat16) else hip.DT_F32
-        self.tdtype = torch.bfloat16 if self.dtype == hip.DT_BF16 else torch.float32
+        self.dtype = hip.PRECISION[dtype]
+        self.tdtype = hip.TORCH_DTYPE[self.dtype]
         H = cfg["hidden_size"]
         nh = cfg["num_attention_heads"]
         if H % nh or H // nh != 64:
@@ -195,14 +195,14 @@ class _Buffers:
 
     def get(self, w, Tp):
         lib = hip.load()
-        es = 2 if w.dtype == hip.DT_BF16 else 4
-        need_l = w.n_layers * Tp * w.hidden
-        if self.layers is None or self.layers.numel() < need_l:
-            self.layers = torch.zeros(need_l, dtype=w.tdtype, device=w.device)
+        es = 4 if w.dtype == hip.DT_F32 else 2
+        need_l = w.n_layers * Tp * w.hidden * es                      # bytes
+        if self.layers is None or self.layers.numel() < need_l or self.layers.device != w.device:
+            self.layers = torch.zeros(need_l, dtype=torch.uint8, device=w.device)
         need_w = int(lib.ruart_bert_workspace_bytes(ctypes.byref(w.c_model), Tp))
-        if self.ws is None or self.ws.numel() < need_w:
+        if self.ws is None or self.ws.numel() < need_w or self.ws.device != w.device:
             self.ws = torch.zeros(need_w, dtype=torch.uint8, device=w.device)
-        return self.layers[:need_l].view(w.n_layers, Tp, w.hidden), self.ws, need_w
+        return self.layers[:need_l].view(w.tdtype).view(w.n_layers, Tp, w.hidden), self.ws, need_w
 
 
 _buffers = _Buffers()
@@ -286,7 +286,7 @@ def word_spans(packed, group, offsets, word_mask, offsets_arr=None):
 class Bert(nn.Module):
     """Drop-in for the reference's ``Bert`` module (Models/Bert/Bert.py:14-45).  ``opt`` keys used:
     BERT_LARGE, BERT_model_file / BERT_large_model_file, datadir, plus ruart extensions
-    ``bert_precision`` ('bf16' default | 'fp32') and ``bert_state`` / ``bert_config`` to pass weights in memory."""
+    ``bert_precision`` ('fp16' default | 'bf16' | 'fp32') and ``bert_state`` / ``bert_config`` to pass weights in memory."""
 
     def __init__(self, opt, device=None):
         super().__init__()
@@ -307,7 +307,7 @@ class Bert(nn.Module):
         if cfg["hidden_size"] != self.bert_dim or cfg["num_hidden_layers"] != self.bert_layer:
             raise ValueError("BERT checkpoint is %dx%d, conf expects %dx%d" % (cfg["num_hidden_layers"], cfg["hidden_size"],
                                                                               self.bert_layer, self.bert_dim))
-        self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "bf16"))
+        self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "fp16"))
         self.pack = not opt.get("bert_no_pack", False)
 
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------

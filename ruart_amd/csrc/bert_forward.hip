@@ -5,6 +5,8 @@
 #include "common.h"
 #include "ruart_hip.h"
 
+extern int ruart_prof_real_rows;
+
 extern "C" const char* ruart_version(void) { return "ruart_hip 0.1 gfx950"; }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -22,7 +24,7 @@ struct Carve {
 }  // namespace
 
 extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows) {
-  const size_t es = m->dtype == RUART_DT_BF16 ? 2 : 4;
+  const size_t es = m->dtype == RUART_DT_F32 ? 4 : 2;
   const size_t R = (size_t)n_rows, H = (size_t)m->hidden, I = (size_t)m->intermediate;
   size_t t = 0;
   t += align_up(R * H * es, 256);       // x0   embedding output
@@ -38,9 +40,10 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
                                   size_t workspace_bytes, void* stream) {
   const int H = m->hidden, I = m->intermediate, R = b->n_rows, dt = m->dtype;
   if (R % 128 || b->n_tokens > R || b->n_tokens <= 0 || H % 64 || m->n_heads * 64 != H) return (int)hipErrorInvalidValue;
-  if (dt == RUART_DT_BF16 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;
+  if (dt != RUART_DT_F32 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;
+  if (dt != RUART_DT_F32 && dt != RUART_DT_BF16 && dt != RUART_DT_F16) return (int)hipErrorInvalidValue;
   if (workspace_bytes < ruart_bert_workspace_bytes(m, R)) return (int)hipErrorInvalidValue;
-  const size_t es = dt == RUART_DT_BF16 ? 2 : 4;
+  const size_t es = dt == RUART_DT_F32 ? 4 : 2;
   Carve c{(char*)workspace, 0};
   void* x0 = c.take((size_t)R * H * es);
   void* qkv = c.take((size_t)R * 3 * H * es);
@@ -54,11 +57,12 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
   if (rc) return rc;
 
   auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act) {
-    if (dt == RUART_DT_BF16)
-      return ruart_gemm_bf16_nt(A, K, W, K, bias, res, N, RUART_DT_BF16, C, N, out_dt, R, N, K, act, stream);
+    if (dt != RUART_DT_F32)
+      return ruart_gemm_16_nt(A, K, W, K, bias, res, N, dt, C, N, out_dt, R, N, K, act, dt, stream);
     return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, R, N, K, act, stream);
   };
 
+  ruart_prof_real_rows = b->n_tokens;
   const void* in = x0;
   for (int l = 0; l < m->n_layers; ++l) {
     void* out = (char*)layers_out + (size_t)l * R * H * es;
@@ -73,5 +77,6 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
     if ((rc = ruart_rows_layernorm(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, H, dt, R, H, stream))) return rc;
     in = out;
   }
+  ruart_prof_real_rows = 0;
   return 0;
 }

@@ -302,6 +302,8 @@ extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma,
   const dim3 grid(ceil_div(rows, 4)), block(256);
   if (out_dtype == RUART_DT_BF16)
     hipLaunchKernelGGL(rows_layernorm_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (bf16_t*)out, ldo, rows, H);
+  else if (out_dtype == RUART_DT_F16)
+    hipLaunchKernelGGL(rows_layernorm_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (f16_t*)out, ldo, rows, H);
   else
     hipLaunchKernelGGL(rows_layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (float*)out, ldo, rows, H);
   RUART_CHECK_LAUNCH();
@@ -315,6 +317,8 @@ extern "C" int ruart_bert_embed_ln(const int* ids, const int* pos, const float* 
   const dim3 grid(ceil_div(rows, 4)), block(256);
   if (out_dtype == RUART_DT_BF16)
     hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb, gamma, beta, eps, (bf16_t*)out, ldo, rows, H);
+  else if (out_dtype == RUART_DT_F16)
+    hipLaunchKernelGGL(embed_ln_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb, gamma, beta, eps, (f16_t*)out, ldo, rows, H);
   else
     hipLaunchKernelGGL(embed_ln_kernel<float>, grid, block, 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb, gamma, beta, eps, (float*)out, ldo, rows, H);
   RUART_CHECK_LAUNCH();
@@ -328,6 +332,8 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
   const dim3 grid(n_blocks, n_heads), block(64);
   if (dtype == RUART_DT_BF16)
     hipLaunchKernelGGL(attn_varlen_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+  else if (dtype == RUART_DT_F16)
+    hipLaunchKernelGGL(attn_varlen_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
   else
     hipLaunchKernelGGL(attn_varlen_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
   RUART_CHECK_LAUNCH();
@@ -341,6 +347,8 @@ extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, i
   const dim3 grid(ceil_div(n_words, 4)), block(256);
   if (dtype == RUART_DT_BF16)
     hipLaunchKernelGGL(pool_mix_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+  else if (dtype == RUART_DT_F16)
+    hipLaunchKernelGGL(pool_mix_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
   else
     hipLaunchKernelGGL(pool_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
   RUART_CHECK_LAUNCH();
@@ -355,6 +363,8 @@ extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_strid
   const dim3 grid(nb), block(256);
   if (dtype == RUART_DT_BF16)
     hipLaunchKernelGGL(pool_mix_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+  else if (dtype == RUART_DT_F16)
+    hipLaunchKernelGGL(pool_mix_bwd_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
   else
     hipLaunchKernelGGL(pool_mix_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
   RUART_CHECK_LAUNCH();
@@ -363,11 +373,14 @@ extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_strid
   return 0;
 }
 
-extern "C" int ruart_cast_f32_to_bf16(const float* in, void* out, long long n, float scale, void* stream) {
-  if (n % 4) return (int)hipErrorInvalidValue;
+extern "C" int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n, float scale, void* stream) {
+  if (n % 4 || (out_dtype != RUART_DT_BF16 && out_dtype != RUART_DT_F16)) return (int)hipErrorInvalidValue;
   const size_t n4 = (size_t)n / 4;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n4, scale);
+  if (out_dtype == RUART_DT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n4, scale);
+  else
+    hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, in, (f16_t*)out, n4, scale);
   RUART_CHECK_LAUNCH();
   return 0;
 }

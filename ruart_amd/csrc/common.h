@@ -7,11 +7,15 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define RUART_DT_F32 0
 #define RUART_DT_BF16 1
+#define RUART_DT_F16 2
 
 #define RUART_CHECK_LAUNCH() \
   do {                       \
@@ -67,10 +71,30 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
   f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return r;
 }
+__device__ __forceinline__ f32x4_t load4(const f16_t* p) {
+  f16x4_t v = *reinterpret_cast<const f16x4_t*>(p);
+  f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+__device__ __forceinline__ void store4(f16_t* p, f32x4_t v) {
+  f16x4_t r = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+  *reinterpret_cast<f16x4_t*>(p) = r;
+}
 __device__ __forceinline__ void store4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
 __device__ __forceinline__ void store4(bf16_t* p, f32x4_t v) {
   bf16x4_t r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
   *reinterpret_cast<bf16x4_t*>(p) = r;
+}
+
+// 16-bit MFMA forms: identical rate and fragment layout for bf16 and f16 (MI355X_MICROARCH.md, Matrix cores)
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> { typedef bf16x8_t type; };
+template <> struct Vec8<f16_t> { typedef f16x8_t type; };
+__device__ __forceinline__ f32x4_t mfma_16x16x32(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma_16x16x32(f16x8_t a, f16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 // XCD-aware remap of a linear workgroup id (cdna_hip_programming.md §5 T1, bijective form):

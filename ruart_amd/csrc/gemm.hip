@@ -7,7 +7,7 @@
 // the layer-norm itself is ruart_rows_layernorm).  Both operands are K-contiguous ("NT"),
 // which is exactly the torch nn.Linear weight layout, so checkpoints load without a transpose.
 //
-//  * gemm_bf16_nt_128: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//  * gemm_16_nt_128: bf16 or f16 operands, fp32 accumulate on v_mfma_f32_16x16x32_{bf16,f16} (same rate).
 //    128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
 //    LDS tiles are [128 rows][64 k] bf16 with the 16-byte chunk index XOR-swizzled by (row & 7),
 //    which makes every ds_read_b128 fragment read conflict-free (cdna_hip_programming.md T2).
@@ -31,9 +31,9 @@ __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + e
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
-template <bool OUT_F32, int RES /*0 none, 1 bf16, 2 f32*/, int ACT /*0 none 1 gelu*/>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_128(const bf16_t* __restrict__ A, int lda,
-                                                        const bf16_t* __restrict__ W, int ldw,
+template <typename T16, bool OUT_F32, int RES /*0 none, 1 same 16-bit type, 2 f32*/, int ACT /*0 none 1 gelu*/>
+__global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A, int lda,
+                                                      const T16* __restrict__ W, int ldw,
                                                         const float* __restrict__ bias, const void* __restrict__ R, int ldr,
                                                         void* __restrict__ C, int ldc, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_128(const bf16_t* __restrict
     srow[i] = q >> 3;
     sch[i] = q & 7;
   }
-  const bf16_t* Ag = A + (size_t)m0 * lda;
-  const bf16_t* Wg = W + (size_t)n0 * ldw;
+  const T16* Ag = A + (size_t)m0 * lda;
+  const T16* Wg = W + (size_t)n0 * ldw;
 
   uint4 ra[4], rb[4];
   auto gload = [&](int k0) {
@@ -89,16 +89,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_128(const bf16_t* __restrict
     if (t + 1 < nt) gload((t + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t wf[4], af[4];
+      typedef typename Vec8<T16>::type frag_t;
+      frag_t wf[4], af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const bf16x8_t*>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        af[i] = *reinterpret_cast<const bf16x8_t*>(smem + cur * kStage + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        wf[i] = *reinterpret_cast<const frag_t*>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        af[i] = *reinterpret_cast<const frag_t*>(smem + cur * kStage + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(wf[i], af[j], acc[i][j]);
     }
     if (t + 1 < nt) lwrite(cur ^ 1);
     __syncthreads();
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_128(const bf16_t* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
-      if (RES == 1) v += load4(reinterpret_cast<const bf16_t*>(R) + (size_t)m * ldr + n);
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
       if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
       if (OUT_F32)
         store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
       else
-        store4(reinterpret_cast<bf16_t*>(C) + (size_t)m * ldc + n, v);
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
     }
   }
 }
@@ -224,19 +225,53 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_64(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int ruart_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
-                                  int ldr, int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
-                                  void* stream) {
-  if (M % BM || N % BN || K % BK || (lda & 7) || (ldw & 7) || (ldc & 3)) return (int)hipErrorInvalidValue;
-  if (act != RUART_ACT_NONE && act != RUART_ACT_GELU) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
+// ---- optional live profiling of the dominant kernel (bench.py roofline): hipEvent pair around every 16-bit GEMM launch
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+std::vector<ProfRec> g_prof_pool;
+size_t g_prof_used = 0;
+bool g_prof_on = false;
+}  // namespace
+int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
+
+extern "C" int ruart_prof_enable(int on) {
+  if (on && g_prof_pool.empty()) {
+    g_prof_pool.resize(8192);
+    for (auto& r : g_prof_pool) {
+      if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return (int)hipErrorOutOfMemory;
+    }
+  }
+  g_prof_on = on != 0;
+  g_prof_used = 0;
+  return 0;
+}
+
+extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* flops) {
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(g_prof_pool[i].b);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipEventElapsedTime(&t, g_prof_pool[i].a, g_prof_pool[i].b)) != hipSuccess) return (int)e;
+    ms += t;
+    fl += g_prof_pool[i].flops;
+  }
+  *total_ms = ms;
+  *launches = (long long)g_prof_used;
+  *flops = fl;
+  g_prof_used = 0;
+  return 0;
+}
+
+template <typename T16>
+static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, int res,
+                         void* C, int ldc, bool of, int M, int N, int K, int act, hipStream_t s) {
   const dim3 grid((M / BM) * (N / BN)), block(256);
-  const int res = residual ? (residual_dtype == RUART_DT_BF16 ? 1 : 2) : 0;
-  const bf16_t* a = (const bf16_t*)A;
-  const bf16_t* w = (const bf16_t*)W;
+  const T16* a = (const T16*)A;
+  const T16* w = (const T16*)W;
 #define LAUNCH(OF, RS, AC) \
-  hipLaunchKernelGGL((gemm_bf16_nt_128<OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K)
-  const bool of = out_dtype == RUART_DT_F32;
+  hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K)
   if (act == RUART_ACT_GELU) {
     if (res != 0) return (int)hipErrorInvalidValue;
     if (of) LAUNCH(true, 0, 1); else LAUNCH(false, 0, 1);
@@ -250,6 +285,32 @@ extern "C" int ruart_gemm_bf16_nt(const void* A, int lda, const void* W, int ldw
 #undef LAUNCH
   RUART_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
+                                int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
+                                void* stream) {
+  if (M % BM || N % BN || K % BK || (lda & 7) || (ldw & 7) || (ldc & 3)) return (int)hipErrorInvalidValue;
+  if (act != RUART_ACT_NONE && act != RUART_ACT_GELU) return (int)hipErrorInvalidValue;
+  if (in_dtype != RUART_DT_BF16 && in_dtype != RUART_DT_F16) return (int)hipErrorInvalidValue;
+  if (out_dtype != RUART_DT_F32 && out_dtype != in_dtype) return (int)hipErrorInvalidValue;
+  if (residual && residual_dtype != RUART_DT_F32 && residual_dtype != in_dtype) return (int)hipErrorInvalidValue;
+  const int res = residual ? (residual_dtype == RUART_DT_F32 ? 2 : 1) : 0;
+  const bool of = out_dtype == RUART_DT_F32;
+  ProfRec* rec = nullptr;
+  if (g_prof_on && g_prof_used < g_prof_pool.size()) {
+    rec = &g_prof_pool[g_prof_used++];
+    const int rows = (ruart_prof_real_rows > 0 && ruart_prof_real_rows <= M) ? ruart_prof_real_rows : M;
+    rec->flops = 2.0 * rows * (double)N * K;
+    hipEventRecord(rec->a, (hipStream_t)stream);
+  }
+  int rc;
+  if (in_dtype == RUART_DT_BF16)
+    rc = launch_gemm16<bf16_t>(A, lda, W, ldw, bias, residual, ldr, res, C, ldc, of, M, N, K, act, (hipStream_t)stream);
+  else
+    rc = launch_gemm16<f16_t>(A, lda, W, ldw, bias, residual, ldr, res, C, ldc, of, M, N, K, act, (hipStream_t)stream);
+  if (rec) hipEventRecord(rec->b, (hipStream_t)stream);
+  return rc;
 }
 
 extern "C" int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,

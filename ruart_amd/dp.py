@@ -1,0 +1,111 @@
+"""Single-node data parallelism for the SDNet training step: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference has no distributed code at all; this is the new exchange step the north star
+asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
+  * every rank runs the whole step on its own B-sample shard (samples are independent; the whole-tensor layer
+    norm couples samples only inside a replica, so the semantics are "N reference steps, gradients averaged");
+  * only what must move moves: trainable, actually-used parameters.  The dead ``get_answer.rnn.*`` GRU (never gets a
+    gradient, Models/Layers.py:395-397) is excluded.  The word-embedding rows >= tune_partial are re-pinned after every
+    step (Models/SDNetTrainer.py:369-373) so their update never survives - but their gradients DO enter the global
+    clipping norm (:366), so by default they are exchanged too (every rank must clip by the same coefficient or the
+    replicas drift).  ``opt['dp_skip_pinned_rows']`` exchanges rows < tune_partial only and zeroes the rest on every
+    rank: ~37 MB fp32 per step instead of 37 MB + 2 * (V - tune_partial) * 300 * 4, at the price of a clip norm
+    that ignores the pinned rows;
+  * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
+    win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order and each
+    bucket's all-reduce is launched asynchronously the moment its last gradient is produced, overlapping the rest
+    of backward; ``average_gradients`` waits, scales by 1/world and scatters back;
+  * works unchanged on the gloo backend (CPU tensors) - that is how the N>1 path is tested without GPUs.
+"""
+import torch
+import torch.distributed as dist
+
+UNUSED_PREFIXES = ("get_answer.rnn.",)
+
+
+class GradSync:
+    def __init__(self, network, opt, group=None, bucket_bytes=16 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.network = network
+        tp = opt.get("tune_partial") if ("TUNE_PARTIAL" in opt and opt.get("dp_skip_pinned_rows")) else None
+        entries = []                       # (name, param, rows or None)
+        for name, p in network.named_parameters():
+            if not p.requires_grad or name.startswith(UNUSED_PREFIXES):
+                continue
+            rows = tp if (tp is not None and name in ("fast_embed.weight", "glove_embed.weight")) else None
+            entries.append((name, p, rows))
+        entries.reverse()                  # gradients arrive roughly in reverse registration order
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for e in entries:
+            n = (e[1][:e[2]] if e[2] is not None else e[1]).numel()
+            if cur and cur_bytes + 4 * n > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(e)
+            cur_bytes += 4 * n
+        if cur:
+            self.buckets.append(cur)
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for (_, p, _) in b:
+                self._bucket_of[p] = bi
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+        self.payload_bytes = sum(4 * ((p[:r] if r is not None else p).numel()) for b in self.buckets for (_, p, r) in b)
+        self._reset()
+
+    def _reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+
+    def _make_hook(self, bi):
+        def hook(param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _views(self, bi):
+        out = []
+        for (_, p, rows) in self.buckets[bi]:
+            g = p.grad
+            if g is None:                  # a used parameter can still miss a gradient on some batch (e.g. empty group)
+                g = torch.zeros_like(p)
+                p.grad = g
+            out.append(g[:rows] if rows is not None else g)
+        return out
+
+    def _launch(self, bi):
+        views = self._views(bi)
+        flat = torch.cat([v.reshape(-1) for v in views])
+        self._flat[bi] = flat
+        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def average_gradients(self):
+        """Call after ``loss.backward()``: finishes the outstanding bucket all-reduces and writes the averaged
+        gradients back in place."""
+        for bi in range(len(self.buckets)):
+            if self._work[bi] is None:     # some gradient of this bucket never fired its hook
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi in range(len(self.buckets)):
+            self._work[bi].wait()
+            flat = self._flat[bi]
+            o = 0
+            for v, (_, p, rows) in zip(self._views(bi), self.buckets[bi]):
+                n = v.numel()
+                v.copy_(flat[o:o + n].view_as(v) * inv)
+                o += n
+                if rows is not None:
+                    p.grad[rows:].zero_()
+            self._flat[bi] = None
+        self._reset()
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank ``src``'s weights (and buffers)."""
+        for t in list(self.network.parameters()) + list(self.network.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)

@@ -14,8 +14,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libruart_hip.so")
 
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+TORCH_DTYPE = {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}
+PRECISION = {"fp32": DT_F32, "bf16": DT_BF16, "fp16": DT_F16}
 
 
 class BertModelC(Structure):
@@ -39,14 +41,14 @@ class BertBatchC(Structure):
 _P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
 _SIGNATURES = {
     "ruart_version": (c_char_p, []),
-    "ruart_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_f32_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
-    "ruart_cast_f32_to_bf16": (_I, [_P, _P, _LL, _F, _P]),
+    "ruart_cast_f32_to_16": (_I, [_P, _P, _I, _LL, _F, _P]),
     "ruart_bert_workspace_bytes": (c_size_t, [POINTER(BertModelC), _I]),
     "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),
     "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -56,6 +58,8 @@ _SIGNATURES = {
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
+    "ruart_prof_enable": (_I, [_I]),
+    "ruart_prof_read": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -1,0 +1,286 @@
+"""``SDNet`` - drop-in for the reference's model class (Models/SDNet.py:20-437) on MI355X.
+
+Same constructor signature ``SDNet(opt, embedding)``, same ``forward(q_list, ocr_list, od_list, return_score=False)
+-> (score_s (B, max_ocr_num + 1), None)``, same sub-module / parameter names (so ``state_dict`` keys match the
+reference's checkpoints), same mutable ``drop_emb`` attribute the trainer flips.
+
+What is different underneath (results identical up to fp32 summation order; BERT in bf16 by default):
+  * one packed BERT pass per step for question + OCR items + object items (ruart_bert_forward), sub-word pooling and
+    the alpha/gamma layer mix fused in one kernel;
+  * OCR / object words stay in a packed (real words, D) matrix: embedding concat, pre-align scatter/gather and the
+    ``multi2one`` LSTM run over real words only; the reference's four Python loops in ``get_prealign_emb`` and the
+    per-item gather loop (:300-318) are index_put / gather with index vectors prepared once per batch (batch.py);
+  * every LSTM recurrence, attention score/softmax/context and whole-tensor layer norm is a HIP kernel (ops.py);
+  * the reference's per-op ``assert isnan == 0`` device syncs are one flag check per forward.
+
+Supported configuration: the shipped conf and its simple toggles.  Branches the shipped conf does not enable
+(img_feature, fixed_answers, ES post_process, ModelParallel, PRE_ALIGN_after_rnn, label_yesno, bidirectional
+multi2one) raise NotImplementedError - they are out of the hot path's scope.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import layers as L
+from . import ops
+from .batch import BatchIndex
+from .bert import Bert, _PoolMix, bert_encode
+from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RNN_from_opt, dropout, row_dropout
+
+_UNSUPPORTED = ("img_feature", "fixed_answers", "ModelParallel", "PRE_ALIGN_after_rnn", "label_yesno", "no_Context_Self_Attention",
+                "no_DeepAttention")
+
+
+class SDNet(nn.Module):
+    def __init__(self, opt, embedding):
+        super().__init__()
+        for k in _UNSUPPORTED:
+            if k in opt:
+                raise NotImplementedError("conf key %r selects a branch outside the accelerated hot path" % k)
+        if "ES_ocr" in opt and opt.get("ES_using_way") == "post_process":
+            raise NotImplementedError("ES_using_way post_process is outside the accelerated hot path")
+        if opt.get("multi2one_bidir"):
+            raise NotImplementedError("bidirectional multi2one is outside the accelerated hot path")
+        self.opt = opt
+        self.vocab_dim = 300
+        self.use_cuda = opt.get("cuda") is True
+        self.q_embedding = opt["q_embedding"].split(",")
+        self.ocr_embedding = opt["ocr_embedding"].split(",")
+        self.drop_emb = False
+        L.set_dropout_prob(0.0 if "DROPOUT" not in opt else float(opt["DROPOUT"]))
+        L.set_seq_dropout("VARIATIONAL_DROPOUT" in opt)
+
+        x_in = q_in = 0
+        for flag, attr, key, dim_key in (("PHOC", "phoc_embed", "phoc_embedding", "phoc_dim"),
+                                         ("FastText", "fast_embed", "fast_embedding", "fast_dim"),
+                                         ("GLOVE", "glove_embed", "glove_embedding", "glove_dim")):
+            if flag in opt:
+                self.vocab_size = int(opt["vocab_size"])
+                emb = nn.Embedding(self.vocab_size, int(opt[dim_key]), padding_idx=1)
+                emb.weight.data = embedding[key].clone()
+                setattr(self, attr, emb)
+        self.glove_dim = int(opt.get("glove_dim", 0))
+        self.fast_dim = int(opt.get("fast_dim", 0))
+        self.phoc_dim = int(opt.get("phoc_dim", 0))
+        for name, dim in (("glove", self.glove_dim), ("fasttext", self.fast_dim), ("phoc", self.phoc_dim)):
+            x_in += dim if name in self.ocr_embedding else 0
+            q_in += dim if name in self.q_embedding else 0
+        if "TUNE_PARTIAL" in opt:
+            if "FastText" in opt:
+                self.fixed_embedding_fast = embedding["fast_embedding"][opt["tune_partial"]:]
+            if "GLOVE" in opt:
+                self.fixed_embedding_glove = embedding["glove_embedding"][opt["tune_partial"]:]
+        else:
+            if "FastText" in opt:
+                self.fast_embed.weight.requires_grad = False
+            if "GLOVE" in opt:
+                self.glove_embed.weight.requires_grad = False
+
+        if "BERT" in opt:
+            self.Bert = Bert(opt, device=opt.get("device", "cuda"))
+            if "LOCK_BERT" not in opt:
+                raise NotImplementedError("fine-tuning BERT (no LOCK_BERT) is a later scope row (SURVEY.md section 8f)")
+            bert_dim, bert_layers = (1024, 24) if "BERT_LARGE" in opt else (768, 12)
+            if "BERT_LINEAR_COMBINE" not in opt:
+                raise NotImplementedError("the hot path is BERT_LINEAR_COMBINE (all layers mixed)")
+            self.alphaBERT = nn.Parameter(torch.ones(bert_layers))
+            self.gammaBERT = nn.Parameter(torch.ones(1, 1))
+            x_in += bert_dim if "bert" in self.ocr_embedding else 0
+            q_in += bert_dim if "bert" in self.q_embedding else 0
+        if "PRE_ALIGN" in opt:
+            self.pre_align = Attention(self.vocab_dim, opt["prealign_hidden"], correlation_func=3, do_similarity=True)
+            if "PRE_ALIGN_befor_rnn" in opt:
+                x_in += self.vocab_dim
+        if "pos" in self.q_embedding or "pos" in self.ocr_embedding:
+            self.pos_embedding = nn.Embedding(int(opt.get("pos_vocab_size", 51)), opt["pos_dim"])
+            x_in += opt["pos_dim"] if "pos" in self.ocr_embedding else 0
+            q_in += opt["pos_dim"] if "pos" in self.q_embedding else 0
+        if "ent" in self.q_embedding or "pos" in self.ocr_embedding:      # sic: the reference tests 'pos' here (SDNet.py:126)
+            self.ent_embedding = nn.Embedding(int(opt.get("ent_vocab_size", 75)), opt["ent_dim"])
+            x_in += opt["ent_dim"] if "ent" in self.ocr_embedding else 0
+            q_in += opt["ent_dim"] if "ent" in self.q_embedding else 0
+
+        self.multi2one, m2o = RNN_from_opt(x_in, opt["multi2one_hidden_size"], num_layers=1, concat_rnn=opt["concat_rnn"],
+                                           bidirectional=opt["multi2one_bidir"])
+        self.multi2one_output_size = m2o
+        self.context_rnn, ctx_out = RNN_from_opt(m2o, opt["hidden_size"], num_layers=opt["in_rnn_layers"], concat_rnn=opt["concat_rnn"])
+        self.ques_rnn, q_out = RNN_from_opt(q_in, opt["hidden_size"], num_layers=opt["in_rnn_layers"], concat_rnn=opt["concat_rnn"])
+        word_hidden = 0 if ("GLOVE" not in opt and "FastText" not in opt) else m2o
+        self.deep_attn = DeepAttention(opt, abstr_list_cnt=opt["in_rnn_layers"],
+                                       deep_att_hidden_size_per_abstr=opt["deep_att_hidden_size_per_abstr"], correlation_func=3,
+                                       word_hidden_size=word_hidden)
+        self.deep_attn_input_size = self.deep_attn.rnn_input_size
+        self.deep_attn_output_size = self.deep_attn.output_size
+        self.high_lvl_ques_rnn, hq_out = RNN_from_opt(q_out * opt["in_rnn_layers"], opt["highlvl_hidden_size"],
+                                                      num_layers=opt["question_high_lvl_rnn_layers"], concat_rnn=True)
+        self.after_deep_attn_size = self.deep_attn_output_size + self.deep_attn_input_size + m2o
+        self.self_attn_input_size = self.after_deep_attn_size
+        self.highlvl_self_att = Attention(self.self_attn_input_size, opt["deep_att_hidden_size_per_abstr"], correlation_func=3)
+        self.high_lvl_context_rnn, ctx_final = RNN_from_opt(self.deep_attn_output_size * 2, opt["highlvl_hidden_size"], num_layers=1,
+                                                            concat_rnn=False)
+        self.ques_self_attn = Attention(hq_out, opt["query_self_attn_hidden_size"], correlation_func=3)
+        q_final = hq_out
+        pos_out = 0
+        if "position_dim" in opt:
+            if opt["position_mod"] == "qk+":
+                self.od_ocr_attn = Attention(ctx_final, opt["hidden_size"], correlation_func=3, do_similarity=True)
+                self.position_attn = Attention(opt["position_dim"], opt["hidden_size"], correlation_func=3, do_similarity=True)
+                pos_out = ctx_final
+            elif opt["position_mod"] == "cat":
+                self.od_ocr_attn = Attention(ctx_final + opt["position_dim"], opt["hidden_size"], correlation_func=3, do_similarity=True)
+                pos_out = ctx_final + opt["position_dim"]
+        self.ques_merger = LinearSelfAttn(q_final)
+        ocr_final = {"cat": ctx_final + pos_out, "atted": pos_out, "original": ctx_final}[opt["pos_att_merge_mod"]]
+        self.get_answer = GetFinalScores(ocr_final, q_final, yesno=False, no_answer="label_no_answer" in opt, useES="useES" in opt)
+
+    # ------------------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.alphaBERT.device
+
+    def prepare(self, q_list, ocr_list, od_list):
+        """Build (or fetch) the per-batch index vectors and the packed BERT stream; cached on the batch dict."""
+        bi = q_list.get("_ruart_index")
+        if bi is None or bi.device != self.device:
+            bi = BatchIndex(q_list, ocr_list, od_list, self.opt, self.device, bert=self.Bert)
+            q_list["_ruart_index"] = bi
+        return bi
+
+    def _layer_weights(self):
+        """softmax(alpha)_l * gamma - the scalar each BERT layer is mixed with (SDNet.py:574-576)."""
+        return F.softmax(self.alphaBERT, dim=0) * self.gammaBERT.view(1)
+
+    def _word_table(self, key):
+        return {"fasttext": "fast_embed", "glove": "glove_embed", "phoc": "phoc_embed"}[key]
+
+    def _embed_question(self, q_list, bert_mix):
+        dev = self.device
+        parts, raw = [], None
+        p_emb = self.opt.get("dropout_emb", 0.0)
+        for key in ("phoc", "fasttext", "glove"):
+            if key in self.q_embedding:
+                e = getattr(self, self._word_table(key))(q_list[key].to(dev))
+                if key == self.opt["q_emb_initial"]:
+                    raw = e
+                parts.append(dropout(e, p=p_emb, training=self.drop_emb) if "dropout_emb" in self.opt else e)
+        if "bert" in self.q_embedding:
+            parts.append(dropout(bert_mix, p=p_emb, training=self.drop_emb))
+        if "pos" in self.q_embedding:
+            parts.append(self.pos_embedding(q_list["pos"].to(dev)))
+        if "ent" in self.q_embedding:
+            parts.append(self.ent_embedding(q_list["ent"].to(dev)))
+        return torch.cat(parts, -1), raw
+
+    def _embed_items(self, items, idx, bert_mix):
+        """Packed (W, D) embedding of the real words of an item group (the reference's get_embedding_from_list,
+        SDNet.py:439-493, restricted to the rows its consumers read)."""
+        dev = self.device
+        d = idx.dev
+        parts, raw = [], None
+        p_emb = self.opt.get("dropout_emb", 0.0)
+        for key in ("phoc", "fasttext", "glove"):
+            if key in self.ocr_embedding:
+                ids = items[key].to(dev).reshape(-1)[d["flat_word"]]
+                e = getattr(self, self._word_table(key))(ids)
+                if key == self.opt["ocr_emb_initial"]:
+                    raw = e
+                parts.append(row_dropout(e, d["item_of_word"], idx.N, p_emb, self.drop_emb) if "dropout_emb" in self.opt else e)
+        if "bert" in self.ocr_embedding:
+            parts.append(row_dropout(bert_mix, d["item_of_word"], idx.N, p_emb, self.drop_emb))
+        if "pos" in self.ocr_embedding:
+            parts.append(self.pos_embedding(items["pos"].to(dev).reshape(-1)[d["flat_word"]]))
+        if "ent" in self.ocr_embedding:
+            parts.append(self.ent_embedding(items["ent"].to(dev).reshape(-1)[d["flat_word"]]))
+        return torch.cat(parts, -1), raw
+
+    def _prealign(self, raw_words, idx, q_raw, q_mask):
+        """SDNet.py:495-551 without the loops: scatter each sample's words into one row, attend over the question's
+        raw word vectors, gather back."""
+        d = idx.dev
+        x1 = raw_words.new_zeros(idx.B, max(idx.Tmax, 1), raw_words.size(1))
+        x1 = x1.index_put((d["sample_of_word"], d["tok_in_sample"]), raw_words)
+        att = self.pre_align(x1, q_raw, q_mask)
+        return att[d["sample_of_word"], d["tok_in_sample"]]
+
+    def _multi2one_last(self, x_words, idx):
+        """``multi2one`` (uni-directional LSTM, SDNet.py:137, 269-271) over real words only, returning the state at
+        each item's last word already scattered to (B, max_num, hidden) - what SDNet.py:288-318 builds item by item."""
+        d = idx.dev
+        rnn = self.multi2one.rnns[0]
+        if L.dropout_p > 0:
+            x_words = row_dropout(x_words, d["item_of_word"], idx.N, L.dropout_p, self.training)
+        xproj = torch.addmm(rnn.bias_ih_l0 + rnn.bias_hh_l0, x_words, rnn.weight_ih_l0.t())
+        Hh = rnn.weight_hh_l0.shape[1]
+        steps = torch.split(xproj[d["step_rows"]], idx.n_active)
+        h0 = x_words.new_zeros(idx.N, Hh)
+        h, _ = L.lstm_cell_steps(steps, rnn.weight_hh_l0, idx.n_active, h0, h0)
+        out = x_words.new_zeros(idx.B, idx.max_num, Hh)
+        return out.index_put((d["sorted_sample"], d["sorted_slot"]), h)
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, q_list, ocr_list, od_list, return_score=False):
+        if return_score:
+            raise NotImplementedError("att_score output is not part of the hot path")
+        opt = self.opt
+        dev = self.device
+        bi = self.prepare(q_list, ocr_list, od_list)
+
+        # ---- BERT: one packed pass, then pooled + mixed per group --------------------------------------------
+        layers = bert_encode(self.Bert.weights, bi.packed)
+        lw = self._layer_weights()
+        H = self.Bert.weights.hidden
+        mixes = []
+        for (s, l, dst, rows) in bi.spans:
+            mixes.append(_PoolMix.apply(lw, layers, s, l, dst, rows, self.Bert.weights.dtype))
+        Bq, Q = q_list[opt["q_emb_initial"]].shape
+        q_bert = mixes[0].view(Bq, Q, H)
+
+        q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev)
+        q_input, q_raw = self._embed_question(q_list, q_bert)
+        ocr_words, ocr_raw = self._embed_items(ocr_list, bi.ocr, mixes[1])
+        od_words, od_raw = self._embed_items(od_list, bi.od, mixes[2])
+        if "PRE_ALIGN_befor_rnn" in opt:
+            q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
+            ocr_words = torch.cat([ocr_words, self._prealign(ocr_raw, bi.ocr, q_raw, q_mask)], -1)
+            od_words = torch.cat([od_words, self._prealign(od_raw, bi.od, q_raw, q_mask)], -1)
+
+        ocr_input = self._multi2one_last(ocr_words, bi.ocr)                     # (B, max_ocr_num, 300)
+        od_input = self._multi2one_last(od_words, bi.od)                        # (B, max_od_num, 300)
+        ocr_mask, od_mask = bi.ocr_mask, bi.od_mask
+
+        # ---- SDNet trunk (SDNet.py:338-415) -------------------------------------------------------------------
+        _, ocr_rnn_layers = self.context_rnn(ocr_input, ocr_mask, return_list=True, LN=True)
+        _, q_rnn_layers = self.ques_rnn(q_input, q_mask, return_list=True, LN=True)
+        _, od_rnn_layers = self.context_rnn(od_input, od_mask, return_list=True, LN=True)
+        q_highlvl = self.high_lvl_ques_rnn(torch.cat(q_rnn_layers, 2), q_mask, LN=True)
+        q_rnn_layers = q_rnn_layers + [q_highlvl]
+
+        q_long = [q_raw]
+        ocr_h, ocr_pre = self.deep_attn([ocr_input], ocr_rnn_layers, q_long, q_rnn_layers, ocr_mask, q_mask, return_bef_rnn=True)
+        od_h, od_pre = self.deep_attn([od_input], od_rnn_layers, q_long, q_rnn_layers, od_mask, q_mask, return_bef_rnn=True)
+
+        ocr_sa_in = torch.cat([ocr_h, ocr_pre, ocr_input], 2)
+        od_sa_in = torch.cat([od_h, od_pre, od_input], 2)
+        ocr_sa = self.highlvl_self_att(ocr_sa_in, ocr_sa_in, ocr_mask, x3=ocr_h)
+        od_sa = self.highlvl_self_att(od_sa_in, od_sa_in, od_mask, x3=od_h)
+        ocr_hl = self.high_lvl_context_rnn(torch.cat([ocr_h, ocr_sa], 2), ocr_mask, LN=True)
+        od_hl = self.high_lvl_context_rnn(torch.cat([od_h, od_sa], 2), od_mask, LN=True)
+
+        if "position_dim" in opt:
+            ocr_pos, od_pos = ocr_list["position"].to(dev), od_list["position"].to(dev)
+            if opt["position_mod"] == "qk+":
+                x_od_ocr = self.od_ocr_attn(ocr_hl, od_hl, od_mask) + self.position_attn(ocr_pos, od_pos, od_mask, x3=od_hl)
+            else:
+                x_od_ocr = self.od_ocr_attn(torch.cat([ocr_hl, ocr_pos], 2), torch.cat([od_hl, od_pos], 2), od_mask)
+        mode = opt["pos_att_merge_mod"]
+        ocr_final = torch.cat([ocr_hl, x_od_ocr], 2) if mode == "cat" else (x_od_ocr if mode == "atted" else ocr_hl)
+
+        q_final = self.ques_self_attn(q_highlvl, q_highlvl, q_mask)
+        q_merged = self.ques_merger.merge(q_final, q_mask)
+        es_len = opt["ES_ocr_len"] if "useES" in opt else None
+        score_s = self.get_answer(ocr_final, q_merged, ocr_mask, es_len, mask_flag="mask_score" in opt)
+        return score_s, None
+
+    def check_nan(self):
+        """One host sync honouring every ``assert torch.sum(torch.isnan(.)) == 0`` of the reference's forward."""
+        ops.nan_flag.check_and_clear()

@@ -203,7 +203,7 @@ def _bertify(g, n_words, bert_vocab, max_bert_len, p2=0.4):
     offs = []
     for c in pieces:
         offs.append([len(ids), len(ids) + int(c)])
-        ids.extend(int(v) for v in g.integers(1000, bert_vocab, size=int(c)))
+        ids.extend(int(v) for v in g.integers(1000 if bert_vocab > 1500 else 10, bert_vocab, size=int(c)))
     ids.append(102)
     return ids, offs
 

@@ -1,0 +1,228 @@
+"""``SDNetTrainer`` / ``BaseTrainer`` - the reference's training-loop surface (Models/SDNetTrainer.py:29-518,
+Models/BaseTrainer.py:6-69) over the MI355X hot path, plus single-node data parallelism.
+
+Kept from the reference: ``setup_model(vocab_embedding)``, ``update(batch, batch_i) -> float``, ``predict(batch)``,
+``evaluate(data_loader, ...)``, ``ToCUDA(batch)``, ``load_model(path)``, ``save_for_predict(path)``,
+``instance_bce_with_logits`` (the probabilities are fed to BCE-with-logits and scaled by the label width, :510-518),
+optimizer selection by ``opt['optimizer']`` (:307-317), global-norm clipping (:366), re-pinning of embedding rows
+>= ``tune_partial`` after every step (:369-373), checkpoint format (:492-509, 453-466).
+
+New: ``world_size > 1`` => one process per GPU, gradients averaged with RCCL (dp.GradSync) before clipping; every rank
+holds identical parameters, so the step is "N independent B-sample reference steps with averaged gradients"
+(SURVEY.md section 8e).  Offline preprocessing, msgpack readers and the spaCy/fastText tooling are out of scope: ``train``
+takes any iterable of collated batches.
+"""
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import layers as L
+from .batch import to_device
+from .sdnet import SDNet
+
+log = logging.getLogger(__name__)
+
+
+class AverageMeter:
+    """Utils/CoQAUtils.py:837-858."""
+
+    def __init__(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+class BaseTrainer:
+    def __init__(self, opt):
+        self.opt = opt
+        self.isTrain = False
+        self.use_cuda = opt.get("cuda") is True
+        self.saveFolder = opt.get("saveFolder", ".")
+
+
+class SDNetTrainer(BaseTrainer):
+    def __init__(self, opt, device=None, process_group=None):
+        super().__init__(opt)
+        L.set_dropout_prob(0.0 if "DROPOUT" not in opt else float(opt["DROPOUT"]))
+        self.seed = int(opt["SEED"])
+        random.seed(self.seed)
+        np.random.seed(self.seed)
+        torch.manual_seed(self.seed)
+        self.batch_size = opt["batch_size"]
+        self.device = torch.device(device if device is not None else "cuda")
+        self.process_group = process_group
+        self.grad_sync = None
+        self.fixed_answers_len = 0
+        self.updates = 0
+
+    # -- model / optimizer ------------------------------------------------------------------------------------
+    def setup_model(self, vocab_embedding):
+        self.train_loss = AverageMeter()
+        opt = dict(self.opt)
+        opt["device"] = self.device
+        self.network = SDNet(opt, vocab_embedding).to(self.device)
+        for name in ("fixed_embedding_fast", "fixed_embedding_glove"):
+            if hasattr(self.network, name):
+                setattr(self.network, name, getattr(self.network, name).to(self.device))
+        params = [p for p in self.network.parameters() if p.requires_grad]
+        o = self.opt["optimizer"]
+        if o == "ADAM":
+            self.optimizer = optim.Adamax(params, weight_decay=0.5, lr=1e-3)
+        elif o == "#":
+            self.optimizer = optim.Adamax(params, lr=self.opt.get("lr", 2e-3))
+        elif o == "ADAM2":
+            self.optimizer = optim.Adam(params, lr=self.opt.get("lr", 1e-3))
+        elif o == "SGD":
+            self.optimizer = optim.SGD(params, lr=self.opt["lr"])
+        else:
+            raise ValueError("optimizer is wrong")
+        if self.opt["loss"] in ("BCE", "BCE_D1"):
+            self.loss_func = self.instance_bce_with_logits
+        elif self.opt["loss"] == "CE":
+            self.loss_func = nn.functional.cross_entropy
+        else:
+            raise ValueError("loss parameter is error")
+        self.updates = 0
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                              and torch.distributed.get_world_size() > 1):
+            from .dp import GradSync
+            self.grad_sync = GradSync(self.network, self.opt, group=self.process_group)
+            self.grad_sync.broadcast_parameters()
+
+    def ToCUDA(self, batch):
+        """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host
+        copies, before the tensors move."""
+        q, ocr, od = batch[0], batch[1], batch[2]
+        if hasattr(self, "network"):
+            self.network.prepare(q, ocr, od)
+        out = to_device(batch, self.device)
+        if "_ruart_index" in q:
+            out[0]["_ruart_index"] = q["_ruart_index"]
+        return out
+
+    def instance_bce_with_logits(self, logits, labels):
+        assert logits.dim() == 2
+        loss = nn.functional.binary_cross_entropy_with_logits(logits, labels)
+        if self.opt["loss"] == "BCE_D1":
+            loss = loss * labels.size(1)
+        return loss
+
+    # -- one optimizer step -----------------------------------------------------------------------------------
+    def update(self, batch, batch_i=0):
+        self.network.train()
+        self.network.drop_emb = True
+        q_list, ocr_list, od_list, targets, extra_info = batch
+        scores, _ = self.network(q_list, ocr_list, od_list)
+        if self.opt["loss"] == "CE":
+            targets = torch.nonzero(targets)[:, 1]
+        loss = self.loss_func(scores, targets)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.average_gradients()
+        torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.opt["grad_clipping"])
+        self.optimizer.step()
+        self.updates += 1
+        if "TUNE_PARTIAL" in self.opt:
+            tp = self.opt["tune_partial"]
+            if "FastText" in self.opt:
+                self.network.fast_embed.weight.data[tp:] = self.network.fixed_embedding_fast
+            if "GLOVE" in self.opt:
+                self.network.glove_embed.weight.data[tp:] = self.network.fixed_embedding_glove
+        # the reference's NaN contract (SDNetTrainer.py:339-359 + the asserts inside forward): one sync, here
+        loss_val = loss.item()
+        self.network.check_nan()
+        assert loss_val == loss_val, "loss nan"
+        self.train_loss.update(loss_val, 1)
+        return loss_val
+
+    # -- inference --------------------------------------------------------------------------------------------
+    def predict(self, batch, all_ans=False):
+        """Models/SDNetTrainer.py:378-451: arg-max over VALID answer slots, ANLS / ACC when answers are known."""
+        from .metrics import note_stvqa, note_textvqa
+        self.network.eval()
+        self.network.drop_emb = False
+        q_list, ocr_list, od_list, gt_list, extra_info = batch
+        with torch.no_grad():
+            scores, _ = self.network(q_list, ocr_list, od_list)
+            loss = self.loss_func(scores, gt_list).item() if gt_list is not None else 0
+        self.network.check_nan()
+        B, n_slots = scores.shape
+        # valid slot k for sample i: k < num_cnt[i] and k != len(ocr_list_i) - 1 (the <OCR> sentinel); the no-answer slot
+        # (last column) always terminates the scan.  Descending-score scan == masked arg-max.
+        num_cnt = torch.as_tensor(ocr_list["num_cnt"], device=scores.device)
+        sentinel = torch.as_tensor([len(e["ocr_list"]) - 1 for e in extra_info], device=scores.device)
+        ar = torch.arange(n_slots, device=scores.device).unsqueeze(0)
+        valid = (ar < num_cnt.unsqueeze(1)) & (ar != sentinel.unsqueeze(1))
+        if "label_no_answer" in self.opt:
+            valid[:, -1] = True
+        idxs = scores.masked_fill(~valid, -1.0).argmax(dim=1).cpu().tolist()
+        prob = scores.detach().cpu()
+        res, save_res, ANLS, ACC = [], [], 0, 0
+        for i, idx in enumerate(idxs):
+            if "label_no_answer" in self.opt and idx == n_slots - 1:
+                answer = "unanswerable"
+            else:
+                answer = extra_info[i]["ocr_list"][idx]
+            res.append({"question_id": extra_info[i]["q_id"], "answer": answer})
+            save_res.append({"question_id": extra_info[i]["q_id"], "prediction": answer, "answers": extra_info[i]["answers"],
+                             "score": prob[i, idx].item(), "idx": idx, "ids_len": n_slots, "ocr_list": extra_info[i]["ocr_list"]})
+            if extra_info[i]["answers"] is not None:
+                a = note_stvqa(extra_info[i]["answers"], answer)
+                c = note_textvqa(extra_info[i]["answers"], answer)
+                ACC += min(c * 10 / 3.0, 1) if len(extra_info[i]["answers"]) == 10 else min(c * 10, 1)
+                ANLS += a if a >= 0.5 else 0
+        return loss, ANLS, ACC, res, save_res
+
+    def evaluate(self, val_loader, batch_i=0, mode="dev"):
+        loss = ANLS = ACC = n = nb = 0
+        res = []
+        for batch in val_loader:
+            batch = self.ToCUDA(batch)
+            l, a, c, r, _ = self.predict(batch)
+            loss, ANLS, ACC, n, nb = loss + l, ANLS + a, ACC + c, n + len(r), nb + 1
+            res.extend(r)
+        return loss / max(nb, 1), ANLS / max(n, 1), ACC / max(n, 1), res
+
+    def train(self, train_loader, val_loader=None, eval_every=1500, log_every=30):
+        """The outer loop of Models/SDNetTrainer.py:107-123 over any iterable of collated batches."""
+        self.isTrain = True
+        for batch_i, batch in enumerate(train_loader):
+            batch = self.ToCUDA(batch)
+            if val_loader is not None and batch_i % eval_every == 0:
+                self.evaluate(val_loader, batch_i)
+            loss = self.update(batch, batch_i)
+            if batch_i % log_every == 0:
+                log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
+
+    # -- checkpoints ------------------------------------------------------------------------------------------
+    def load_model(self, model_path):
+        """:453-466 - tolerant load: unknown keys dropped, missing keys keep their current value."""
+        ckpt = torch.load(model_path, map_location="cpu")
+        state = ckpt["state_dict"]["network"]
+        cur = self.network.state_dict()
+        state = {k: v for k, v in state.items() if k in cur}
+        for k, v in cur.items():
+            state.setdefault(k, v)
+        self.network.load_state_dict(state)
+
+    def save_for_predict(self, filename):
+        """:492-509 - network weights without BERT / fixed embeddings, plus the config."""
+        skip = ("CoVe", "ELMo", "AllenELMo", "Bert")
+        state = {k: v for k, v in self.network.state_dict().items() if not k.startswith(skip)}
+        for k in ("eval_embed.weight", "fixed_embedding_fast", "fixed_embedding_glove"):
+            state.pop(k, None)
+        cfg = {k: v for k, v in self.opt.items() if isinstance(v, (int, float, str, bool))}
+        try:
+            torch.save({"state_dict": {"network": state}, "config": cfg}, filename)
+        except BaseException:
+            log.info("[ WARN: Saving failed... continuing anyway. ]")

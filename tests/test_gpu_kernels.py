@@ -32,45 +32,48 @@ def maxerr(a, b):
 
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (384, 768, 3072), (128, 2304, 768)])
-@pytest.mark.parametrize("mode", ["plain", "gelu", "res_bf16_out_f32", "res_f32_out_bf16"])
-def test_gemm_bf16(M, N, K, mode):
+@pytest.mark.parametrize("mode", ["plain", "gelu", "res16_out_f32", "res_f32_out16"])
+@pytest.mark.parametrize("dt", [hip.DT_BF16, hip.DT_F16])
+def test_gemm_16(M, N, K, mode, dt):
     lib = hip.load()
     d = dev()
+    td = hip.TORCH_DTYPE[dt]
     g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    A = torch.randn(M, K, generator=g).to(td)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(td)
     bias = torch.randn(N, generator=g)
     ref = A.double() @ W.double().t() + bias.double()
     res = None
-    res_dt, out_dt, act = hip.DT_BF16, hip.DT_BF16, hip.ACT_NONE
+    res_dt, out_dt, act = dt, dt, hip.ACT_NONE
     if mode == "gelu":
         act = hip.ACT_GELU
         ref = O.gelu_erf(ref)
-    elif mode == "res_bf16_out_f32":
-        res = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    elif mode == "res16_out_f32":
+        res = torch.randn(M, N, generator=g).to(td)
         ref = ref + res.double()
         out_dt = hip.DT_F32
-    elif mode == "res_f32_out_bf16":
+    elif mode == "res_f32_out16":
         res = torch.randn(M, N, generator=g)
         ref = ref + res.double()
         res_dt = hip.DT_F32
     Ad, Wd, bd = A.to(d), W.to(d), bias.to(d)
     Rd = res.to(d) if res is not None else None
-    C = torch.empty(M, N, dtype=torch.float32 if out_dt == hip.DT_F32 else torch.bfloat16, device=d)
-    rc = lib.ruart_gemm_bf16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, res_dt, hip.ptr(C), N, out_dt, M, N, K,
-                                act, hip.stream_ptr())
+    C = torch.empty(M, N, dtype=torch.float32 if out_dt == hip.DT_F32 else td, device=d)
+    rc = lib.ruart_gemm_16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, res_dt, hip.ptr(C), N, out_dt, M, N, K,
+                              act, dt, hip.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
-    tol = 2e-3 if out_dt == hip.DT_F32 else 3e-2      # fp32 accumulate; bf16 output rounding dominates otherwise
+    # inputs are exactly representable, accumulation is fp32: only the output rounding differs between the two storage types
+    tol = 2e-3 if out_dt == hip.DT_F32 else (3e-2 if dt == hip.DT_BF16 else 4e-3)
     assert maxerr(C.float(), ref) < tol * max(1.0, float(ref.abs().max()) / 4)
 
 
-def test_gemm_bf16_rejects_bad_shapes():
+def test_gemm_16_rejects_bad_shapes():
     lib = hip.load()
     d = dev()
     x = torch.zeros(128, 64, dtype=torch.bfloat16, device=d)
-    assert lib.ruart_gemm_bf16_nt(hip.ptr(x), 64, hip.ptr(x), 64, None, None, 0, 1, hip.ptr(x), 128, 1, 100, 128, 64, 0,
-                                  hip.stream_ptr()) != 0
+    assert lib.ruart_gemm_16_nt(hip.ptr(x), 64, hip.ptr(x), 64, None, None, 0, 1, hip.ptr(x), 128, 1, 100, 128, 64, 0, 1,
+                                hip.stream_ptr()) != 0
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 53, 29), (64, 64, 16), (200, 250, 1388), (130, 125, 250), (100, 1200, 300)])
@@ -92,7 +95,7 @@ def test_gemm_f32(M, N, K, act):
 
 
 @pytest.mark.parametrize("H", [128, 768, 1024])
-@pytest.mark.parametrize("out_dt", [hip.DT_F32, hip.DT_BF16])
+@pytest.mark.parametrize("out_dt", [hip.DT_F32, hip.DT_BF16, hip.DT_F16])
 def test_rows_layernorm_and_embed(H, out_dt):
     lib = hip.load()
     d = dev()
@@ -101,11 +104,11 @@ def test_rows_layernorm_and_embed(H, out_dt):
     x = torch.randn(rows, H, generator=g) * 2 + 0.3
     gamma, beta = 1 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
     ref = O.bert_layer_norm(x, gamma, beta)
-    out = torch.empty(rows, H, dtype=torch.float32 if out_dt == hip.DT_F32 else torch.bfloat16, device=d)
+    out = torch.empty(rows, H, dtype=hip.TORCH_DTYPE[out_dt], device=d)
     xd, gd, bd = x.to(d), gamma.to(d), beta.to(d)
     assert lib.ruart_rows_layernorm(hip.ptr(xd), H, hip.ptr(gd), hip.ptr(bd), 1e-12, hip.ptr(out), H, out_dt, rows, H,
                                     hip.stream_ptr()) == 0
-    assert maxerr(out.float(), ref) < (3e-6 if out_dt == hip.DT_F32 else 2e-2)
+    assert maxerr(out.float(), ref) < {hip.DT_F32: 3e-6, hip.DT_BF16: 2e-2, hip.DT_F16: 3e-3}[out_dt]
     V, P = 50, 40
     word, ptab, ttab = torch.randn(V, H, generator=g), torch.randn(P, H, generator=g), torch.randn(2, H, generator=g)
     ids = torch.randint(0, V, (rows,), generator=g)
@@ -115,7 +118,7 @@ def test_rows_layernorm_and_embed(H, out_dt):
     idd, posd = ids.int().to(d), pos.int().to(d)
     assert lib.ruart_bert_embed_ln(hip.ptr(idd), hip.ptr(posd), hip.ptr(wd), hip.ptr(pd), hip.ptr(td), hip.ptr(gd), hip.ptr(bd),
                                    1e-12, hip.ptr(out), H, out_dt, rows, H, hip.stream_ptr()) == 0
-    assert maxerr(out.float(), ref) < (3e-6 if out_dt == hip.DT_F32 else 2e-2)
+    assert maxerr(out.float(), ref) < {hip.DT_F32: 3e-6, hip.DT_BF16: 2e-2, hip.DT_F16: 3e-3}[out_dt]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -128,7 +131,7 @@ def _bert_case(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["bert_small", "bert_base"])
-@pytest.mark.parametrize("precision,pack,tol", [("fp32", True, 5e-5), ("fp32", False, 5e-5), ("bf16", True, 6e-2)])
+@pytest.mark.parametrize("precision,pack,tol", [("fp32", True, 5e-5), ("fp32", False, 5e-5), ("bf16", True, 6e-2), ("fp16", True, 1.5e-2), ("fp16", False, 1.5e-2)])
 def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol):
     """Whole encoder through ruart_bert_forward vs the reference's own layer outputs (gen_golden.py)."""
     from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
@@ -247,7 +250,7 @@ def test_fused_attention_vs_reference(layers_golden, tag):
     a = torch.relu(x1 @ W.t()) * diag
     k = torch.relu(x2 @ W.t())
     y = ops.fused_attention(a, k, x2 if x3 is None else x3, T(z[tag + "_mask"]).to(d))
-    assert maxerr(y, T(z[tag + "_y"])) < 1e-5
+    assert maxerr(y, T(z[tag + "_y"])) < 1e-5 * max(1.0, float(np.abs(z[tag + "_y"]).max()))
     y.backward(T(z[tag + "_gy"]).to(d))
     ops.nan_flag.check_and_clear()
     for got, name in ((x1.grad, "_gx1"), (x2.grad, "_gx2"), (W.grad, "_gW")):

@@ -1,0 +1,133 @@
+"""End-to-end parity of the product SDNet (HIP path) on a real MI355X against the reference's golden outputs
+(tests/golden/sdnet_e2e.npz: scores, loss and gradients of the UNMODIFIED reference on the same seeded inputs),
+and trainer-level behaviour.
+
+Tolerance (BASELINE.json north star): answer probabilities within 1e-3 of the fp32 CPU reference.  That bound is met with
+16-bit MFMA operands in the f16 form (11 significand bits; same MFMA rate as bf16), which is the default; the bf16 form
+(8 significand bits) lands at ~3e-3 on these seeded random weights and is held to 5e-3; fp32 validation mode to 5e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ruart_amd import synth                              # noqa: E402
+from ruart_amd.arguments import default_opt               # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build(z, precision, device="cuda:0", **extra):
+    from ruart_amd.sdnet import SDNet
+    opt = default_opt(vocab_size=int(z["vocab_size"]), cuda=True, device=device, bert_precision=precision, **extra)
+    cfg = synth.bert_config(vocab_size=2000)
+    opt["bert_state"] = synth.make_bert_weights(cfg, seed=int(z["seed"]))
+    opt["bert_config"] = cfg
+    sw = synth.make_sdnet_weights(opt, seed=int(z["seed"]))
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)      # state-dict keys == the reference's
+    return net.to(device), opt
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "sdnet_e2e.npz"))
+
+
+@pytest.mark.parametrize("precision,tol_p,tol_g", [("fp32", 5e-5, 2e-3), ("fp16", 1e-3, 1e-1), ("bf16", 5e-3, 4e-1)])
+def test_sdnet_forward_backward_vs_reference(golden, precision, tol_p, tol_g):
+    import ruart_amd.layers as L
+    z = golden
+    net, opt = build(z, precision)
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=30, n_ocr=100, n_od=30,
+                                              bert_vocab=2000, ragged=True)
+    assert ocr["num_cnt"] == z["ocr_num_cnt"].tolist()
+    L.set_dropout_prob(0.0)
+    net.train()
+    net.drop_emb = False
+    scores, _ = net(q, ocr, od)
+    net.check_nan()
+    got = scores.detach().cpu().numpy()
+    err = np.abs(got - z["scores"]).max()
+    assert got.shape == z["scores"].shape and np.allclose(got.sum(1), 1.0, atol=1e-5)
+    assert err < tol_p, "max |p - p_ref| = %.3e" % err
+    gt = gt.to(scores.device)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
+    assert abs(loss.item() - float(z["loss"])) < 10 * tol_p
+    loss.backward()
+    params = dict(net.named_parameters())
+    worst_norm, worst_elem = (0.0, ""), (0.0, "")
+    for name, ref_norm in zip(z["grad_names"].tolist(), z["grad_norms"].tolist()):
+        g = params[name].grad
+        if ref_norm < 0:
+            assert g is None, name                    # non-trainable scalar / the dead GRU: no gradient, as in the reference
+            continue
+        if g is None:
+            # ques_merger.linear.bias: a constant added to every key's score; softmax is shift invariant, the reference's
+            # gradient for it is rounding noise (~1e-9) and the fused kernel does not materialise it
+            assert name == "ques_merger.linear.bias" and ref_norm < 1e-6, (name, ref_norm)
+            continue
+        rel = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, 1e-4)
+        worst_norm = max(worst_norm, (rel, name))
+        key = "grad:" + name
+        if key in z.files:
+            ref = z[key]
+            e = np.abs(g.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-5)
+            worst_elem = max(worst_elem, (float(e), name))
+    print("precision %s: max |dp| %.2e; worst grad-norm rel err %.2e (%s); worst grad element err / max|g| %.2e (%s)"
+          % (precision, err, worst_norm[0], worst_norm[1], worst_elem[0], worst_elem[1]))
+    assert worst_norm[0] < tol_g, worst_norm
+    assert worst_elem[0] < 2 * tol_g, worst_elem
+
+
+def test_trainer_update_and_predict(golden):
+    from ruart_amd.trainer import SDNetTrainer
+    z = golden
+    opt = default_opt(vocab_size=1500, cuda=True, DROPOUT=0.0, dropout_emb=0.0)      # deterministic: same batch must improve
+    cfg = synth.bert_config(vocab_size=2000)
+    opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=1033), cfg
+    sw = synth.make_sdnet_weights(opt, seed=1033)
+    tr = SDNetTrainer(opt, device="cuda:0")
+    tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    pinned = tr.network.fast_embed.weight.data[opt["tune_partial"]:].clone()
+    batch = synth.synthetic_batch(opt, 4, seed=11, n_q=12, n_ocr=30, n_od=9, bert_vocab=2000, ragged=True)
+    losses = [tr.update(tr.ToCUDA(batch), i) for i in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses     # same batch: the loss must go down
+    assert torch.equal(tr.network.fast_embed.weight.data[opt["tune_partial"]:], pinned)   # rows >= tune_partial re-pinned
+    assert tr.network.get_answer.rnn.weight_ih.grad is None                                # dead GRU never trained
+    loss, anls, acc, res, save_res = tr.predict(tr.ToCUDA(batch))
+    assert len(res) == 4 and all("answer" in r for r in res)
+    # checkpoint round trip with the reference's format
+    path = "/tmp/ruart_ckpt_test.pt"
+    tr.save_for_predict(path)
+    ck = torch.load(path, map_location="cpu")
+    assert not any(k.startswith("Bert") for k in ck["state_dict"]["network"])
+    before = tr.network.alphaBERT.detach().clone()
+    with torch.no_grad():
+        tr.network.alphaBERT.add_(1.0)
+    tr.load_model(path)
+    assert torch.equal(tr.network.alphaBERT.detach(), before)
+
+
+def test_variational_dropout_contract():
+    """Layers.py:23-30: one mask per (row, feature) shared over time, scaled by 1/(1-p)."""
+    import ruart_amd.layers as L
+    L.set_seq_dropout(True)
+    x = torch.ones(5, 7, 11, device="cuda:0")
+    y = L.dropout(x, p=0.4, training=True)
+    assert torch.equal(y[:, 0], y[:, 3])
+    vals = set(y.unique().cpu().tolist())
+    assert vals <= {0.0, 1.0 / 0.6} or all(abs(v) < 1e-6 or abs(v - 1 / 0.6) < 1e-5 for v in vals)
+    assert torch.equal(L.dropout(x, p=0.4, training=False), x)
+
+
+def test_no_cpu_fallback():
+    from ruart_amd import hip, ops
+    with pytest.raises(hip.HipError):
+        ops.fused_attention(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.ones(1, 2))
