@@ -44,6 +44,8 @@ const char* ruart_version(void);
 int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
                      int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
                      void* stream);
+/* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
+int ruart_gemm_set_tile_order(int group_m);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
                       float* C, int ldc, int M, int N, int K, int act, void* stream);

@@ -31,45 +31,64 @@ __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + e
 // byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
+// erf for the 16-bit epilogue: Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 - far below the half-ulp of an f16/bf16
+// output (>= 2.4e-4 relative) - at a third of erff's instruction count (the GELU epilogue runs on 3072-wide rows).
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <typename T16, bool OUT_F32, int RES /*0 none, 1 same 16-bit type, 2 f32*/, int ACT /*0 none 1 gelu*/>
 __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A, int lda,
                                                       const T16* __restrict__ W, int ldw,
-                                                        const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                        void* __restrict__ C, int ldc, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];
+                                                      const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                      void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kTile = BM * BK * 2;             // bytes of one operand tile (16 KB)
+  constexpr int kStage = 2 * kTile;              // A tile then W tile
+  __shared__ __attribute__((aligned(1024))) char smem[2 * kStage];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = N / BN;
-  const int nwg = gridDim.x;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-
-  constexpr int kStage = (BM + BN) * BK * 2;     // bytes per pipeline stage: A tile then W tile
-
-  // staging assignment: 1024 chunks of 16 B per operand tile, 4 per thread
-  int srow[4], sch[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = tid + 256 * i;
-    srow[i] = q >> 3;
-    sch[i] = q & 7;
+  const int ntn = N / BN, ntm = M / BM;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  // L2-friendly order inside an XCD's contiguous id range: groups of GROUP_M row panels, column-major inside a group,
+  // so a window of ~64 co-resident workgroups touches ~8 activation panels x ~8 weight panels instead of 64 + 64.
+  int tm, tn;
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
   }
-  const T16* Ag = A + (size_t)m0 * lda;
-  const T16* Wg = W + (size_t)n0 * ldw;
+  const int m0 = tm * BM, n0 = tn * BN;
 
-  uint4 ra[4], rb[4];
-  auto gload = [&](int k0) {
+  // Direct-to-LDS staging (global_load_lds_dwordx4): one wave-instruction fills 1 KB = 8 tile rows of 128 B.  The LDS
+  // image is lane-linear, so the XOR swizzle is applied to the SOURCE chunk: lane l (row l>>3 of the 8, slot l&7)
+  // fetches logical chunk (l&7) ^ (l>>3) (cdna_hip_programming.md rule 21: linear dest + swizzled source + swizzled read).
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
+  const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8;
+  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
+  auto stage = [&](int buf, int k0) {
+    char* base = smem + buf * kStage + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const uint4*>(Ag + (size_t)srow[i] * lda + k0 + sch[i] * 8);
-      rb[i] = *reinterpret_cast<const uint4*>(Wg + (size_t)srow[i] * ldw + k0 + sch[i] * 8);
-    }
-  };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(smem + buf * kStage + lds_off(srow[i], sch[i])) = ra[i];
-      *reinterpret_cast<uint4*>(smem + buf * kStage + BM * BK * 2 + lds_off(srow[i], sch[i])) = rb[i];
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + kTile + i * 1024), 16, 0, 0);
     }
   };
 
@@ -79,31 +98,35 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = K / BK;
-  gload(0);
-  lwrite(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) gload((t + 1) * BK);
+  typedef typename Vec8<T16>::type frag_t;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * kStage;
+    const char* sw = sa + kTile;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      typedef typename Vec8<T16>::type frag_t;
       frag_t wf[4], af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const frag_t*>(smem + cur * kStage + BM * BK * 2 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        af[i] = *reinterpret_cast<const frag_t*>(smem + cur * kStage + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        af[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(wf[i], af[j], acc[i][j]);
     }
-    if (t + 1 < nt) lwrite(cur ^ 1);
+  };
+
+  const int nt = K / BK;
+  stage(0, 0);
+  __syncthreads();                  // (the compiler drains vmcnt before the barrier while an LDS-DMA is outstanding)
+  for (int t = 0; t < nt - 1; ++t) {
+    stage((t + 1) & 1, (t + 1) * BK);
+    compute(t & 1);
     __syncthreads();
   }
+  compute((nt - 1) & 1);
 
   // epilogue: acc[i][j][r] = C[m = m0+wm*64+j*16+fr][n = n0+wn*64+i*16+fq*4+r]
 #pragma unroll
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
       f32x4_t v = acc[i][j] + bv;
       if (ACT == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
       }
       if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
       if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
@@ -233,7 +256,14 @@ std::vector<ProfRec> g_prof_pool;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 }  // namespace
+int g_tile_order = 8;            // GROUP_M of the tile walk (0 = plain row-major); tuning knob, see ruart_gemm_set_tile_order
 int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
+
+extern "C" int ruart_gemm_set_tile_order(int group_m) {
+  if (group_m < 0 || group_m > 64) return (int)hipErrorInvalidValue;
+  g_tile_order = group_m;
+  return 0;
+}
 
 extern "C" int ruart_prof_enable(int on) {
   if (on && g_prof_pool.empty()) {
@@ -271,7 +301,7 @@ static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const f
   const T16* a = (const T16*)A;
   const T16* w = (const T16*)W;
 #define LAUNCH(OF, RS, AC) \
-  hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K)
+  hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, g_tile_order)
   if (act == RUART_ACT_GELU) {
     if (res != 0) return (int)hipErrorInvalidValue;
     if (of) LAUNCH(true, 0, 1); else LAUNCH(false, 0, 1);

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
+    "ruart_gemm_set_tile_order": (_I, [_I]),
     "ruart_prof_enable": (_I, [_I]),
     "ruart_prof_read": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
 }
