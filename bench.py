@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--n-batches", type=int, default=2, help="distinct pre-staged synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 

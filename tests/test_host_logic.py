@@ -1,0 +1,182 @@
+"""Host-side logic (CPU only): conf reader, collate mirror, sampler, batch index vectors, BERT packing plan,
+answer metrics.  Collate and sampler are checked against outputs of the reference's own VQA_collate / VQA_Sampler
+(tests/golden/host.npz, generator oracle/gen_golden.py::gen_host)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ruart_amd import synth
+from ruart_amd.arguments import Arguments, default_opt
+from ruart_amd.batch import ItemIndex, VQA_collate, offsets_to_array
+from ruart_amd.metrics import note_stvqa, note_textvqa, stvqa_score
+from ruart_amd.sampler import VQA_Sampler
+
+
+def test_conf_reader_semantics(tmp_path):
+    p = tmp_path / "conf"
+    p.write_text("A\nB\t3\nC 0.5\n# comment\nD true\nE ./x/y\nB 9\nF 1 2 3\noptimizer   #\n\n")
+    opt = Arguments(str(p)).readArguments()
+    assert opt == {"A": True, "B": 3, "C": 0.5, "D": True, "E": "./x/y", "optimizer": "#"}
+    with pytest.raises(Exception):
+        Arguments(str(tmp_path / "missing"))
+    d = default_opt()
+    assert d["hidden_size"] == 125 and d["LN"] is True and d["optimizer"] == "#" and d["concat_rnn"] is False
+    assert d["ES_ocr_len"] == 10 and d["max_ocr_num"] == 100 and "PRE_ALIGN_befor_rnn" in d
+
+
+def _samples_like_generator(opt, n, seed):
+    """must mirror oracle/gen_golden.py::synthetic_samples draw for draw"""
+    g = np.random.default_rng(seed)
+
+    def item(nw, nb, sentinel=None):
+        words = [sentinel] if sentinel is not None else g.integers(5, 900, size=nw).tolist()
+        bert = [101] + g.integers(1000, 2000, size=nb).tolist() + [102]
+        offs, cur = [], 1
+        for k in range(len(words)):
+            c = 1 + (k < nb - len(words))
+            offs.append([cur, cur + c])
+            cur += c
+        return {"fasttext": words, "pos": g.integers(0, 51, size=len(words)).tolist(), "ent": g.integers(0, 75, size=len(words)).tolist(),
+                "bert": bert, "bert_offsets": offs, "position": g.random(8).round(4).tolist()}
+
+    out = []
+    for i in range(n):
+        nq = int(g.integers(3, 12))
+        q = {"glove": g.integers(5, 900, size=nq).tolist(), "pos": g.integers(0, 51, size=nq).tolist(),
+             "ent": g.integers(0, 75, size=nq).tolist(), "bert": [101] + g.integers(1000, 2000, size=nq + 2).tolist() + [102],
+             "bert_offsets": [[1 + k, 2 + k] for k in range(nq)]}
+        n_ocr, n_od = int(g.integers(12, 20)), int(g.integers(1, 6))
+        ocr = [item(int(g.integers(1, 4)), int(g.integers(3, 7))) for _ in range(n_ocr - 1)] + [item(1, 1, sentinel=3)]
+        od = [item(int(g.integers(1, 3)), int(g.integers(2, 4))) for _ in range(n_od - 1)] + [item(1, 1, sentinel=4)]
+        gt = torch.zeros(1, opt["max_ocr_num"] + 1)
+        gt[0, int(g.integers(0, n_ocr - 1))] = 1.0
+        out.append({"q": q, "ocr": ocr, "od": od, "gt": gt, "extra_info": {"q_id": i, "answers": None, "ocr_list": ["w"] * n_ocr,
+                                                                         "image_path": "x"}})
+    return out
+
+
+def test_collate_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "host.npz"))
+    opt = default_opt()
+    q, ocr, od, gt, extra = VQA_collate(opt).VQA_collate_fun(_samples_like_generator(opt, 3, int(z["seed"])))
+    assert np.array_equal(gt.numpy(), z["gt"])
+    for name, d in (("q", q), ("ocr", ocr), ("od", od)):
+        for k in z.files:
+            if not k.startswith(name + ":") or k.endswith(("num_cnt", "len_cnt", "n_offsets")):
+                continue
+            key = k.split(":", 1)[1]
+            got = d[key]
+            assert got.dtype == {"b": torch.bool, "i": torch.int64, "f": torch.float32}[z[k].dtype.kind], (k, got.dtype)
+            assert np.array_equal(got.numpy(), z[k]), k
+        if name != "q":
+            assert d["num_cnt"] == z[name + ":num_cnt"].tolist()
+            assert np.concatenate([np.array(l) for l in d["len_cnt"]]).tolist() == z[name + ":len_cnt"].tolist()
+        assert [len(o) for o in d["bert_offsets"]] == z[name + ":n_offsets"].tolist()
+
+
+def test_sampler_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "host.npz"))
+    data = list(range(23))
+    assert np.array_equal(np.array(list(VQA_Sampler(data, 7, 5, True))), z["sampler_train"])
+    assert np.array_equal(np.array(list(VQA_Sampler(data, 7, 5, True, batch_st=3))), z["sampler_train_resume"])
+    assert np.array_equal(np.array(list(VQA_Sampler(data, None, 4, True, epoch=2))), z["sampler_epoch"])
+    assert np.array_equal(np.array(list(VQA_Sampler(data, 99, 5, False))), z["sampler_eval"])
+
+
+def test_sampler_rank_sharding_partitions_the_global_stream():
+    data = list(range(50))
+    whole = list(VQA_Sampler(data, 6, 8, True))                       # single process, batch 8
+    parts = [list(VQA_Sampler(data, 6, 4, True, rank=r, world_size=2)) for r in range(2)]
+    for step in range(6):
+        merged = sorted(parts[0][step] + parts[1][step])
+        assert merged == sorted(whole[step]) and len(parts[0][step]) == 4
+
+
+def test_metrics_known_answers():
+    assert stvqa_score("abc", "bd") == pytest.approx(0.33333333333333337)
+    assert note_stvqa(["Coca Cola", "cola"], "coca") == pytest.approx(0.75)
+    assert note_textvqa(["a", "A", "b"], "a") == pytest.approx(0.2)
+    assert stvqa_score("", "") == 1
+
+
+def test_item_index_reproduces_the_reference_loops():
+    """The index vectors must reproduce Models/SDNet.py:300-318 (last-word gather) and :495-551 (pre-align re-packing)."""
+    opt = default_opt(vocab_size=300)
+    _, ocr, _, _, _ = synth.synthetic_batch(opt, 3, seed=2, n_q=8, n_ocr=25, n_od=6, bert_vocab=2000, ragged=True)
+    idx = ItemIndex(ocr, "fasttext", ocr["position"].size(1))
+    N, Lw = ocr["fasttext"].shape
+    g = torch.Generator().manual_seed(0)
+    dense = torch.randn(N, Lw, 5, generator=g)                      # stands for any per-(item, word) tensor
+    packed = dense.reshape(N * Lw, 5)[torch.from_numpy(idx.flat_word)]
+    # pre-align packing: the reference's per-sample rows
+    ref = torch.zeros(idx.B, idx.Tmax, 5)
+    i = 0
+    for b in range(idx.B):
+        c = 0
+        for j in ocr["len_cnt"][b]:
+            ref[b, c:c + j] = dense[i, :j]
+            c += j
+            i += 1
+    mine = torch.zeros(idx.B, idx.Tmax, 5).index_put((torch.from_numpy(idx.sample_of_word), torch.from_numpy(idx.tok_in_sample)), packed)
+    assert torch.equal(ref, mine)
+    # last-word gather through the sorted multi2one schedule: emulate "state = value of the item's last processed word"
+    order_state = torch.zeros(N, 5)
+    off = 0
+    for s, n in enumerate(idx.n_active):
+        rows = torch.from_numpy(idx.step_rows[off:off + n])
+        order_state = torch.cat([packed[rows], order_state[n:]], 0)
+        off += n
+    out = torch.zeros(idx.B, idx.max_num, 5).index_put((torch.from_numpy(idx.sorted_sample), torch.from_numpy(idx.sorted_slot)), order_state)
+    ref = torch.zeros(idx.B, idx.max_num, 5)
+    i = 0
+    for b in range(idx.B):
+        for k, j in enumerate(ocr["len_cnt"][b]):
+            ref[b, k] = dense[i, j - 1]
+            i += 1
+    assert torch.equal(ref, out)
+    assert idx.mask.sum(1).tolist() == ocr["num_cnt"]
+
+
+def test_offsets_array_tolerates_flat_empty_marker():
+    arr = offsets_to_array([[[1, 3], [3, 4]], [1, 1], []], 3, 4)
+    assert arr[0, :2].tolist() == [[1, 3], [3, 4]] and arr[1].sum() == 0 and arr[2].sum() == 0
+
+
+def test_packed_token_plan_on_cpu():
+    """PackedTokens runs on the host (numpy) - check the block plan invariants without a GPU."""
+    from ruart_amd.bert import PackedTokens
+    g = np.random.default_rng(1)
+    lens = [1, 2, 64, 65, 3, 200, 7, 7, 7, 64, 1]
+    L = 200
+    ids = np.zeros((len(lens), L), dtype=np.int64)
+    for i, l in enumerate(lens):
+        ids[i, :l] = g.integers(1, 99, size=l)
+    p = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu")
+    q0, q1, k0, k1 = [t.numpy() for t in p.blk]
+    assert p.T == sum(lens) and p.Tp % 128 == 0 and p.Tp >= p.T
+    covered = np.zeros(p.T, dtype=int)
+    lo, hi = p.tok_lo.numpy(), p.tok_hi.numpy()
+    for b in range(p.n_blocks):
+        assert 0 < q1[b] - q0[b] <= 64
+        covered[q0[b]:q1[b]] += 1
+        assert k0[b] <= lo[q0[b]:q1[b]].min() and k1[b] >= hi[q0[b]:q1[b]].max()     # keys of every query are staged
+    assert (covered == 1).all()
+    assert (hi - lo == np.repeat(lens, lens)).all()
+    assert np.array_equal(p.ids.numpy()[:p.T], ids[ids != 0]) and (p.ids.numpy()[p.T:] == 0).all()
+    # unpacked mode keeps every slot and carries the -10000 key bias
+    p2 = PackedTokens([(torch.from_numpy(ids[:3, :8]), torch.from_numpy(ids[:3, :8] != 0))], "cpu", pack=False)
+    assert p2.T == 24 and (p2.key_bias.numpy() == np.where((ids[:3, :8] != 0).reshape(-1), 0, -10000)).all()
+
+
+def test_word_spans_follow_reference_pooling_rules():
+    from ruart_amd.bert import PackedTokens, word_spans
+    ids = np.array([[5, 6, 7, 8, 9, 0, 0], [5, 6, 0, 0, 0, 0, 0]])
+    p = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu")
+    offsets = [[[1, 2], [2, 4], [4, 4]], [1, 1]]                 # single piece, two pieces, empty span; item without words
+    wm = np.array([[1, 1, 1, 0], [0, 0, 0, 0]], dtype=bool)
+    s, n, d, rows = word_spans(p, 0, offsets, wm)
+    assert s.tolist() == [1, 2] and n.tolist() == [1, 2] and d.tolist() == [0, 1] and rows == 8
+    with pytest.raises(ValueError):
+        word_spans(p, 0, [[[4, 7]], [1, 1]], np.array([[1, 0, 0, 0], [0, 0, 0, 0]], dtype=bool))   # span runs into padding
