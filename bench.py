@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
-    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "bert512"])
+    ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--n-batches", type=int, default=2, help="distinct pre-staged synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=8)
@@ -100,6 +101,44 @@ def cpu_baseline(opt, cfg, n_samples, seed=1033):
                       % (n_samples, dt)}
 
 
+def bert512(a, device, lib):
+    """Secondary, north-star shape: BERT-base + fused attention FORWARD on input_ids (B, L) all valid (default (64, 512)).
+    Reports achieved TFLOP/s on the algorithmic 169 869 312 + 36 864 L flop per token against the 2.5 PF MFMA peak."""
+    from ruart_amd import hip, synth
+    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
+    cfg = synth.bert_config()
+    note("bert512: building weights")
+    W = BertEncoderWeights(synth.make_bert_weights(cfg, seed=1033, w_std=0.02), cfg, device, a.precision)
+    L = a.seq_len
+    ids = torch.randint(1000, cfg["vocab_size"], (a.batch, L))
+    packed = PackedTokens([(ids, torch.ones_like(ids, dtype=torch.bool))], device, mfma_long=a.precision != "fp32")
+    for _ in range(a.warmup):
+        bert_encode(W, packed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        bert_encode(W, packed)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    flops = a.batch * L * (169869312 + 36864 * L)
+    hip.check(lib.ruart_prof_enable(1), "prof_enable")
+    for _ in range(a.steps):
+        bert_encode(W, packed)
+    torch.cuda.synchronize()
+    ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    hip.check(lib.ruart_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
+    lib.ruart_prof_enable(0)
+    out = {"metric": "BERT-base + attention forward, (B=%d, L=%d), achieved TFLOP/s" % (a.batch, L), "value": round(flops / dt / 1e12, 1),
+           "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3),
+           "higher_is_better": True, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+           "config": {"workload": "north-star shape: bert-base forward over %d x %d valid tokens" % (a.batch, L)},
+           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flops / dt / 1e12 / PEAK_TFLOPS, 4), "traffic": None,
+                        "gemm_only_tflops": round(fl.value / (ms.value * 1e-3) / 1e12, 1) if n.value else None,
+                        "gemm_share": round(ms.value / a.steps / (dt * 1e3), 3) if n.value else None}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,6 +159,8 @@ def main():
     from ruart_amd import hip, synth
     from ruart_amd.arguments import default_opt
     lib = hip.load()
+    if a.mode == "bert512":
+        return bert512(a, device, lib)
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
     note("building model")

@@ -46,6 +46,10 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
                      void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
+/* Tuning knob: 0 (default) = 128x128 tile / 2 LDS stages, 1 = 256x128 tile / 3 stages with counted vmcnt (M % 256 == 0),
+ * 2 = persistent 128x128 (next tile's first stage in flight during the epilogue).  Measured on the BERT shapes
+ * (DESIGN.md section 5): 0 and 1 tie, 2 loses on K = 3072; all three are kept selectable for the next round's tuning. */
+int ruart_gemm_set_variant(int v);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,
                       float* C, int ldc, int M, int N, int K, int act, void* stream);
@@ -66,12 +70,16 @@ int ruart_bert_embed_ln(const int* ids, const int* pos_ids, const float* word_em
 int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
                          int out_dtype, int rows, int H, void* stream);
 /* Models/Bert/modeling.py:234-250 on a packed token stream.  qkv rows are [Q | K | V] (3H wide), Q already
- * scaled by 1/sqrt(64).  Query block b covers tokens [blk_q0[b], blk_q1[b]) (<= 64) and stages keys
- * [blk_k0[b], blk_k1[b]); token t attends to keys [tok_lo[t], tok_hi[t]) (its own sequence).  key_bias (may be
- * NULL) is added to every score of key j (the reference's -10000 for kept-but-masked positions). */
+ * scaled by 1/sqrt(64).  Two kinds of query blocks:
+ *   short windows (n_blocks): block b covers tokens [blk_q0[b], blk_q1[b]) (<= 64, whole short sequences) and stages keys
+ *     [blk_k0[b], blk_k1[b]); token t attends to keys [tok_lo[t], tok_hi[t]) (its own sequence) - VALU kernel, any dtype;
+ *   long blocks (n_long_blocks): 64 consecutive queries of ONE sequence, keys [lblk_k0, lblk_k1) = that whole sequence -
+ *     MFMA flash-attention kernel, 16-bit dtypes only (in fp32 mode the host plans long sequences as short-window blocks).
+ * key_bias (may be NULL) is added to every score of key j (the reference's -10000 for kept-but-masked positions). */
 int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype, int H, int n_heads, int n_blocks,
                          const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
-                         const int* tok_hi, const float* key_bias, void* stream);
+                         const int* tok_hi, const float* key_bias, int n_long_blocks, const int* lblk_q0, const int* lblk_q1,
+                         const int* lblk_k0, const int* lblk_k1, void* stream);
 /* Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: out[dst_row[w]] = sum_l layer_w[l] *
  * mean(layer_l[span_start[w] .. +span_len[w])).  layers = n_layers matrices [rows, H], layer_stride elements apart.
  * Rows of `out` that no word maps to are left untouched (the caller zero-fills: masked words are zeros). */
@@ -107,6 +115,8 @@ typedef struct {
   int n_blocks;
   const int *blk_q0, *blk_q1, *blk_k0, *blk_k1, *tok_lo, *tok_hi;
   const float* key_bias; /* NULL when every kept token is attendable */
+  int n_long_blocks;     /* 64-query blocks of sequences longer than 64 tokens (MFMA kernel); 0 in fp32 mode */
+  const int *lblk_q0, *lblk_q1, *lblk_k0, *lblk_k1;
 } ruart_bert_batch;
 
 size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows);
@@ -115,16 +125,17 @@ int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, voi
                        size_t workspace_bytes, void* stream);
 
 /* ---- SDNet kernels (Models/Layers.py) ---------------------------------------------------------------------- */
-/* Layers.py:244 + :275-288 (after the ReLU projections): for each batch b
- *   S = a[b] (L1 x h) . k[b]^T (L2 x h);  S[:, j] = -inf where mask[b][j] == 0;  P = softmax_j(S);  out = P . v[b]
- * a = ReLU(x1 W^T) * diag, k = ReLU(x2 W^T) are produced by the caller.  P (B, L1, L2) is saved for backward
- * when probs != NULL.  fp32. */
-int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, float* out, float* probs, int B,
-                   int L1, int L2, int h, int D3, void* stream);
-/* gradients of the op above: given grad_out (B,L1,D3) and saved P: grad_a (B,L1,h), grad_k (B,L2,h), grad_v (B,L2,D3). */
-int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out, float* grad_a,
-                   float* grad_k, float* grad_v, float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3,
-                   void* stream);
+/* Layers.py:228-231 + :244 + :275-288: for each batch b, with pa = x1 W^T (B,L1,h) and pk = x2 W^T (B,L2,h) from the caller,
+ *   a = act(pa) * diag,  k = act(pk)      act = ReLU when relu != 0; diag_len 0: no diag, 1: one scalar, h: per column
+ *   S = a . k^T;  S[:, j] = -inf where mask[b][j] == 0;  P = softmax_j(S);  out = P . v[b]  (v: (B,L2,D3))
+ * P (B, L1, L2) is saved for backward when probs != NULL.  fp32. */
+int ruart_attn_fwd(const float* pa, const float* pk, const float* v, const unsigned char* mask, const float* diag, int diag_len,
+                   int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream);
+/* gradients of the op above, given grad_out (B,L1,D3) and saved P: grad_pa (B,L1,h), grad_pk (B,L2,h), grad_v (B,L2,D3);
+ * grad_diag (h floats, ACCUMULATED with atomics: zero it first) only for a vector diag, else pass NULL. */
+int ruart_attn_bwd(const float* pa, const float* pk, const float* v, const float* probs, const float* grad_out, const float* diag,
+                   int diag_len, int relu, float* grad_pa, float* grad_pk, float* grad_v, float* grad_diag,
+                   float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3, void* stream);
 
 /* Layers.py:167-168: F.layer_norm over the WHOLE tensor of n elements, no affine.  stats[0] = mean, stats[1] = rstd.
  * ws: 2 * 1024 floats of scratch. */

@@ -161,7 +161,7 @@ class BatchIndex:
         if bert is not None:
             from .bert import PackedTokens, word_spans
             groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
-            self.packed = PackedTokens(groups, self.device, pack=bert.pack)
+            self.packed = PackedTokens(groups, self.device, pack=bert.pack, mfma_long=bert.weights.dtype != 0)
             spans = []
             for g, (items, wk) in enumerate(((q_list, wk_q), (ocr_list, wk_o), (od_list, wk_o))):
                 wm = _np(items[wk + "_mask"])

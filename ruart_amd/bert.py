@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import hip
 
-ROW_PAD = 128          # GEMM row granularity (ruart_gemm_bf16_nt: M % 128 == 0)
+ROW_PAD = 256          # GEMM row granularity (ruart_gemm_16_nt: M % 128 == 0; the 256-row tile variant needs 256)
 
 
 def _np(x):
@@ -106,7 +106,7 @@ class PackedTokens:
     ``pack=True`` keeps only mask==1 positions; ``pack=False`` keeps every position and turns the mask into the
     reference's additive -10000 key bias (exact reference semantics for arbitrary masks)."""
 
-    def __init__(self, groups, device, pack=True):
+    def __init__(self, groups, device, pack=True, mfma_long=True):
         ids_l, pos_l, len_l, bias_l = [], [], [], []
         self.group_index = []            # per group: (N, L) int32 packed index of each kept position, -1 if dropped
         base = 0
@@ -134,16 +134,17 @@ class PackedTokens:
         cu = np.zeros(len(lens) + 1, dtype=np.int64)
         np.cumsum(lens, out=cu[1:])
         seq_of = np.repeat(np.arange(len(lens)), lens)
-        blk = self._plan_blocks(lens, cu)
-        nb = blk.shape[1]
+        blk, lblk = self._plan_blocks(lens, cu, mfma_long)
+        nb, nlb = blk.shape[1], lblk.shape[1]
         # one int32 host buffer -> one H2D copy
-        host = np.zeros(2 * Tp + 2 * T + 4 * nb, dtype=np.int32)
+        host = np.zeros(2 * Tp + 2 * T + 4 * nb + 4 * nlb, dtype=np.int32)
         host[0:T] = np.concatenate(ids_l)
         host[Tp:Tp + T] = np.concatenate(pos_l)
         host[2 * Tp:2 * Tp + T] = cu[seq_of]
         host[2 * Tp + T:2 * Tp + 2 * T] = cu[seq_of + 1]
-        host[2 * Tp + 2 * T:] = blk.reshape(-1)
-        self.T, self.Tp, self.n_blocks = T, Tp, nb
+        host[2 * Tp + 2 * T:2 * Tp + 2 * T + 4 * nb] = blk.reshape(-1)
+        host[2 * Tp + 2 * T + 4 * nb:] = lblk.reshape(-1)
+        self.T, self.Tp, self.n_blocks, self.n_long_blocks = T, Tp, nb, nlb
         self.n_seq = len(lens)
         self.max_len = int(lens.max())
         self.sum_len_sq = float((lens.astype(np.float64) ** 2).sum())
@@ -155,6 +156,8 @@ class PackedTokens:
         self.tok_lo = dev[o:o + T]; o += T
         self.tok_hi = dev[o:o + T]; o += T
         self.blk = [dev[o + i * nb:o + (i + 1) * nb] for i in range(4)]
+        o += 4 * nb
+        self.lblk = [dev[o + i * nlb:o + (i + 1) * nlb] for i in range(4)]
         self.key_bias = None
         if not pack:
             self.key_bias = torch.from_numpy(np.concatenate(bias_l)).to(device)
@@ -164,26 +167,35 @@ class PackedTokens:
         b.blk_q0, b.blk_q1, b.blk_k0, b.blk_k1 = [t.data_ptr() for t in self.blk]
         b.tok_lo, b.tok_hi = self.tok_lo.data_ptr(), self.tok_hi.data_ptr()
         b.key_bias = self.key_bias.data_ptr() if self.key_bias is not None else None
+        b.n_long_blocks = nlb
+        b.lblk_q0, b.lblk_q1, b.lblk_k0, b.lblk_k1 = [t.data_ptr() if nlb else None for t in self.lblk]
         self.c_batch = b
 
     @staticmethod
-    def _plan_blocks(lens, cu):
-        """Query blocks of <= 64 tokens made of whole sequences; a sequence longer than 64 is split into
-        64-query chunks that each see the whole sequence as keys.  Returns int array (4, n_blocks):
-        q0, q1, k0, k1."""
+    def _plan_blocks(lens, cu, mfma_long=True):
+        """Query blocks of <= 64 tokens.  Short sequences are packed whole into windows (VALU kernel, each lane walks its own
+        sequence's keys).  A sequence longer than 64 is split into 64-query chunks that each see the whole sequence as keys:
+        these go to the MFMA flash kernel (``mfma_long``) or, in fp32 mode, to the same VALU kernel.
+        Returns two int arrays (4, n): q0, q1, k0, k1."""
         S = len(lens)
-        out = []
+        short, long_ = [], []
         s = 0
         while s < S:
             if lens[s] > 64:
+                tgt = long_ if mfma_long else short
                 for q0 in range(int(cu[s]), int(cu[s + 1]), 64):
-                    out.append((q0, min(q0 + 64, int(cu[s + 1])), int(cu[s]), int(cu[s + 1])))
+                    tgt.append((q0, min(q0 + 64, int(cu[s + 1])), int(cu[s]), int(cu[s + 1])))
                 s += 1
                 continue
             e = int(np.searchsorted(cu, cu[s] + 64, side="right")) - 1      # last boundary within 64 tokens
-            out.append((int(cu[s]), int(cu[e]), int(cu[s]), int(cu[e])))
+            while e > s + 1 and (lens[s:e] > 64).any():                      # never swallow a long sequence
+                e -= 1
+            e = max(e, s + 1)
+            short.append((int(cu[s]), int(cu[e]), int(cu[s]), int(cu[e])))
             s = e
-        return np.array(out, dtype=np.int32).T.copy()
+        def arr(x):
+            return np.array(x, dtype=np.int32).reshape(-1, 4).T.copy()
+        return arr(short), arr(long_)
 
 
 class _Buffers:
@@ -312,7 +324,7 @@ class Bert(nn.Module):
 
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
     def encode(self, groups):
-        packed = PackedTokens(groups, self._device, pack=self.pack)
+        packed = PackedTokens(groups, self._device, pack=self.pack, mfma_long=self.weights.dtype != hip.DT_F32)
         return packed, bert_encode(self.weights, packed)
 
     def pool_mix(self, packed, layers, group, offsets, word_mask, layer_w, offsets_arr=None):

@@ -68,7 +68,7 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
     void* out = (char*)layers_out + (size_t)l * R * H * es;
     if ((rc = gemm(in, H, m->w_qkv[l], m->b_qkv[l], nullptr, qkv, dt, 3 * H, RUART_ACT_NONE))) return rc;
     if ((rc = ruart_bert_attention(qkv, 3 * H, ctx, H, dt, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
-                                   b->tok_lo, b->tok_hi, b->key_bias, stream)))
+                                   b->tok_lo, b->tok_hi, b->key_bias, b->n_long_blocks, b->lblk_q0, b->lblk_q1, b->lblk_k0, b->lblk_k1, stream)))
       return rc;
     if ((rc = gemm(ctx, H, m->w_ao[l], m->b_ao[l], in, pre, RUART_DT_F32, H, RUART_ACT_NONE))) return rc;
     if ((rc = ruart_rows_layernorm(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid, H, dt, R, H, stream))) return rc;

@@ -194,6 +194,144 @@ __global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------------------------
+// MFMA flash attention for LONG sequences (one sequence per 64-query block; the (B, 512) north-star shape).
+// Everything is laid out "query on lane&15":
+//   S^T (keys x queries) = K . Q^T      A = K rows from LDS (ds_read_b128), B = Q fragments held in registers
+//   online softmax per query column: 16 scores per lane + two cross-lane-group shuffles
+//   O^T (d x queries)   += V^T . P^T    B = the S^T accumulators themselves (converted to 16-bit, no data movement:
+//                                       an accumulator tile is a valid B operand with a permuted k order, cdna guide
+//                                       section 3), A = V^T fetched with ds_read_b64_tr_b16 (hardware transpose, T10)
+//                                       in the SAME permuted key order: element j of lane group g = key 16(j>>2)+4g+(j&3).
+// K/V tiles of 64 keys are staged through registers into LDS rows of 128+16 bytes (conflict-light for both the row
+// reads and the transposed reads); rows past the sequence end are zero-filled so masked probabilities never meet NaNs.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tr16x4_t;
+typedef __attribute__((address_space(3))) tr16x4_t* tr_ptr_t;
+
+template <typename T16>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
+                                                         const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                         const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                         const float* __restrict__ key_bias) {
+  constexpr int RS = 144;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * RS];
+  typedef typename Vec8<T16>::type frag_t;
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
+  const int tq = q0 + wave * 16 + fr;
+  const bool qvalid = tq < q1;
+
+  frag_t qf[2];
+  {
+    const T16* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
+    qf[0] = *reinterpret_cast<const frag_t*>(qp);
+    qf[1] = *reinterpret_cast<const frag_t*>(qp + 32);
+  }
+  float m = -1e30f, l = 0.f;
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 2, sc0 = (tid & 3) * 2;       // staging: row 0..63, two 16-byte chunks
+  for (int kt = k0; kt < k1; kt += 64) {
+    const int tn = min(64, k1 - kt);
+    __syncthreads();
+    {
+      uint4 kv[2], vv[2];
+      if (srow < tn) {
+        const T16* kp = qkv + (size_t)(kt + srow) * ld + H + h * 64 + sc0 * 8;
+        kv[0] = *reinterpret_cast<const uint4*>(kp);
+        kv[1] = *reinterpret_cast<const uint4*>(kp + 8);
+        vv[0] = *reinterpret_cast<const uint4*>(kp + H);
+        vv[1] = *reinterpret_cast<const uint4*>(kp + H + 8);
+      } else {
+        kv[0] = kv[1] = vv[0] = vv[1] = make_uint4(0, 0, 0, 0);
+      }
+      *reinterpret_cast<uint4*>(Ks + srow * RS + sc0 * 16) = kv[0];
+      *reinterpret_cast<uint4*>(Ks + srow * RS + sc0 * 16 + 16) = kv[1];
+      *reinterpret_cast<uint4*>(Vs + srow * RS + sc0 * 16) = vv[0];
+      *reinterpret_cast<uint4*>(Vs + srow * RS + sc0 * 16 + 16) = vv[1];
+    }
+    __syncthreads();
+
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      sacc[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + (it * 16 + fr) * RS + (ks * 32 + g * 8) * 2);
+        sacc[it] = mfma_16x16x32(kf, qf[ks], sacc[it]);
+      }
+    }
+    // sacc[it][r] = score(key kt + it*16 + g*4 + r, query fr)
+    float mx = -1e30f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = it * 16 + g * 4 + r;
+        float v = sacc[it][r];
+        if (key_bias && j < tn) v += key_bias[kt + j];
+        v = (j < tn) ? v : -1e30f;
+        sacc[it][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float scl = __expf(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = it * 16 + g * 4 + r;
+        const float p = (j < tn) ? __expf(sacc[it][r] - mn) : 0.f;
+        sacc[it][r] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * scl + rs;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= scl;
+
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      frag_t pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[j] = (T16)sacc[2 * s2][j];
+        pf[4 + j] = (T16)sacc[2 * s2 + 1][j];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // transposed fetch of V: block rows (keys) 32*s2 + 4g .. +3 and +16, columns dt*16 .. +15; lane 4q+p of the 16-lane
+        // group supplies row q, columns 4p..4p+3 and receives column (lane&15), rows 0..3
+        const char* base = Vs + (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
+        const tr16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)base);
+        const tr16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(base + 16 * RS));
+        union { struct { tr16x4_t a, b; } s; frag_t f; } u;
+        u.s.a = lo;
+        u.s.b = hi;
+        o[dt] = mfma_16x16x32(u.f, pf, o[dt]);
+      }
+    }
+  }
+  if (qvalid) {
+    const float inv = 1.0f / l;
+    T16* op = ctx + (size_t)tq * ldc + h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(op + dt * 16, o[dt] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sub-word pooling fused with the layer mix.  One wave per word.
 //   out[dst_row[w]][:] = sum_l wl[l] * mean_{p in [start, start+len)} layer_l[p][:]
 // ---------------------------------------------------------------------------------------------
@@ -327,16 +465,28 @@ extern "C" int ruart_bert_embed_ln(const int* ids, const int* pos, const float* 
 
 extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype, int H, int n_heads, int n_blocks,
                                     const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1,
-                                    const int* tok_lo, const int* tok_hi, const float* key_bias, void* stream) {
-  if (n_heads * 64 != H || n_blocks <= 0) return (int)hipErrorInvalidValue;
-  const dim3 grid(n_blocks, n_heads), block(64);
-  if (dtype == RUART_DT_BF16)
-    hipLaunchKernelGGL(attn_varlen_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-  else if (dtype == RUART_DT_F16)
-    hipLaunchKernelGGL(attn_varlen_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-  else
-    hipLaunchKernelGGL(attn_varlen_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-  RUART_CHECK_LAUNCH();
+                                    const int* tok_lo, const int* tok_hi, const float* key_bias, int n_long_blocks,
+                                    const int* lblk_q0, const int* lblk_q1, const int* lblk_k0, const int* lblk_k1, void* stream) {
+  if (n_heads * 64 != H || n_blocks < 0 || n_long_blocks < 0 || n_blocks + n_long_blocks <= 0) return (int)hipErrorInvalidValue;
+  if (n_long_blocks > 0 && dtype == RUART_DT_F32) return (int)hipErrorInvalidValue;   // the MFMA kernel is 16-bit only
+  if (n_blocks > 0) {
+    const dim3 grid(n_blocks, n_heads), block(64);
+    if (dtype == RUART_DT_BF16)
+      hipLaunchKernelGGL(attn_varlen_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+    else if (dtype == RUART_DT_F16)
+      hipLaunchKernelGGL(attn_varlen_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+    else
+      hipLaunchKernelGGL(attn_varlen_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+    RUART_CHECK_LAUNCH();
+  }
+  if (n_long_blocks > 0) {
+    const dim3 grid(n_long_blocks, n_heads), block(256);
+    if (dtype == RUART_DT_BF16)
+      hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+    else
+      hipLaunchKernelGGL(attn_flash_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+    RUART_CHECK_LAUNCH();
+  }
   return 0;
 }
 

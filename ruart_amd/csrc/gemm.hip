@@ -153,6 +153,248 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent form of the 128x128x64 kernel: 2 workgroups per CU walk the (XCD-remapped, grouped) tile list with a
+// stride of gridDim.x, and the K loop is flattened over (tile, k-step): the first stage of the NEXT tile is already in
+// flight while the current tile's last MFMAs and its epilogue run, so the ~2 us load latency of a prologue and the
+// store tail of an epilogue - 30-40 % of a K=768 tile's life - overlap instead of serialising.
+// ------------------------------------------------------------------------------------------------
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(256) void gemm_16_nt_128p(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                       const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                       void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kTile = BM * BK * 2;
+  constexpr int kStage = 2 * kTile;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN, ntm = M / BM;
+  const int ntiles = ntn * ntm;
+  const int nt = K / BK;
+  const int G = gridDim.x;
+  // this workgroup's tiles: logical ids xcd_remap(b), then +G, +2G ... (G is a multiple of 8, so the XCD class is kept)
+  const int first = blockIdx.x;
+  const int my_tiles = (ntiles - first + G - 1) / G;
+  if (my_tiles <= 0) return;
+
+  auto tile_origin = [&](int j, int& m0, int& n0) {
+    const int lin = first + j * G;
+    const int round0 = (lin / G) * G;
+    const int cnt = min(G, ntiles - round0);                   // tiles in this round (the last round may be partial)
+    const int id = round0 + xcd_remap(lin - round0, cnt);      // bijective on [round0, round0 + cnt)
+    int tm, tn;
+    if (order == 0) {
+      tm = id / ntn;
+      tn = id % ntn;
+    } else {
+      const int per_group = order * ntn;
+      const int g = id / per_group, f0 = g * order;
+      const int gsz = min(ntm - f0, order);
+      const int r = id - g * per_group;
+      tm = f0 + r % gsz;
+      tn = r / gsz;
+    }
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
+  auto stage = [&](int buf, int m0, int n0, int k0) {
+    const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8 + k0;
+    const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8 + k0;
+    char* base = smem + buf * kStage + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step), (lptr_t)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step), (lptr_t)(base + kTile + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+  int m0, n0, nm0, nn0;
+  tile_origin(0, m0, n0);
+  stage(0, m0, n0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int j = 0; j < my_tiles; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool has_next = j + 1 < my_tiles;
+    if (has_next) tile_origin(j + 1, nm0, nn0);
+    for (int t = 0; t < nt; ++t) {
+      // prefetch the next flattened step: next k-step of this tile, or k-step 0 of the next tile
+      if (t + 1 < nt) stage(buf ^ 1, m0, n0, (t + 1) * BK);
+      else if (has_next) stage(buf ^ 1, nm0, nn0, 0);
+      const char* sa = smem + buf * kStage;
+      const char* sw = sa + kTile;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        frag_t wf[4], af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+          af[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_16x16x32(wf[i], af[jj], acc[i][jj]);
+      }
+      if (t + 1 == nt) {
+        // epilogue of this tile, with the next tile's first stage in flight
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = n0 + wn * 64 + i * 16 + fq * 4;
+          f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+          if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int m = m0 + wm * 64 + jj * 16 + fr;
+            f32x4_t v = acc[i][jj] + bv;
+            if (ACT == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+            }
+            if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
+            if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
+            if (OUT_F32)
+              store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
+            else
+              store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
+          }
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+    m0 = nm0;
+    n0 = nn0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 per wave), THREE LDS stages of 48 KB.
+// Why: PMC on the 128x128 kernel (profiles/r01_gemm_pmc.md) shows it is bound by global->LDS latency/throughput
+// (~36 GB/s per CU delivered; MFMA pipe 24 % busy, LDS conflicts 0).  This variant moves 25 % fewer bytes per flop
+// (85 flop/B instead of 64) and keeps two K-steps of LDS-DMA in flight across the barrier: the next-next stage is issued
+// before the MFMAs of the current one, the wait is a COUNTED s_waitcnt vmcnt(6) (= the 6 global_load_lds of the newest
+// stage stay outstanding) and the barrier is a raw s_barrier, which - unlike __syncthreads() - does not drain the DMA
+// queue (cdna_hip_programming.md, "Pipelining across barriers").  RAW: a stage is read one barrier after the wait that
+// retires it; WAR: stage (t+2)%3 was last read in step t-1 and every wave has passed that step's barrier.
+// ------------------------------------------------------------------------------------------------
+#define BM2 256
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(512) void gemm_16_nt_256(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                      void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kTileA = BM2 * BK * 2;           // 32 KB
+  constexpr int kTileW = BN * BK * 2;            // 16 KB
+  constexpr int kStage = kTileA + kTileW;        // 48 KB
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 3 * kStage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN, ntm = M / BM2;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+  const int m0 = tm * BM2, n0 = tn * BN;
+
+  // staging: A tile = 32 wave-instructions of 1 KB (8 rows), 4 per wave; W tile = 16, 2 per wave
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
+  const T16* w_src = W + (size_t)(n0 + wave * 16 + srow) * ldw + schunk * 8;
+  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
+  auto stage = [&](int buf, int k0) {
+    char* base = smem + buf * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + wave * 4096 + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + kTileA + wave * 2048 + i * 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * kStage;
+    const char* sw = sa + kTileA;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        af[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(wf[i], af[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  const int nt = K / BK;
+  stage(0, 0);
+  if (nt > 1) stage(1, BK);
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int nxt2 = cur == 0 ? 2 : cur - 1;           // (cur + 2) % 3
+    if (t + 2 < nt) stage(nxt2, (t + 2) * BK);
+    compute(cur);
+    // retire stage t+1 (issued one step ago); the stage just issued (6 DMAs per lane-wave) may stay in flight
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      f32x4_t v = acc[i][j] + bv;
+      if (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32 path: 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
 // ------------------------------------------------------------------------------------------------
 #define FBM 64
@@ -259,9 +501,15 @@ bool g_prof_on = false;
 int g_tile_order = 8;            // GROUP_M of the tile walk (0 = plain row-major); tuning knob, see ruart_gemm_set_tile_order
 int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
 
+extern int g_gemm_variant;
 extern "C" int ruart_gemm_set_tile_order(int group_m) {
   if (group_m < 0 || group_m > 64) return (int)hipErrorInvalidValue;
   g_tile_order = group_m;
+  return 0;
+}
+extern "C" int ruart_gemm_set_variant(int v) {
+  if (v < 0 || v > 2) return (int)hipErrorInvalidValue;
+  g_gemm_variant = v;
   return 0;
 }
 
@@ -294,14 +542,38 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
   return 0;
 }
 
+int g_gemm_variant = 0;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128
+int g_gemm_persist_blocks = 512; // persistent grid: 2 workgroups x 256 CUs
+
+template <typename T16, bool OF, int RS, int AC>
+static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr,
+                       void* C, int ldc, int M, int N, int K, hipStream_t s) {
+  if (g_gemm_variant == 2) {
+    const int ntiles = (M / BM) * (N / BN);
+    int grid = g_gemm_persist_blocks < ntiles ? g_gemm_persist_blocks : ((ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((gemm_16_nt_128p<T16, OF, RS, AC>), dim3(grid), dim3(256), 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc,
+                       M, N, K, g_tile_order);
+  } else if (big) {
+    static bool attr_set = false;
+    auto kern = gemm_16_nt_256<T16, OF, RS, AC>;
+    constexpr int lds = 3 * (BM2 + BN) * BK * 2;
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)done; (void)attr_set;
+    hipLaunchKernelGGL(kern, dim3((M / BM2) * (N / BN)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       g_tile_order);
+  } else {
+    hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), dim3((M / BM) * (N / BN)), dim3(256), 0, s, a, lda, w, ldw, bias, residual,
+                       ldr, C, ldc, M, N, K, g_tile_order);
+  }
+}
+
 template <typename T16>
 static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, int res,
                          void* C, int ldc, bool of, int M, int N, int K, int act, hipStream_t s) {
-  const dim3 grid((M / BM) * (N / BN)), block(256);
+  const bool big = g_gemm_variant == 1 && (M % BM2 == 0);
   const T16* a = (const T16*)A;
   const T16* w = (const T16*)W;
-#define LAUNCH(OF, RS, AC) \
-  hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), grid, block, 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, g_tile_order)
+#define LAUNCH(OF, RS, AC) launch_one<T16, OF, RS, AC>(big, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, s)
   if (act == RUART_ACT_GELU) {
     if (res != 0) return (int)hipErrorInvalidValue;
     if (of) LAUNCH(true, 0, 1); else LAUNCH(false, 0, 1);

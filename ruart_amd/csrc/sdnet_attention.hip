@@ -30,12 +30,28 @@ __device__ __forceinline__ f32x4_t mma16(const float* As, int lda, const float* 
   return acc;
 }
 
+// Activation folded into the staging of the projected operands (Layers.py:228-231): a = ReLU(p1) * diag, k = ReLU(p2).
+// diag_len: 0 = none, 1 = one scalar (do_similarity), otherwise a per-column vector of that length.
+struct Act {
+  int relu;
+  const float* diag;
+  int diag_len;
+  __device__ __forceinline__ float operator()(float v, int col) const {
+    if (relu) v = fmaxf(v, 0.f);
+    if (diag_len == 1) v *= diag[0];
+    else if (diag_len > 1) v *= diag[col];
+    return v;
+  }
+};
+__device__ __forceinline__ Act no_act() { return Act{0, nullptr, 0}; }
+
 // stage rows [r0, r0+nr) x cols [c0, c0+CH) of a row-major (rows x cols, ld) matrix into dst[nr_pad][ldd], zero-filled
-__device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols) {
+__device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols,
+                                      Act act = Act{0, nullptr, 0}) {
   for (int e = threadIdx.x; e < nr_pad * CH; e += blockDim.x) {
     const int r = e / CH, c = e % CH;
     const int gr = r0 + r, gc = c0 + c;
-    dst[r * ldd + c] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+    dst[r * ldd + c] = (gr < rows && gc < cols) ? act(src[(size_t)gr * ld + gc], gc) : 0.f;
   }
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
@@ -55,7 +71,8 @@ extern __shared__ __attribute__((aligned(16))) float dsm[];
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ k,
                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ probs, int L1, int L2, int h,
-                                                       int D3, int* __restrict__ nan_flag) {
+                                                       int D3, int* __restrict__ nan_flag, int relu, const float* __restrict__ diag,
+                                                       int diag_len) {
   const int b = blockIdx.y, i0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
@@ -73,8 +90,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < h; c0 += CH) {
     __syncthreads();
-    stage(a_s, LDA_, 16, ab, h, i0, L1, c0, h);
-    stage(kv_s, LDA_, L2p, kb, h, 0, L2, c0, h);
+    stage(a_s, LDA_, 16, ab, h, i0, L1, c0, h, Act{relu, diag, diag_len});
+    stage(kv_s, LDA_, L2p, kb, h, 0, L2, c0, h, Act{relu, nullptr, 0});
     __syncthreads();
     const int kc = min(CH, (h - c0 + 3) & ~3);
 #pragma unroll
@@ -145,7 +162,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                          const float* __restrict__ probs, const float* __restrict__ gout,
                                                          float* __restrict__ grad_a, float* __restrict__ dS, int L1, int L2, int h,
-                                                         int D3) {
+                                                         int D3, const float* __restrict__ pa, int relu,
+                                                         const float* __restrict__ diag, int diag_len,
+                                                         float* __restrict__ grad_diag) {
   const int b = blockIdx.y, i0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
@@ -202,29 +221,46 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   }
   for (int d0 = 0; d0 < h; d0 += CH) {      // grad_a = dS . k
     __syncthreads();
-    stage(kv_s, LDB_, L2p, kb, h, 0, L2, d0, h);
+    stage(kv_s, LDB_, L2p, kb, h, 0, L2, d0, h, Act{relu, nullptr, 0});
     __syncthreads();
     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
     o = mma16(S_s, ldS, kv_s + wave * 16, LDB_, 1, L2p, o);
     const int d = d0 + wave * 16 + (lane & 15);
+    // o = d(loss)/d(a) with a = ReLU(pa) * diag: chain to pa and to diag
+    float gd = 0.f;
+    const float dsc = (d < h) ? (diag_len == 1 ? diag[0] : (diag_len > 1 ? diag[d] : 1.f)) : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + (lane >> 4) * 4 + r;
-      if (i < L1 && d < h) grad_a[((size_t)b * L1 + i) * h + d] = o[r];
+      if (i < L1 && d < h) {
+        const size_t at = ((size_t)b * L1 + i) * h + d;
+        float g = o[r];
+        if (pa) {
+          const float pv = pa[at];
+          gd += g * (relu ? fmaxf(pv, 0.f) : pv);
+          g = (relu && pv <= 0.f) ? 0.f : g * dsc;
+        }
+        grad_a[at] = g;
+      }
+    }
+    if (grad_diag) {      // vector diag only: sum over this tile's 16 rows = the 4 lanes sharing a column
+      gd += __shfl_xor(gd, 16, 64);
+      gd += __shfl_xor(gd, 32, 64);
+      if ((lane >> 4) == 0 && d < h) atomicAdd(grad_diag + d, gd);
     }
   }
 }
 
 // backward B: per (batch, 16 key rows): C[16 j][N] = X^T . Y with X (L1 x L2) in {dS, P}, Y (L1 x N) in {a, gO}
 __device__ __forceinline__ void tn_product(const float* X, int L1, int L2, int j0, const float* Y, int N, float* C, float* xt_s,
-                                           float* y_s) {
+                                           float* y_s, Act yact, const float* out_gate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int n0 = 0; n0 < N; n0 += CH) {
     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < L1; r0 += CH) {
       __syncthreads();
       stage_t16(xt_s, LDA_, X, L2, r0, L1, j0, L2);     // xt_s[j][i]
-      stage(y_s, LDB_, CH, Y, N, r0, L1, n0, N);         // y_s[i][n]
+      stage(y_s, LDB_, CH, Y, N, r0, L1, n0, N, yact);   // y_s[i][n]
       __syncthreads();
       const int kc = min(CH, (L1 - r0 + 3) & ~3);
       o = mma16(xt_s, LDA_, y_s + wave * 16, LDB_, 1, kc, o);
@@ -233,7 +269,10 @@ __device__ __forceinline__ void tn_product(const float* X, int L1, int L2, int j
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = j0 + (lane >> 4) * 4 + r;
-      if (j < L2 && n < N) C[(size_t)j * N + n] = o[r];
+      if (j < L2 && n < N) {
+        const size_t at = (size_t)j * N + n;
+        C[at] = (out_gate && out_gate[at] <= 0.f) ? 0.f : o[r];       // d/d(pk) of ReLU(pk)
+      }
     }
   }
 }
@@ -241,13 +280,15 @@ __device__ __forceinline__ void tn_product(const float* X, int L1, int L2, int j
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ a, const float* __restrict__ probs,
                                                           const float* __restrict__ dS, const float* __restrict__ gout,
                                                           float* __restrict__ grad_k, float* __restrict__ grad_v, int L1, int L2, int h,
-                                                          int D3) {
+                                                          int D3, const float* __restrict__ pk, int relu,
+                                                          const float* __restrict__ diag, int diag_len) {
   const int b = blockIdx.y, j0 = blockIdx.x * 16;
   float* xt_s = dsm;                   // [16][LDA_]
   float* y_s = xt_s + 16 * LDA_;       // [CH][LDB_]
   const size_t pb = (size_t)b * L1 * L2;
-  tn_product(dS + pb, L1, L2, j0, a + (size_t)b * L1 * h, h, grad_k + (size_t)b * L2 * h, xt_s, y_s);
-  tn_product(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s);
+  tn_product(dS + pb, L1, L2, j0, a + (size_t)b * L1 * h, h, grad_k + (size_t)b * L2 * h, xt_s, y_s, Act{relu, diag, diag_len},
+             (relu && pk) ? pk + (size_t)b * L2 * h : nullptr);
+  tn_product(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s, no_act(), nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,25 +366,31 @@ static size_t attn_lds_bytes(int L2) {
   return sizeof(float) * (size_t)(16 * LDA_ + 16 * ldS + L2p * LDB_);
 }
 
-extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, float* out, float* probs,
-                              int B, int L1, int L2, int h, int D3, void* stream) {
+extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
+                              int diag_len, int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
   const dim3 grid(ceil_div(L1, 16), B), block(256);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3, ruart_nan_flag_ptr);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
+                     ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len);
   RUART_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
-                              float* grad_a, float* grad_k, float* grad_v, float* ds_ws, int B, int L1, int L2, int h, int D3,
-                              void* stream) {
+                              const float* diag, int diag_len, int relu, float* grad_a, float* grad_k, float* grad_v,
+                              float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
+  const bool act = relu || diag_len;
+  const float* dg = diag_len ? diag : nullptr;
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
-                     grad_out, grad_a, ds_ws, L1, L2, h, D3);
+                     grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,
+                     (diag_len > 1) ? grad_diag : nullptr);
   RUART_CHECK_LAUNCH();
   const size_t lds = sizeof(float) * (16 * LDA_ + CH * LDB_);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
-                     grad_k, grad_v, L1, L2, h, D3);
+                     grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -35,7 +35,8 @@ class BertModelC(Structure):
 class BertBatchC(Structure):
     _fields_ = [("n_tokens", c_int), ("n_rows", c_int), ("ids", c_void_p), ("pos_ids", c_void_p), ("n_blocks", c_int),
                 ("blk_q0", c_void_p), ("blk_q1", c_void_p), ("blk_k0", c_void_p), ("blk_k1", c_void_p),
-                ("tok_lo", c_void_p), ("tok_hi", c_void_p), ("key_bias", c_void_p)]
+                ("tok_lo", c_void_p), ("tok_hi", c_void_p), ("key_bias", c_void_p),
+                ("n_long_blocks", c_int), ("lblk_q0", c_void_p), ("lblk_q1", c_void_p), ("lblk_k0", c_void_p), ("lblk_k1", c_void_p)]
 
 
 _P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
@@ -45,20 +46,21 @@ _SIGNATURES = {
     "ruart_gemm_f32_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
-    "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_cast_f32_to_16": (_I, [_P, _P, _I, _LL, _F, _P]),
     "ruart_bert_workspace_bytes": (c_size_t, [POINTER(BertModelC), _I]),
     "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),
-    "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_whole_ln_fwd": (_I, [_P, _P, _P, _P, _LL, _F, _P]),
     "ruart_whole_ln_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),
+    "ruart_gemm_set_variant": (_I, [_I]),
     "ruart_prof_enable": (_I, [_I]),
     "ruart_prof_read": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
 }

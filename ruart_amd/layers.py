@@ -25,13 +25,47 @@ def set_seq_dropout(option):
     do_seq_dropout = option
 
 
+class MaskBank:
+    """Pre-generated variational-dropout masks.  The reference draws one small Bernoulli tensor per dropout site
+    (~50 sites per forward => ~200 tiny launches for fill / bernoulli / scale / multiply).  Here one launch per distinct
+    p fills a big buffer of already-scaled masks at the start of the step; a site just takes the next slice.  The
+    buffer is sized from the previous step's demand; if it runs dry the site falls back to drawing its own mask."""
+
+    def __init__(self):
+        self.buf = {}        # p -> (tensor, offset)
+        self.demand = {}     # p -> elements used last step
+        self.used = {}
+
+    def begin_step(self, device):
+        for p, n in self.used.items():
+            self.demand[p] = max(self.demand.get(p, 0), n)
+        self.used = {}
+        self.buf = {}
+        for p, n in self.demand.items():
+            if n > 0:
+                t = torch.empty(int(n * 1.05) + 1024, device=device, dtype=torch.float32).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+                self.buf[p] = [t, 0]
+
+    def take(self, rows, cols, p, like):
+        n = rows * cols
+        self.used[p] = self.used.get(p, 0) + n
+        ent = self.buf.get(p)
+        if ent is not None and ent[0].device == like.device and ent[1] + n <= ent[0].numel():
+            m = ent[0][ent[1]:ent[1] + n].view(rows, cols)
+            ent[1] += n
+            return m
+        return torch.bernoulli(like.new_full((rows, cols), 1.0 - p)) / (1.0 - p)
+
+
+mask_bank = MaskBank()
+
+
 def seq_dropout(x, p=0, training=False):
     """Variational dropout (Layers.py:23-30): one Bernoulli mask per (batch row, feature), shared over time,
     scaled by 1/(1-p)."""
     if not training or p == 0:
         return x
-    mask = torch.bernoulli(x.new_full((x.size(0), x.size(2)), 1.0 - p)) / (1.0 - p)
-    return mask.unsqueeze(1) * x
+    return mask_bank.take(x.size(0), x.size(2), p, x).unsqueeze(1) * x
 
 
 def dropout(x, p=0, training=False):
@@ -48,8 +82,7 @@ def row_dropout(x, rows_of, n_rows, p, training):
         return x
     if not do_seq_dropout:
         return F.dropout(x, p=p, training=True)
-    mask = torch.bernoulli(x.new_full((n_rows, x.size(1)), 1.0 - p)) / (1.0 - p)
-    return x * mask[rows_of]
+    return x * mask_bank.take(n_rows, x.size(1), p, x)[rows_of]
 
 
 class StackedBRNN(nn.Module):
@@ -153,16 +186,15 @@ class AttentionScore(nn.Module):
         else:
             self.diagonal = Parameter(torch.ones(1, 1, hidden_size), requires_grad=True)
 
-    def project(self, x1, x2):
+    def project_raw(self, x1, x2):
+        """W x1, W x2 (after input dropout); the ReLU and the diagonal are applied inside the fused attention kernel."""
         x1 = dropout(x1, p=dropout_p, training=self.training)
         x2 = dropout(x2, p=dropout_p, training=self.training)
-        a = F.relu(self.linear(x1)) * self.diagonal
-        k = F.relu(self.linear(x2))
-        return a, k
+        return self.linear(x1), self.linear(x2)
 
     def forward(self, x1, x2):
-        a, k = self.project(x1, x2)
-        return a.bmm(k.transpose(1, 2))
+        p1, p2 = self.project_raw(x1, x2)
+        return (F.relu(p1) * self.diagonal).bmm(F.relu(p2).transpose(1, 2))
 
 
 class Attention(nn.Module):
@@ -176,8 +208,8 @@ class Attention(nn.Module):
     def forward(self, x1, x2, x2_mask, x3=None, drop_diagonal=False, return_score=False):
         if drop_diagonal or return_score:
             raise NotImplementedError("drop_diagonal / return_score are not used by SDNet.forward")
-        a, k = self.scoring.project(x1, x2)
-        return ops.fused_attention(a, k, x2 if x3 is None else x3, x2_mask)
+        p1, p2 = self.scoring.project_raw(x1, x2)
+        return ops.fused_attention(p1, p2, x2 if x3 is None else x3, x2_mask, diag=self.scoring.diagonal, relu=True)
 
 
 def RNN_from_opt(input_size_, hidden_size_, num_layers=1, concat_rnn=False, add_feat=0, bidirectional=True, rnn_type=nn.LSTM,

@@ -12,7 +12,7 @@ _WS = {}
 
 
 def _scratch(device, n):
-    key = (device, "f32")
+    key = (device, torch.cuda.current_stream(device).cuda_stream)      # per stream: branches run concurrently
     t = _WS.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 4096), dtype=torch.float32, device=device)
@@ -46,43 +46,50 @@ nan_flag = _NanFlag()
 
 # ---------------------------------------------------------------------------------------------------------
 class _FusedAttention(torch.autograd.Function):
-    """out = softmax_j(mask(a . k^T)) . v   (Models/Layers.py:244, 275-288)."""
+    """out = softmax_j(mask(a . k^T)) . v with a = act(pa) * diag, k = act(pk)   (Models/Layers.py:228-231, 244, 275-288)."""
 
     @staticmethod
-    def forward(ctx, a, k, v, mask):
+    def forward(ctx, pa, pk, v, mask, diag, relu):
         lib = hip.load()
-        for t in (a, k, v):
+        for t in (pa, pk, v):
             hip.require_gpu(t, torch.float32)
-        nan_flag.ensure(a.device)
-        B, L1, h = a.shape
-        L2, D3 = k.shape[1], v.shape[2]
-        out = torch.empty(B, L1, D3, dtype=torch.float32, device=a.device)
-        probs = torch.empty(B, L1, L2, dtype=torch.float32, device=a.device)
-        rc = lib.ruart_attn_fwd(hip.ptr(a), hip.ptr(k), hip.ptr(v), hip.ptr(mask), hip.ptr(out), hip.ptr(probs), B, L1, L2, h, D3,
-                                hip.stream_ptr())
+        nan_flag.ensure(pa.device)
+        B, L1, h = pa.shape
+        L2, D3 = pk.shape[1], v.shape[2]
+        dl = 0 if diag is None else diag.numel()
+        out = torch.empty(B, L1, D3, dtype=torch.float32, device=pa.device)
+        probs = torch.empty(B, L1, L2, dtype=torch.float32, device=pa.device)
+        rc = lib.ruart_attn_fwd(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(mask), hip.ptr(diag), dl, int(relu), hip.ptr(out),
+                                hip.ptr(probs), B, L1, L2, h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_fwd")
-        ctx.save_for_backward(a, k, v, probs)
+        ctx.save_for_backward(pa, pk, v, probs, diag)
+        ctx.relu = int(relu)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = hip.load()
-        a, k, v, probs = ctx.saved_tensors
-        B, L1, h = a.shape
-        L2, D3 = k.shape[1], v.shape[2]
+        pa, pk, v, probs, diag = ctx.saved_tensors
+        B, L1, h = pa.shape
+        L2, D3 = pk.shape[1], v.shape[2]
+        dl = 0 if diag is None else diag.numel()
         gout = gout.contiguous()
-        ga, gk, gv = torch.empty_like(a), torch.empty_like(k), torch.empty_like(v)
+        ga, gk, gv = torch.empty_like(pa), torch.empty_like(pk), torch.empty_like(v)
         ds = torch.empty_like(probs)
-        rc = lib.ruart_attn_bwd(hip.ptr(a), hip.ptr(k), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(ga), hip.ptr(gk),
-                                hip.ptr(gv), hip.ptr(ds), B, L1, L2, h, D3, hip.stream_ptr())
+        gdiag = torch.zeros(h, dtype=torch.float32, device=pa.device) if (dl > 1 and ctx.needs_input_grad[4]) else None
+        rc = lib.ruart_attn_bwd(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
+                                hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2, h, D3,
+                                hip.stream_ptr())
         hip.check(rc, "ruart_attn_bwd")
-        return ga, gk, gv, None
+        return ga, gk, gv, None, (gdiag.view_as(diag) if gdiag is not None else None), None
 
 
-def fused_attention(a, k, v, mask):
-    """a (B,L1,h), k (B,L2,h), v (B,L2,D3) fp32; mask (B,L2) uint8/bool (0 = masked key)."""
+def fused_attention(a, k, v, mask, diag=None, relu=False):
+    """a (B,L1,h), k (B,L2,h), v (B,L2,D3) fp32; mask (B,L2) uint8/bool (0 = masked key).  With ``relu`` / ``diag`` the
+    activation of the reference's AttentionScore is applied inside the kernel: a <- ReLU(a) * diag, k <- ReLU(k)."""
     m = mask.to(torch.uint8).contiguous()
-    return _FusedAttention.apply(a.contiguous(), k.contiguous(), v.contiguous(), m)
+    d = None if diag is None else diag.contiguous().view(-1)
+    return _FusedAttention.apply(a.contiguous(), k.contiguous(), v.contiguous(), m, d, relu)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -224,6 +224,8 @@ class SDNet(nn.Module):
         opt = self.opt
         dev = self.device
         bi = self.prepare(q_list, ocr_list, od_list)
+        if self.training or self.drop_emb:
+            L.mask_bank.begin_step(dev)
 
         # ---- BERT: one packed pass, then pooled + mixed per group --------------------------------------------
         layers = bert_encode(self.Bert.weights, bi.packed)
@@ -234,37 +236,50 @@ class SDNet(nn.Module):
             mixes.append(_PoolMix.apply(lw, layers, s, l, dst, rows, self.Bert.weights.dtype))
         Bq, Q = q_list[opt["q_emb_initial"]].shape
         q_bert = mixes[0].view(Bq, Q, H)
-
         q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev)
-        q_input, q_raw = self._embed_question(q_list, q_bert)
-        ocr_words, ocr_raw = self._embed_items(ocr_list, bi.ocr, mixes[1])
-        od_words, od_raw = self._embed_items(od_list, bi.od, mixes[2])
-        if "PRE_ALIGN_befor_rnn" in opt:
-            q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
-            ocr_words = torch.cat([ocr_words, self._prealign(ocr_raw, bi.ocr, q_raw, q_mask)], -1)
-            od_words = torch.cat([od_words, self._prealign(od_raw, bi.od, q_raw, q_mask)], -1)
-
-        ocr_input = self._multi2one_last(ocr_words, bi.ocr)                     # (B, max_ocr_num, 300)
-        od_input = self._multi2one_last(od_words, bi.od)                        # (B, max_od_num, 300)
         ocr_mask, od_mask = bi.ocr_mask, bi.od_mask
 
-        # ---- SDNet trunk (SDNet.py:338-415) -------------------------------------------------------------------
-        _, ocr_rnn_layers = self.context_rnn(ocr_input, ocr_mask, return_list=True, LN=True)
-        _, q_rnn_layers = self.ques_rnn(q_input, q_mask, return_list=True, LN=True)
-        _, od_rnn_layers = self.context_rnn(od_input, od_mask, return_list=True, LN=True)
-        q_highlvl = self.high_lvl_ques_rnn(torch.cat(q_rnn_layers, 2), q_mask, LN=True)
-        q_rnn_layers = q_rnn_layers + [q_highlvl]
+        # The question, OCR and object branches are independent until they meet in deep_attn / od_ocr_attn.  Their
+        # kernels are small (B=64 rows), so they run on three HIP streams and overlap on the 256 CUs; autograd replays
+        # each backward on its forward's stream, so the backward overlaps the same way.
+        main = torch.cuda.current_stream(dev)
+        use_streams = bool(opt.get("ruart_streams", True))
+        s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
 
+        q_input, q_raw = self._embed_question(q_list, q_bert)
+        if "PRE_ALIGN_befor_rnn" in opt:
+            q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
+        self._fork(main, (s_q, s_od), [q_input, q_raw, q_mask, mixes[2], od_mask])
+
+        with torch.cuda.stream(s_q):                                            # ---- question branch (SDNet.py:339, 350)
+            _, q_rnn_layers = self.ques_rnn(q_input, q_mask, return_list=True, LN=True)
+            q_highlvl = self.high_lvl_ques_rnn(torch.cat(q_rnn_layers, 2), q_mask, LN=True)
+            q_rnn_layers = q_rnn_layers + [q_highlvl]
+            ev_q_layers = s_q.record_event() if use_streams else None
+            q_final = self.ques_self_attn(q_highlvl, q_highlvl, q_mask)        # SDNet.py:411-415
+            q_merged = self.ques_merger.merge(q_final, q_mask)
         q_long = [q_raw]
-        ocr_h, ocr_pre = self.deep_attn([ocr_input], ocr_rnn_layers, q_long, q_rnn_layers, ocr_mask, q_mask, return_bef_rnn=True)
-        od_h, od_pre = self.deep_attn([od_input], od_rnn_layers, q_long, q_rnn_layers, od_mask, q_mask, return_bef_rnn=True)
 
-        ocr_sa_in = torch.cat([ocr_h, ocr_pre, ocr_input], 2)
-        od_sa_in = torch.cat([od_h, od_pre, od_input], 2)
-        ocr_sa = self.highlvl_self_att(ocr_sa_in, ocr_sa_in, ocr_mask, x3=ocr_h)
-        od_sa = self.highlvl_self_att(od_sa_in, od_sa_in, od_mask, x3=od_h)
-        ocr_hl = self.high_lvl_context_rnn(torch.cat([ocr_h, ocr_sa], 2), ocr_mask, LN=True)
-        od_hl = self.high_lvl_context_rnn(torch.cat([od_h, od_sa], 2), od_mask, LN=True)
+        def context_branch(items, idx, mix, mask):
+            """embedding, pre-align, multi2one, context_rnn, deep_attn, self-attention, high-level rnn for OCR or objects"""
+            words, raw = self._embed_items(items, idx, mix)
+            if "PRE_ALIGN_befor_rnn" in opt:
+                words = torch.cat([words, self._prealign(raw, idx, q_raw, q_mask)], -1)
+            x = self._multi2one_last(words, idx)                                # (B, max_num, 300)
+            _, rnn_layers = self.context_rnn(x, mask, return_list=True, LN=True)
+            if ev_q_layers is not None:
+                torch.cuda.current_stream(dev).wait_event(ev_q_layers)
+                for t in q_rnn_layers:
+                    t.record_stream(torch.cuda.current_stream(dev))
+            h, pre = self.deep_attn([x], rnn_layers, q_long, q_rnn_layers, mask, q_mask, return_bef_rnn=True)
+            sa_in = torch.cat([h, pre, x], 2)
+            sa = self.highlvl_self_att(sa_in, sa_in, mask, x3=h)
+            return self.high_lvl_context_rnn(torch.cat([h, sa], 2), mask, LN=True)
+
+        with torch.cuda.stream(s_od):                                           # ---- object branch
+            od_hl = context_branch(od_list, bi.od, mixes[2], od_mask)
+        ocr_hl = context_branch(ocr_list, bi.ocr, mixes[1], ocr_mask)           # ---- OCR branch on the main stream
+        self._join(main, (s_od, s_q), [od_hl, q_merged])
 
         if "position_dim" in opt:
             ocr_pos, od_pos = ocr_list["position"].to(dev), od_list["position"].to(dev)
@@ -274,12 +289,38 @@ class SDNet(nn.Module):
                 x_od_ocr = self.od_ocr_attn(torch.cat([ocr_hl, ocr_pos], 2), torch.cat([od_hl, od_pos], 2), od_mask)
         mode = opt["pos_att_merge_mod"]
         ocr_final = torch.cat([ocr_hl, x_od_ocr], 2) if mode == "cat" else (x_od_ocr if mode == "atted" else ocr_hl)
-
-        q_final = self.ques_self_attn(q_highlvl, q_highlvl, q_mask)
-        q_merged = self.ques_merger.merge(q_final, q_mask)
         es_len = opt["ES_ocr_len"] if "useES" in opt else None
         score_s = self.get_answer(ocr_final, q_merged, ocr_mask, es_len, mask_flag="mask_score" in opt)
         return score_s, None
+
+    # -- stream plumbing -----------------------------------------------------------------------------------
+    def _side_streams(self, dev):
+        st = getattr(self, "_streams", None)
+        if st is None or st[0].device != dev:
+            st = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._streams = st
+        return st
+
+    @staticmethod
+    def _fork(main, sides, tensors):
+        """side streams may start once everything enqueued on ``main`` so far is done; tensors made on ``main`` and
+        read on a side stream are registered with the caching allocator."""
+        for s in sides:
+            if s is main:
+                continue
+            s.wait_stream(main)
+            for t in tensors:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(s)
+
+    @staticmethod
+    def _join(main, sides, tensors):
+        for s in sides:
+            if s is not main:
+                main.wait_stream(s)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
 
     def check_nan(self):
         """One host sync honouring every ``assert torch.sum(torch.isnan(.)) == 0`` of the reference's forward."""

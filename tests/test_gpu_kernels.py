@@ -139,7 +139,7 @@ def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol
     d = dev()
     W = BertEncoderWeights(w, cfg, d, precision)
     ids, mask = T(z["ids"]), T(z["mask"])
-    packed = PackedTokens([(ids, mask)], d, pack=pack)
+    packed = PackedTokens([(ids, mask)], d, pack=pack, mfma_long=precision != "fp32")
     layers = bert_encode(W, packed).float().cpu()
     gi = packed.group_index[0]
     sel = T(z["mask"]).bool()
@@ -152,14 +152,16 @@ def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol
         assert err < tol, "%s %s %s: max abs err %.3e" % (name, precision, k, err)
 
 
-def test_bert_long_sequences_and_split_groups(golden_dir):
-    """Sequences longer than one 64-query block (the (B, 512)-style shape) and several groups in one pass."""
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("fp16", 1.5e-2), ("bf16", 8e-2)])
+def test_bert_long_sequences_and_split_groups(golden_dir, precision, tol):
+    """Sequences longer than one 64-query block (the (B, 512)-style shape: MFMA flash kernel in the 16-bit modes, key-tiled
+    VALU kernel in fp32) mixed with short ones, several groups in one pass, and the unpacked -10000 mode."""
     from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
     cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                             max_position_embeddings=256)
-    w = synth.make_bert_weights(cfg, seed=3)
+    w = synth.make_bert_weights(cfg, seed=3, w_std=0.08)
     g = np.random.default_rng(0)
-    lens_a, lens_b = [200, 65, 64, 1, 130], [7, 3, 256]
+    lens_a, lens_b = [200, 65, 64, 1, 130], [7, 3, 256, 129]
     def mk(lens, L):
         ids = np.zeros((len(lens), L), dtype=np.int64)
         for i, l in enumerate(lens):
@@ -167,16 +169,19 @@ def test_bert_long_sequences_and_split_groups(golden_dir):
         return T(ids), T(ids != 0)
     ga, gb = mk(lens_a, 200), mk(lens_b, 256)
     d = dev()
-    W = BertEncoderWeights(w, cfg, d, "fp32")
-    packed = PackedTokens([ga, gb], d)
-    layers = bert_encode(W, packed).cpu()
+    W = BertEncoderWeights(w, cfg, d, precision)
     wt = {k: T(v) for k, v in w.items()}
-    for gi, (ids, mask) in enumerate((ga, gb)):
-        with torch.no_grad():
-            ref = O.bert_forward(wt, cfg, ids, mask)
-        idx = T(packed.group_index[gi])
-        for l in range(2):
-            assert maxerr(layers[l][idx[mask]], ref[l][mask]) < 5e-5
+    for pack in (True, False):
+        packed = PackedTokens([ga, gb], d, pack=pack, mfma_long=precision != "fp32")
+        assert (packed.n_long_blocks > 0) == (precision != "fp32")
+        layers = bert_encode(W, packed).float().cpu()
+        for gi, (ids, mask) in enumerate((ga, gb)):
+            with torch.no_grad():
+                ref = O.bert_forward(wt, cfg, ids, mask)
+            idx = T(packed.group_index[gi])
+            for l in range(2):
+                err = maxerr(layers[l][idx[mask]], ref[l][mask])
+                assert err < tol, (precision, pack, gi, l, err)
 
 
 def test_pool_mix_fwd_bwd():
@@ -247,9 +252,8 @@ def test_fused_attention_vs_reference(layers_golden, tag):
     W = T(z[tag + "_W"]).to(d).requires_grad_()
     diag = T(z[tag + "_diag"]).to(d).requires_grad_()
     x3 = T(z[tag + "_x3"]).to(d).requires_grad_() if tag + "_x3" in z.files else None
-    a = torch.relu(x1 @ W.t()) * diag
-    k = torch.relu(x2 @ W.t())
-    y = ops.fused_attention(a, k, x2 if x3 is None else x3, T(z[tag + "_mask"]).to(d))
+    # raw projections in; ReLU and the diagonal are applied inside the kernel (and chained in its backward)
+    y = ops.fused_attention(x1 @ W.t(), x2 @ W.t(), x2 if x3 is None else x3, T(z[tag + "_mask"]).to(d), diag=diag, relu=True)
     assert maxerr(y, T(z[tag + "_y"])) < 1e-5 * max(1.0, float(np.abs(z[tag + "_y"]).max()))
     y.backward(T(z[tag + "_gy"]).to(d))
     ops.nan_flag.check_and_clear()

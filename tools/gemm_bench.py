@@ -15,17 +15,20 @@ ap.add_argument("--rows", type=int, default=42880)
 ap.add_argument("--dtype", default="fp16")
 ap.add_argument("--orders", default="0,4,8,16")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--variants", default="0,2")
 a = ap.parse_args()
 lib = hip.load()
 d = torch.device("cuda:0")
 dt = hip.PRECISION[a.dtype]
 td = hip.TORCH_DTYPE[dt]
-M = (a.rows + 127) // 128 * 128
+M = (a.rows + 255) // 256 * 256
 shapes = [("qkv", 2304, 768, hip.ACT_NONE, False), ("ao", 768, 768, hip.ACT_NONE, True), ("ff1", 3072, 768, hip.ACT_GELU, False),
           ("ff2", 768, 3072, hip.ACT_NONE, True)]
 g = torch.Generator(device="cpu").manual_seed(0)
-for order in [int(x) for x in a.orders.split(",")]:
+import itertools
+for variant, order in itertools.product([int(x) for x in a.variants.split(",")], [int(x) for x in a.orders.split(",")]):
     assert lib.ruart_gemm_set_tile_order(order) == 0
+    assert lib.ruart_gemm_set_variant(variant) == 0
     tot_t, tot_f = 0.0, 0.0
     line = []
     for name, N, K, act, res in shapes:
@@ -53,4 +56,4 @@ for order in [int(x) for x in a.orders.split(",")]:
         tot_t += us
         tot_f += fl
         line.append("%s %6.1f us %6.0f TF" % (name, us, fl / us / 1e6))
-    print("order %2d | %s | layer total %7.1f us  %6.0f TF/s" % (order, " | ".join(line), tot_t, tot_f / tot_t / 1e6), flush=True)
+    print("variant %d order %2d | %s | layer total %7.1f us  %6.0f TF/s" % (variant, order, " | ".join(line), tot_t, tot_f / tot_t / 1e6), flush=True)
