@@ -46,9 +46,10 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
                      void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
-/* Tuning knob: 0 (default) = 128x128 tile / 2 LDS stages, 1 = 256x128 tile / 3 stages with counted vmcnt (M % 256 == 0),
- * 2 = persistent 128x128 (next tile's first stage in flight during the epilogue).  Measured on the BERT shapes
- * (DESIGN.md section 5): 0 and 1 tie, 2 loses on K = 3072; all three are kept selectable for the next round's tuning. */
+/* Tile variant of ruart_gemm_16_nt: 0 = 128x128 tile / 2 LDS stages, 1 = 256x128 tile / 3 stages with counted vmcnt
+ * (M % 256 == 0), 2 = persistent 128x128, 3 (default) = 256x256 tile / 2 stages, one workgroup per CU (M, N % 256 == 0,
+ * else falls back to 0).  All variants sum in the same order and are bitwise identical (tools/gemm_check.py); measured
+ * rates per BERT shape are in DESIGN.md section 5. */
 int ruart_gemm_set_variant(int v);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,

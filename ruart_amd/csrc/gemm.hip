@@ -395,6 +395,109 @@ __global__ __launch_bounds__(512) void gemm_16_nt_256(const T16* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2 along M x 4 along N, 128x64 per wave = 8x4 MFMA tiles, 128 accumulator VGPRs), two LDS
+// stages of 64 KB, one workgroup per CU.  The 128x128 kernel is bound by how many bytes a CU can pull from L2 into LDS
+// per unit time (PMC: ~36 GB/s/CU, MFMA pipe 24 % busy); this tile needs HALF the bytes per flop (128 flop/B), so the same
+// byte rate feeds twice the MFMA work.  Same direct-to-LDS staging, source-side swizzle and fused epilogue.
+// ------------------------------------------------------------------------------------------------
+#define BM4 256
+#define BN4 256
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kTile = BM4 * BK * 2;            // 32 KB per operand tile
+  constexpr int kStage = 2 * kTile;              // 64 KB
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * kStage = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntn = N / BN4, ntm = M / BM4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+  const int m0 = tm * BM4, n0 = tn * BN4;
+
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
+  const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8;
+  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
+  auto stage = [&](int buf, int k0) {
+    char* base = smem + buf * kStage + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + kTile + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * kStage;
+    const char* sw = sa + kTile;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[4], af[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[j] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma_16x16x32(wf[i], af[j], acc[i][j]);
+    }
+  };
+
+  const int nt = K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt - 1; ++t) {
+    stage((t + 1) & 1, (t + 1) * BK);
+    compute(t & 1);
+    __syncthreads();
+  }
+  compute((nt - 1) & 1);
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + wm * 128 + j * 16 + fr;
+      f32x4_t v = acc[i][j] + bv;
+      if (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32 path: 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
 // ------------------------------------------------------------------------------------------------
 #define FBM 64
@@ -508,7 +611,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {
-  if (v < 0 || v > 2) return (int)hipErrorInvalidValue;
+  if (v < 0 || v > 3) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
@@ -542,13 +645,20 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
   return 0;
 }
 
-int g_gemm_variant = 0;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128
+int g_gemm_variant = 3;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128, 3: 256x256 2-stage (M, N % 256 == 0)
 int g_gemm_persist_blocks = 512; // persistent grid: 2 workgroups x 256 CUs
 
 template <typename T16, bool OF, int RS, int AC>
 static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr,
                        void* C, int ldc, int M, int N, int K, hipStream_t s) {
-  if (g_gemm_variant == 2) {
+  if (g_gemm_variant == 3 && M % BM4 == 0 && N % BN4 == 0) {
+    auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
+    constexpr int lds = 2 * 2 * BM4 * BK * 2;
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)done;
+    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       g_tile_order);
+  } else if (g_gemm_variant == 2) {
     const int ntiles = (M / BM) * (N / BN);
     int grid = g_gemm_persist_blocks < ntiles ? g_gemm_persist_blocks : ((ntiles + 7) / 8) * 8;
     hipLaunchKernelGGL((gemm_16_nt_128p<T16, OF, RS, AC>), dim3(grid), dim3(256), 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc,

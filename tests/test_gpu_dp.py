@@ -1,0 +1,64 @@
+"""The data-parallel code path on the real device: one NCCL (= RCCL) rank.  A single MI355X box cannot host two RCCL
+ranks, so this exercises process-group init on the device, the gradient hooks, bucketed asynchronous all-reduce on HIP
+streams and the averaged update - and checks that with world size 1 the step is bit-identical to the plain step.
+(The 2-rank logic is covered on CPU with gloo in test_dp_gloo.py; N = 2..8 are the driver's scaling runs.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ruart_amd import synth                       # noqa: E402
+from ruart_amd.arguments import default_opt        # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _make(opt, cfg, sw, dp):
+    from ruart_amd.trainer import SDNetTrainer
+    import torch.distributed as dist
+    tr = SDNetTrainer(opt, device="cuda:0", process_group=dist.group.WORLD if dp else None)
+    if not dp:
+        tr.process_group = None
+    tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    tr.network.load_state_dict({k: T(v) for k, v in sw.items()})
+    return tr
+
+
+def test_single_rank_nccl_step_equals_plain_step():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        opt = default_opt(vocab_size=1500, cuda=True, DROPOUT=0.0, dropout_emb=0.0)
+        cfg = synth.bert_config(vocab_size=2000)
+        opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=1033), cfg
+        sw = synth.make_sdnet_weights(opt, seed=1033)
+        batch = synth.synthetic_batch(opt, 3, seed=5, n_q=10, n_ocr=24, n_od=7, bert_vocab=2000, ragged=True)
+        plain = _make(opt, cfg, sw, dp=False)
+        assert plain.grad_sync is None
+        l0 = [plain.update(plain.ToCUDA(batch), i) for i in range(3)]
+        dp = _make(opt, cfg, sw, dp=True)
+        assert dp.grad_sync is not None and len(dp.grad_sync.buckets) >= 1
+        names = [n for b in dp.grad_sync.buckets for (n, _, _) in b]
+        assert not any(n.startswith("get_answer.rnn") for n in names)
+        l1 = [dp.update(dp.ToCUDA(batch), i) for i in range(3)]
+        assert l0 == l1, (l0, l1)
+        for (n, a), (_, b) in zip(plain.network.named_parameters(), dp.network.named_parameters()):
+            assert torch.equal(a, b), n
+        t = torch.ones(4, device="cuda:0")
+        dist.all_reduce(t)
+        dist.barrier()
+        assert float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()

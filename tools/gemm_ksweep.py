@@ -8,7 +8,7 @@ lib = hip.load()
 d = torch.device("cuda:0")
 dt, td = hip.DT_F16, torch.float16
 M = 42880 // 256 * 256
-for variant, N, K in itertools.product([0, 1], [768, 3072], [768, 1536, 3072, 6144]):
+for variant, N, K in itertools.product([0, 3], [768, 3072], [768, 3072]):
     lib.ruart_gemm_set_variant(variant)
     A = torch.randn(M, K, device=d).to(td)
     W = (torch.randn(N, K, device=d) * 0.05).to(td)
