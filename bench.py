@@ -11,7 +11,7 @@ averaged over ranks with RCCL.  A "step" is one such pass over one synthetic bat
 already resident in HBM when the timed region starts.  Weak scaling: B per GPU is fixed.
 
 Extra objects on the same line:
-  roofline     - the dominant kernel (gemm_16_nt_128, the 768x768 / 768x3072 BERT projections): algorithmic FLOPs
+  roofline     - the dominant kernel (gemm_16_nt_256sq, the 768x768 / 768x3072 BERT projections): algorithmic FLOPs
                  (2 * real_tokens * N * K per launch) / its HIP-event time measured live on the launch stream over a second
                  pass of the same K steps, against the 2.5 PFLOP/s dense 16-bit MFMA peak.
   cpu_baseline - the CPU oracle (oracle/ruart_oracle.py, kind "port": the reference cannot travel) timed on this box's
@@ -221,7 +221,7 @@ def main():
         lib.ruart_prof_enable(0)
         if n.value:
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_16_nt_128", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": "gemm_16_nt_256sq", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None, "launches": int(n.value),
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "gemm_share_of_step": round(ms.value / a.steps / (dt / a.steps * 1e3), 3)}

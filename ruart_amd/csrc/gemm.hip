@@ -35,12 +35,13 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r
 // output (>= 2.4e-4 relative) - at a third of erff's instruction count (the GELU epilogue runs on 3072-wide rows).
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));          // raw v_rcp_f32 (1 ulp), not an IEEE divide
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float r = 1.0f - p * t * __expf(-ax * ax);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);      // exp(-x^2) on v_exp_f32
+  const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)); }
@@ -474,25 +475,39 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
   }
   compute((nt - 1) & 1);
 
+  // Epilogue through LDS: the MFMA accumulator layout gives a lane 4 consecutive columns of 16 DIFFERENT rows, i.e. 64-byte
+  // pieces of 16 cache lines per store instruction (PMC/TA-bound: 5x the line touches of a row-wise store).  Each wave parks
+  // its 128x64 tile in its own 8.5 KB of the (now idle) staging memory, 32 rows at a time, and reads it back row-wise:
+  // one instruction then covers 4 whole rows x 256 B (fp32) / 128 B (16-bit) for the residual load and the store alike.
+  __syncthreads();                                   // every wave is done reading operand tiles
+  constexpr int ERS = 272;                           // 64 fp32 + 16 B pad: conflict-free for both the b128 writes and reads
+  char* my = smem + wave * (32 * ERS);               // 8.5 KB per wave, 32 rows per pass
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + wn * 64 + rcol;
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + fq * 4;
-    f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+  for (int hh = 0; hh < 4; ++hh) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + wm * 128 + j * 16 + fr;
-      f32x4_t v = acc[i][j] + bv;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = rr * 4 + rrow;
+      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
+      const int m = m0 + wm * 128 + hh * 32 + lr;
       if (ACT == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
       }
-      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
-      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
       if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
       else
-        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
     }
   }
 }
