@@ -513,6 +513,143 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256x256x64, "A in registers" pipeline: see the comment above the main loop.  Same tile, staging and epilogue as
+// gemm_16_nt_256sq; only the K loop differs.
+// ------------------------------------------------------------------------------------------------
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_16_nt_256ar(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kTile = BM4 * BK * 2;            // 32 KB per operand tile
+  constexpr int kStage = 2 * kTile;              // 64 KB
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * kStage = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntn = N / BN4, ntm = M / BM4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+  const int m0 = tm * BM4, n0 = tn * BN4;
+
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
+  const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8;
+  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
+
+  // staging split by operand: A tile (4 DMAs per wave) and W tile (4 DMAs per wave) are issued at different times
+  auto stage_a = [&](int buf, int k0) {
+    char* base = smem + buf * kStage + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
+  };
+  auto stage_w = [&](int buf, int k0) {
+    char* base = smem + buf * kStage + kTile + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+
+  // Pipeline ("A in registers"): at the top of K-tile t every wave pulls ALL its A fragments of the tile (16 x b128 = 64 VGPRs)
+  // into registers; after one barrier the A half of that LDS buffer is dead and is refilled with A(t+2) right away, while
+  // the MFMAs of tile t still run out of registers + the W half.  W(t+1) is issued at the very top of tile t.  So up to
+  // 96 KB of LDS-DMA are in flight per CU (A(t+1), W(t+1), A(t+2)) instead of 64 KB, with two LDS buffers only.
+  // Waits are counted: at the end of tile t only the 4 DMAs of A(t+2) may remain outstanding (vmcnt(4)); barriers are raw
+  // s_barrier so they do not drain the DMA queue.
+  const int nt = K / BK;
+  stage_a(0, 0);
+  stage_w(0, 0);
+  if (nt > 1) {
+    stage_a(1, BK);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const char* sa = smem + buf * kStage;
+    const char* sw = sa + kTile;
+    if (t + 1 < nt) stage_w(buf ^ 1, (t + 1) * BK);           // W half of the other buffer was released by the last barrier
+    frag_t af[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[ks][j] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fq));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // every wave holds its A fragments: A[buf] is dead
+    if (t + 2 < nt) stage_a(buf, (t + 2) * BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = mfma_16x16x32(wf[i], af[ks][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // tile t+1 is complete in LDS; W[buf] is dead
+  }
+
+  // Epilogue through LDS: the MFMA accumulator layout gives a lane 4 consecutive columns of 16 DIFFERENT rows, i.e. 64-byte
+  // pieces of 16 cache lines per store instruction (PMC/TA-bound: 5x the line touches of a row-wise store).  Each wave parks
+  // its 128x64 tile in its own 8.5 KB of the (now idle) staging memory, 32 rows at a time, and reads it back row-wise:
+  // one instruction then covers 4 whole rows x 256 B (fp32) / 128 B (16-bit) for the residual load and the store alike.
+  // (the loop's last barrier already guarantees every wave is done reading operand tiles)
+  constexpr int ERS = 272;                           // 64 fp32 + 16 B pad: conflict-free for both the b128 writes and reads
+  char* my = smem + wave * (32 * ERS);               // 8.5 KB per wave, 32 rows per pass
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + wn * 64 + rcol;
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = rr * 4 + rrow;
+      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
+      const int m = m0 + wm * 128 + hh * 32 + lr;
+      if (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32 path: 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
 // ------------------------------------------------------------------------------------------------
 #define FBM 64
@@ -626,7 +763,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {
-  if (v < 0 || v > 3) return (int)hipErrorInvalidValue;
+  if (v < 0 || v > 4) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
@@ -666,7 +803,14 @@ int g_gemm_persist_blocks = 512; // persistent grid: 2 workgroups x 256 CUs
 template <typename T16, bool OF, int RS, int AC>
 static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr,
                        void* C, int ldc, int M, int N, int K, hipStream_t s) {
-  if (g_gemm_variant == 3 && M % BM4 == 0 && N % BN4 == 0) {
+  if (g_gemm_variant == 4 && M % BM4 == 0 && N % BN4 == 0) {
+    auto kern = gemm_16_nt_256ar<T16, OF, RS, AC>;
+    constexpr int lds = 2 * 2 * BM4 * BK * 2;
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)done;
+    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       g_tile_order);
+  } else if (g_gemm_variant >= 3 && M % BM4 == 0 && N % BN4 == 0) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
     constexpr int lds = 2 * 2 * BM4 * BK * 2;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
