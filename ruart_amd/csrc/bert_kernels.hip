@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------------------------
-// MFMA flash attention for LONG sequences (one sequence per 64-query block; the (B, 512) north-star shape).
+// MFMA flash attention (16-bit modes): 64-query blocks of one long sequence (the (B, 512) north-star shape) AND windows of
+// several whole short sequences (one key tile, block-diagonal mask from tok_lo/tok_hi).
 // Everything is laid out "query on lane&15":
 //   S^T (keys x queries) = K . Q^T      A = K rows from LDS (ds_read_b128), B = Q fragments held in registers
 //   online softmax per query column: 16 scores per lane + two cross-lane-group shuffles
@@ -212,6 +213,7 @@ template <typename T16>
 __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
                                                          const int* __restrict__ bq0, const int* __restrict__ bq1,
                                                          const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                         const int* __restrict__ tok_lo, const int* __restrict__ tok_hi,
                                                          const float* __restrict__ key_bias) {
   constexpr int RS = 144;
   __shared__ __attribute__((aligned(16))) char Ks[64 * RS];
@@ -223,6 +225,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
   const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
   const int tq = q0 + wave * 16 + fr;
   const bool qvalid = tq < q1;
+  // this lane's query attends to keys [lo, hi): its own sequence.  A block is either 64 queries of one long sequence
+  // (lo, hi = the whole sequence) or a window of several whole short sequences (block-diagonal mask).
+  const int lo = qvalid ? tok_lo[tq] : 0, hi = qvalid ? tok_hi[tq] : 0;
 
   frag_t qf[2];
   {
@@ -273,10 +278,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
     for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = it * 16 + g * 4 + r;
+        const int j = kt + it * 16 + g * 4 + r;
+        const bool ok = j >= lo && j < hi;
         float v = sacc[it][r];
-        if (key_bias && j < tn) v += key_bias[kt + j];
-        v = (j < tn) ? v : -1e30f;
+        if (key_bias && ok) v += key_bias[j];
+        v = ok ? v : -1e30f;
         sacc[it][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
     for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = it * 16 + g * 4 + r;
-        const float p = (j < tn) ? __expf(sacc[it][r] - mn) : 0.f;
+        const int j = kt + it * 16 + g * 4 + r;
+        const float p = (j >= lo && j < hi) ? __expf(sacc[it][r] - mn) : 0.f;
         sacc[it][r] = p;
         rs += p;
       }
@@ -469,22 +475,24 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
                                     const int* lblk_q0, const int* lblk_q1, const int* lblk_k0, const int* lblk_k1, void* stream) {
   if (n_heads * 64 != H || n_blocks < 0 || n_long_blocks < 0 || n_blocks + n_long_blocks <= 0) return (int)hipErrorInvalidValue;
   if (n_long_blocks > 0 && dtype == RUART_DT_F32) return (int)hipErrorInvalidValue;   // the MFMA kernel is 16-bit only
-  if (n_blocks > 0) {
-    const dim3 grid(n_blocks, n_heads), block(64);
-    if (dtype == RUART_DT_BF16)
-      hipLaunchKernelGGL(attn_varlen_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-    else if (dtype == RUART_DT_F16)
-      hipLaunchKernelGGL(attn_varlen_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-    else
-      hipLaunchKernelGGL(attn_varlen_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
-    RUART_CHECK_LAUNCH();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RUART_DT_F32) {
+    if (n_blocks > 0) {
+      hipLaunchKernelGGL(attn_varlen_kernel<float>, dim3(n_blocks, n_heads), dim3(64), 0, st, (const float*)qkv, ld, (float*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias);
+      RUART_CHECK_LAUNCH();
+    }
+    return 0;
   }
-  if (n_long_blocks > 0) {
-    const dim3 grid(n_long_blocks, n_heads), block(256);
+  // 16-bit: the MFMA kernel serves both block kinds (short windows are a one-tile call with a block-diagonal mask)
+  for (int kind = 0; kind < 2; ++kind) {
+    const int nb = kind ? n_long_blocks : n_blocks;
+    if (nb <= 0) continue;
+    const int *a0 = kind ? lblk_q0 : blk_q0, *a1 = kind ? lblk_q1 : blk_q1, *a2 = kind ? lblk_k0 : blk_k0, *a3 = kind ? lblk_k1 : blk_k1;
+    const dim3 grid(nb, n_heads), block(256);
     if (dtype == RUART_DT_BF16)
-      hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+      hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, a0, a1, a2, a3, tok_lo, tok_hi, key_bias);
     else
-      hipLaunchKernelGGL(attn_flash_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+      hipLaunchKernelGGL(attn_flash_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, a0, a1, a2, a3, tok_lo, tok_hi, key_bias);
     RUART_CHECK_LAUNCH();
   }
   return 0;

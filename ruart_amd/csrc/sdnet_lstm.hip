@@ -48,21 +48,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const float* __restrict__
       pre = fmaf(w[j], hv[0], pre); pre = fmaf(w[j + 1], hv[1], pre);
       pre = fmaf(w[j + 2], hv[2], pre); pre = fmaf(w[j + 3], hv[3], pre);
     }
-    if (row) pre_s[g] = pre;
+    // every gate row applies its own activation (one v_exp per thread, no divergence: tanh(x) = 2 sigmoid(2x) - 1), so the
+    // serial combine below is left with a single tanh per hidden unit
+    const size_t o = ((size_t)b * T + t);
+    if (row) {
+      const bool is_g = (g >= 2 * h) && (g < 3 * h);
+      const float sg = 1.0f / (1.0f + __expf(is_g ? -2.0f * pre : -pre));
+      const float a = is_g ? 2.0f * sg - 1.0f : sg;
+      pre_s[g] = a;
+      if (gates) gates[o * ldx + (size_t)d * G + g] = a;
+    }
     __syncthreads();
     if (g < h) {
-      const float ig = sigmoidf_(pre_s[g]), fg = sigmoidf_(pre_s[h + g]);
-      const float gg = tanhf(pre_s[2 * h + g]), og = sigmoidf_(pre_s[3 * h + g]);
+      const float ig = pre_s[g], fg = pre_s[h + g], gg = pre_s[2 * h + g], og = pre_s[3 * h + g];
       c = fg * c + ig * gg;
-      const float hh = og * tanhf(c);
+      const float tc = 2.0f / (1.0f + __expf(-2.0f * c)) - 1.0f;
+      const float hh = og * tc;
       h_s[g] = hh;
-      const size_t o = ((size_t)b * T + t);
       y[o * ldy + (size_t)d * h + g] = hh;
       bad |= !(hh == hh);
-      if (gates) {
-        float* gp = gates + o * ldx + (size_t)d * G + g;
-        gp[0] = ig; gp[h] = fg; gp[2 * h] = gg; gp[3 * h] = og;
-      }
       if (cells) cells[o * ldy + (size_t)d * h + g] = c;
     }
     __syncthreads();
