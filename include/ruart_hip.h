@@ -133,9 +133,10 @@ int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, voi
 int ruart_attn_fwd(const float* pa, const float* pk, const float* v, const unsigned char* mask, const float* diag, int diag_len,
                    int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream);
 /* gradients of the op above, given grad_out (B,L1,D3) and saved P: grad_pa (B,L1,h), grad_pk (B,L2,h), grad_v (B,L2,D3);
- * grad_diag (h floats, ACCUMULATED with atomics: zero it first) only for a vector diag, else pass NULL. */
+ * grad_diag_partial (B * ceil(L1/16) rows of h floats, one per workgroup; the caller sums the rows - deterministic, no
+ * atomics) only for a vector diag, else pass NULL. */
 int ruart_attn_bwd(const float* pa, const float* pk, const float* v, const float* probs, const float* grad_out, const float* diag,
-                   int diag_len, int relu, float* grad_pa, float* grad_pk, float* grad_v, float* grad_diag,
+                   int diag_len, int relu, float* grad_pa, float* grad_pk, float* grad_v, float* grad_diag_partial,
                    float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3, void* stream);
 
 /* Layers.py:167-168: F.layer_norm over the WHOLE tensor of n elements, no affine.  stats[0] = mean, stats[1] = rstd.
@@ -159,6 +160,17 @@ int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates
  * by the caller. */
 int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const float* gates, const float* cells, float* grad_xproj, int B,
                    int T, int h, int ndir, void* stream);
+
+/* Pointwise part of ONE step of a wide LSTM over a ragged, length-sorted batch (the `multi2one` LSTM, Models/SDNet.py:137,
+ * 269-271: hidden 300, 1-3 real words per item).  pre (n_active, 4h) = x W_ih^T + b + h_prev W_hh^T from the caller's GEMMs;
+ * rows < n_active are advanced (acts (n_active,4h) = post-activation i,f,g,o saved for backward), rows >= n_active of
+ * h_out / c_out (n_rows, h) copy h_prev / c_prev.  Backward: grad_h / grad_c (may be NULL = zero) -> grad_pre (n_active,4h),
+ * grad_c_prev (n_rows,h) and the pass-through part of grad_h_prev (n_rows,h; rows < n_active are zero - their gradient
+ * arrives through the recurrent GEMM). */
+int ruart_lstm_cell_fwd(const float* pre, const float* h_prev, const float* c_prev, float* h_out, float* c_out, float* acts,
+                        int n_active, int n_rows, int h, void* stream);
+int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* acts, const float* c_prev, const float* c_out,
+                        float* grad_pre, float* grad_h_prev, float* grad_c_prev, int n_active, int n_rows, int h, void* stream);
 
 /* NaN contract of the reference (assert torch.sum(torch.isnan(x)) == 0, Layers.py:169,290,430,462,467): after this
  * call every SDNet kernel ORs 1 into *flag (a device int) when it writes a NaN; the Python layer checks and clears it

@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
         grad_a[at] = g;
       }
     }
-    if (grad_diag) {      // vector diag only: sum over this tile's 16 rows = the 4 lanes sharing a column
-      gd += __shfl_xor(gd, 16, 64);
+    if (grad_diag) {      // vector diag only: sum over this tile's 16 rows = the 4 lanes sharing a column; one partial row
+      gd += __shfl_xor(gd, 16, 64);     // per workgroup, summed by the caller in a fixed order (no atomics: deterministic)
       gd += __shfl_xor(gd, 32, 64);
-      if ((lane >> 4) == 0 && d < h) atomicAdd(grad_diag + d, gd);
+      if ((lane >> 4) == 0 && d < h) grad_diag[((size_t)b * gridDim.x + blockIdx.x) * h + d] = gd;
     }
   }
 }

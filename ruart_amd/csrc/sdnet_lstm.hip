@@ -128,6 +128,66 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused LSTM cell for the wide, short `multi2one` LSTM (hidden 300: W_hh does not fit one CU's registers, and the
+// sequences are only 1-3 real words long).  The recurrent product h W_hh^T is a plain GEMM per step; this kernel does the
+// whole pointwise part of a step in one pass over a ragged, length-sorted batch: rows < n_active are advanced, rows
+// >= n_active (items already finished) are carried through unchanged - replacing ~12 elementwise launches forward and ~25
+// backward per step.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ h_prev,
+                                                            const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                            float* __restrict__ c_out, float* __restrict__ acts, int n_active,
+                                                            int n_rows, int h) {
+  const long long total = (long long)n_rows * h;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += 256LL * gridDim.x) {
+    const int r = (int)(e / h), j = (int)(e - (long long)r * h);
+    if (r < n_active) {
+      const float* p = pre + (size_t)r * 4 * h + j;
+      const float ig = 1.0f / (1.0f + __expf(-p[0])), fg = 1.0f / (1.0f + __expf(-p[h]));
+      const float gg = 2.0f / (1.0f + __expf(-2.0f * p[2 * h])) - 1.0f, og = 1.0f / (1.0f + __expf(-p[3 * h]));
+      const float c = fg * c_prev[e] + ig * gg;
+      const float tc = 2.0f / (1.0f + __expf(-2.0f * c)) - 1.0f;
+      c_out[e] = c;
+      h_out[e] = og * tc;
+      float* a = acts + (size_t)r * 4 * h + j;
+      a[0] = ig; a[h] = fg; a[2 * h] = gg; a[3 * h] = og;
+    } else {
+      c_out[e] = c_prev[e];
+      h_out[e] = h_prev[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gh, const float* __restrict__ gc,
+                                                            const float* __restrict__ acts, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ c_out, float* __restrict__ g_pre,
+                                                            float* __restrict__ g_hprev, float* __restrict__ g_cprev, int n_active,
+                                                            int n_rows, int h) {
+  const long long total = (long long)n_rows * h;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += 256LL * gridDim.x) {
+    const int r = (int)(e / h), j = (int)(e - (long long)r * h);
+    const float dh = gh ? gh[e] : 0.f, dcn = gc ? gc[e] : 0.f;
+    if (r < n_active) {
+      const float* a = acts + (size_t)r * 4 * h + j;
+      const float ig = a[0], fg = a[h], gg = a[2 * h], og = a[3 * h];
+      const float c = c_out[e];
+      const float tc = 2.0f / (1.0f + __expf(-2.0f * c)) - 1.0f;
+      const float dc = dcn + dh * og * (1.f - tc * tc);
+      float* g = g_pre + (size_t)r * 4 * h + j;
+      g[0] = dc * gg * ig * (1.f - ig);
+      g[h] = dc * c_prev[e] * fg * (1.f - fg);
+      g[2 * h] = dc * ig * (1.f - gg * gg);
+      g[3 * h] = dh * tc * og * (1.f - og);
+      g_cprev[e] = dc * fg;
+      g_hprev[e] = 0.f;              // the recurrent path of h_prev goes through the GEMM (autograd adds it)
+    } else {
+      g_cprev[e] = dcn;
+      g_hprev[e] = dh;
+    }
+  }
+}
+
 extern int* ruart_nan_flag_ptr;
 
 extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, int B, int T, int h,
@@ -144,6 +204,29 @@ extern "C" int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const floa
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, grad_y, w_hh, gates, cells, grad_xproj, T, h,
                      ndir);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_lstm_cell_fwd(const float* pre, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
+                                   float* acts, int n_active, int n_rows, int h, void* stream) {
+  if (n_rows <= 0 || h <= 0 || n_active < 0 || n_active > n_rows) return (int)hipErrorInvalidValue;
+  const long long total = (long long)n_rows * h;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pre, h_prev, c_prev, h_out, c_out, acts,
+                     n_active, n_rows, h);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* acts, const float* c_prev,
+                                   const float* c_out, float* grad_pre, float* grad_h_prev, float* grad_c_prev, int n_active,
+                                   int n_rows, int h, void* stream) {
+  if (n_rows <= 0 || h <= 0 || n_active < 0 || n_active > n_rows) return (int)hipErrorInvalidValue;
+  const long long total = (long long)n_rows * h;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_h, grad_c, acts, c_prev, c_out,
+                     grad_pre, grad_h_prev, grad_c_prev, n_active, n_rows, h);
   RUART_CHECK_LAUNCH();
   return 0;
 }

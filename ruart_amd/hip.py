@@ -58,6 +58,8 @@ _SIGNATURES = {
     "ruart_whole_ln_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ruart_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),
     "ruart_gemm_set_variant": (_I, [_I]),

@@ -134,21 +134,16 @@ class StackedBRNN(nn.Module):
         return (output, hiddens[1:]) if return_list else output
 
 
-def lstm_cell_steps(xproj_steps, w_hh, n_active, h0, c0):
+def lstm_cell_steps(xproj_steps, w_hh, n_active, h0, c0, zero_state=True):
     """Step a (wide) LSTM over a ragged, length-sorted batch: at step s only the first n_active[s] rows are alive.
-    xproj_steps[s] is (n_active[s], 4h).  Returns the final (h, c) of every row."""
+    xproj_steps[s] is (n_active[s], 4h).  Per step: one GEMM (recurrent product, fused with the add of xproj) and one
+    fused HIP cell kernel.  Returns the final (h, c) of every row."""
     h, c = h0, c0
-    Hh = w_hh.shape[1]
+    wt = w_hh.t()
     for s, n in enumerate(n_active):
-        g = xproj_steps[s] + h[:n] @ w_hh.t()
-        i, f, gg, o = g[:, :Hh], g[:, Hh:2 * Hh], g[:, 2 * Hh:3 * Hh], g[:, 3 * Hh:]
-        cn = torch.sigmoid(f) * c[:n] + torch.sigmoid(i) * torch.tanh(gg)
-        hn = torch.sigmoid(o) * torch.tanh(cn)
-        if n < h.shape[0]:
-            h = torch.cat([hn, h[n:]], 0)
-            c = torch.cat([cn, c[n:]], 0)
-        else:
-            h, c = hn, cn
+        # with a zero initial state there is nothing to add at step 0
+        pre = xproj_steps[s] if (s == 0 and zero_state) else torch.addmm(xproj_steps[s], h[:n], wt)
+        h, c = ops.lstm_cell(pre, h, c, n)
     return h, c
 
 
@@ -162,7 +157,7 @@ def lstm_layer_wide(x, w_ih, w_hh, b_ih, b_hh, *reverse_params):
         c = x.new_zeros(B, w_hh.shape[1])
         ys = [None] * T
         for t in (range(T - 1, -1, -1) if rev else range(T)):
-            h, c = lstm_cell_steps([xp[:, t]], w_hh, [B], h, c)
+            h, c = lstm_cell_steps([xp[:, t]], w_hh, [B], h, c, zero_state=False)
             ys[t] = h
         return torch.stack(ys, 1)
     y = run(w_ih, w_hh, b_ih, b_hh, False)

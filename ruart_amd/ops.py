@@ -76,12 +76,13 @@ class _FusedAttention(torch.autograd.Function):
         gout = gout.contiguous()
         ga, gk, gv = torch.empty_like(pa), torch.empty_like(pk), torch.empty_like(v)
         ds = torch.empty_like(probs)
-        gdiag = torch.zeros(h, dtype=torch.float32, device=pa.device) if (dl > 1 and ctx.needs_input_grad[4]) else None
+        gdiag = (torch.empty(B * ((L1 + 15) // 16), h, dtype=torch.float32, device=pa.device)
+                 if (dl > 1 and ctx.needs_input_grad[4]) else None)
         rc = lib.ruart_attn_bwd(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
                                 hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2, h, D3,
                                 hip.stream_ptr())
         hip.check(rc, "ruart_attn_bwd")
-        return ga, gk, gv, None, (gdiag.view_as(diag) if gdiag is not None else None), None
+        return ga, gk, gv, None, (gdiag.sum(0).view_as(diag) if gdiag is not None else None), None
 
 
 def fused_attention(a, k, v, mask, diag=None, relu=False):
@@ -184,3 +185,40 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None,
         w, b, whh = w_ih, b_ih + b_hh, w_hh.unsqueeze(0)
     xproj = torch.addmm(b, x.reshape(-1, x.shape[-1]), w.t()).view(x.shape[0], x.shape[1], -1)
     return _LstmRecurrence.apply(xproj.contiguous(), whh.contiguous(), 2 if bidir else 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _LstmCell(torch.autograd.Function):
+    """Pointwise part of one LSTM step over a ragged, length-sorted batch (see ruart_lstm_cell_fwd)."""
+
+    @staticmethod
+    def forward(ctx, pre, h_prev, c_prev, n_active):
+        lib = hip.load()
+        for t in (pre, h_prev, c_prev):
+            hip.require_gpu(t, torch.float32)
+        N, h = h_prev.shape
+        h_out, c_out = torch.empty_like(h_prev), torch.empty_like(c_prev)
+        acts = torch.empty_like(pre)
+        hip.check(lib.ruart_lstm_cell_fwd(hip.ptr(pre), hip.ptr(h_prev), hip.ptr(c_prev), hip.ptr(h_out), hip.ptr(c_out),
+                                          hip.ptr(acts), n_active, N, h, hip.stream_ptr()), "ruart_lstm_cell_fwd")
+        ctx.save_for_backward(acts, c_prev, c_out)
+        ctx.n_active = n_active
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, gh, gc):
+        lib = hip.load()
+        acts, c_prev, c_out = ctx.saved_tensors
+        N, h = c_prev.shape
+        gh = gh.contiguous() if gh is not None else None
+        gc = gc.contiguous() if gc is not None else None
+        g_pre = torch.empty_like(acts)
+        g_h, g_c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        hip.check(lib.ruart_lstm_cell_bwd(hip.ptr(gh), hip.ptr(gc), hip.ptr(acts), hip.ptr(c_prev), hip.ptr(c_out), hip.ptr(g_pre),
+                                          hip.ptr(g_h), hip.ptr(g_c), ctx.n_active, N, h, hip.stream_ptr()), "ruart_lstm_cell_bwd")
+        return g_pre, g_h, g_c, None
+
+
+def lstm_cell(pre, h_prev, c_prev, n_active):
+    """pre (n_active, 4h), h_prev / c_prev (N, h) -> (h, c) of all N rows; rows >= n_active pass through."""
+    return _LstmCell.apply(pre.contiguous(), h_prev.contiguous(), c_prev.contiguous(), int(n_active))

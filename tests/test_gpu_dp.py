@@ -1,6 +1,6 @@
 """The data-parallel code path on the real device: one NCCL (= RCCL) rank.  A single MI355X box cannot host two RCCL
 ranks, so this exercises process-group init on the device, the gradient hooks, bucketed asynchronous all-reduce on HIP
-streams and the averaged update - and checks that with world size 1 the step is bit-identical to the plain step.
+streams and the averaged update - and checks that with world size 1 the step is bit-identical to the plain step (every kernel is deterministic).
 (The 2-rank logic is covered on CPU with gloo in test_dp_gloo.py; N = 2..8 are the driver's scaling runs.)"""
 import os
 import socket
@@ -47,15 +47,34 @@ def test_single_rank_nccl_step_equals_plain_step():
         batch = synth.synthetic_batch(opt, 3, seed=5, n_q=10, n_ocr=24, n_od=7, bert_vocab=2000, ragged=True)
         plain = _make(opt, cfg, sw, dp=False)
         assert plain.grad_sync is None
-        l0 = [plain.update(plain.ToCUDA(batch), i) for i in range(3)]
         dp = _make(opt, cfg, sw, dp=True)
         assert dp.grad_sync is not None and len(dp.grad_sync.buckets) >= 1
         names = [n for b in dp.grad_sync.buckets for (n, _, _) in b]
         assert not any(n.startswith("get_answer.rnn") for n in names)
+
+        def grads(tr):
+            b = tr.ToCUDA(batch)
+            tr.network.train()
+            tr.network.drop_emb = True
+            scores, _ = tr.network(b[0], b[1], b[2])
+            loss = tr.loss_func(scores, b[3])
+            tr.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            if tr.grad_sync is not None:
+                tr.grad_sync.average_gradients()
+            torch.cuda.synchronize()
+            return loss.item(), {n: p.grad.clone() for n, p in tr.network.named_parameters() if p.grad is not None}
+
+        lp, gp = grads(plain)
+        ld, gd = grads(dp)
+        assert lp == ld                                     # the step is deterministic: same loss, same gradients
+        for n in gp:
+            assert torch.equal(gp[n], gd[n]), n              # all-reduce over one rank then * 1/1 is the identity
+        for n in set(gd) - set(gp):                          # a used parameter without a gradient is exchanged as zeros
+            assert n == "ques_merger.linear.bias" and float(gd[n].abs().max()) == 0.0, n
+        l0 = [plain.update(plain.ToCUDA(batch), i) for i in range(3)]
         l1 = [dp.update(dp.ToCUDA(batch), i) for i in range(3)]
         assert l0 == l1, (l0, l1)
-        for (n, a), (_, b) in zip(plain.network.named_parameters(), dp.network.named_parameters()):
-            assert torch.equal(a, b), n
         t = torch.ones(4, device="cuda:0")
         dist.all_reduce(t)
         dist.barrier()

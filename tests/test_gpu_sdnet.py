@@ -131,3 +131,90 @@ def test_no_cpu_fallback():
     from ruart_amd import hip, ops
     with pytest.raises(hip.HipError):
         ops.fused_attention(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), torch.ones(1, 2))
+
+
+def test_full_size_properties():
+    """BASELINE.json's full per-GPU shape (B=64, q=30, 100 OCR items, 36 objects, bert-base): too big for the CPU oracle in a
+    test, so parity is checked through size-independent properties:
+      * every score row is a probability vector; nothing is NaN;
+      * batch-permutation equivariance: samples only interact through the whole-tensor layer-norm statistics, which are
+        permutation invariant - permuting the samples must permute the score rows (up to fp32 summation order);
+      * packing invariance: dropping padded word-piece slots (pack=True) vs keeping them with the reference's -10000 mask;
+      * the f16 production path against the exact-fp32 validation path at full size: mean, 99th percentile, worst case."""
+    from ruart_amd.sdnet import SDNet
+    import ruart_amd.layers as L
+    dev = "cuda:0"
+    cfg = synth.bert_config(vocab_size=3000)
+    bw = synth.make_bert_weights(cfg, seed=21)
+    B = 64
+
+    def make(precision, **extra):
+        opt = default_opt(vocab_size=2000, cuda=True, device=dev, bert_precision=precision, max_od_num=36, **extra)
+        opt["bert_state"], opt["bert_config"] = bw, cfg
+        sw = synth.make_sdnet_weights(opt, seed=21)
+        net = SDNet(opt, {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+        net.load_state_dict({k: T(v) for k, v in sw.items()})
+        net.to(dev).eval()
+        net.drop_emb = False
+        return net, opt
+
+    net32, opt = make("fp32")
+    batch = synth.synthetic_batch(opt, B, seed=31, n_q=30, n_ocr=100, n_od=36, bert_vocab=3000, ragged=True)
+
+    def run(net, b):
+        q, ocr, od = [dict(x) for x in b[:3]]
+        q.pop("_ruart_index", None)
+        with torch.no_grad():
+            s, _ = net(q, ocr, od)
+        net.check_nan()
+        return s.float().cpu()
+
+    s32 = run(net32, batch)
+    assert s32.shape == (B, opt["max_ocr_num"] + 1) and torch.isfinite(s32).all()
+    assert float((s32.sum(1) - 1).abs().max()) < 1e-5
+    # masked answer slots (beyond the sample's items) carry exactly zero probability
+    for b in range(B):
+        n = batch[1]["num_cnt"][b]
+        assert n == 100 or float(s32[b, n:-1].abs().max()) == 0.0
+
+    # ---- batch permutation (exact-fp32 path: only fp32 reduction orders move) -------------------------------
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).tolist()
+
+    def permute_items(d, perm):
+        starts = np.concatenate([[0], np.cumsum(d["num_cnt"])])
+        rows = np.concatenate([np.arange(starts[p], starts[p + 1]) for p in perm])
+        out = {}
+        for k, v in d.items():
+            if k in ("num_cnt", "len_cnt"):
+                out[k] = [v[p] for p in perm]
+            elif k == "position":
+                out[k] = v[perm]
+            elif isinstance(v, torch.Tensor):
+                out[k] = v[rows]
+            else:
+                out[k] = [v[r] for r in rows]
+        return out
+
+    q, ocr, od = batch[:3]
+    qp = {k: (v[perm] if isinstance(v, torch.Tensor) else [v[p] for p in perm]) for k, v in q.items() if k != "_ruart_index"}
+    pbatch = (qp, permute_items(ocr, perm), permute_items(od, perm))
+    sp = run(net32, pbatch)
+    assert float((sp - s32[perm]).abs().max()) < 5e-5
+    # ---- packing invariance: dropped padding vs the reference's -10000 mask ----------------------------------
+    net32_np, _ = make("fp32", bert_no_pack=True)
+    s_np = run(net32_np, batch)
+    assert float((s_np - s32).abs().max()) < 5e-5
+    del net32_np, net32
+
+    # ---- the f16 production path against the exact-fp32 path at full size -----------------------------------
+    net16, _ = make("fp16")
+    s16 = run(net16, batch)
+    d16 = (s16 - s32).abs()
+    perm_noise = float((run(net16, pbatch) - s16[perm]).abs().max())
+    frac = float((d16 > 1e-3).float().mean())
+    print("full size: max |p_f16 - p_fp32| = %.2e, mean %.2e, fraction of the %d outputs above 1e-3: %.1e; "
+          "f16 packing-order noise %.2e" % (float(d16.max()), float(d16.mean()), d16.numel(), frac, perm_noise))
+    # Statistical bound of the 16-bit path at full size (DESIGN.md section 2): 16-bit MFMA operands cannot hold a hard 1e-3 on
+    # every one of 6 464 outputs of this random-weight model (the trunk amplifies BERT feature noise ~10x); the exact
+    # fp32 mode does.  Mean error, the 99th percentile and the worst case are pinned here.
+    assert float(d16.mean()) < 1e-4 and frac < 0.02 and float(d16.max()) < 2e-2
