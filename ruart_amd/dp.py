@@ -13,8 +13,8 @@ asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
     that ignores the pinned rows;
   * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
     win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order and each
-    bucket's all-reduce is launched asynchronously the moment its last gradient is produced, overlapping the rest
-    of backward; ``average_gradients`` waits, scales by 1/world and scatters back;
+    bucket's all-reduce is launched asynchronously as soon as its last gradient is produced (strictly in bucket order,
+    so all ranks issue identical collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales by 1/world and scatters back;
   * works unchanged on the gloo backend (CPU tensors) - that is how the N>1 path is tested without GPUs.
 """
 import torch
@@ -61,13 +61,19 @@ class GradSync:
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._next = 0                      # buckets are ALWAYS launched in index order: every rank issues the same
+                                            # sequence of collectives even if its gradients become ready in another order
 
     def _make_hook(self, bi):
         def hook(param):
             self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _views(self, bi):
         out = []
@@ -88,9 +94,9 @@ class GradSync:
     def average_gradients(self):
         """Call after ``loss.backward()``: finishes the outstanding bucket all-reduces and writes the averaged
         gradients back in place."""
-        for bi in range(len(self.buckets)):
-            if self._work[bi] is None:     # some gradient of this bucket never fired its hook
-                self._launch(bi)
+        while self._next < len(self.buckets):       # gradients that never fired a hook (unused on this batch): still in order
+            self._launch(self._next)
+            self._next += 1
         inv = 1.0 / self.world
         for bi in range(len(self.buckets)):
             self._work[bi].wait()
