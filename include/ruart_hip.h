@@ -129,7 +129,7 @@ int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, voi
 /* Layers.py:228-231 + :244 + :275-288: for each batch b, with pa = x1 W^T (B,L1,h) and pk = x2 W^T (B,L2,h) from the caller,
  *   a = act(pa) * diag,  k = act(pk)      act = ReLU when relu != 0; diag_len 0: no diag, 1: one scalar, h: per column
  *   S = a . k^T;  S[:, j] = -inf where mask[b][j] == 0;  P = softmax_j(S);  out = P . v[b]  (v: (B,L2,D3))
- * P (B, L1, L2) is saved for backward when probs != NULL.  fp32. */
+ * P (B, L1, L2) is saved for backward when probs != NULL.  fp32.  L2 <= 384 (the key/value panel lives in LDS). */
 int ruart_attn_fwd(const float* pa, const float* pk, const float* v, const unsigned char* mask, const float* diag, int diag_len,
                    int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream);
 /* gradients of the op above, given grad_out (B,L1,D3) and saved P: grad_pa (B,L1,h), grad_pk (B,L2,h), grad_v (B,L2,D3);

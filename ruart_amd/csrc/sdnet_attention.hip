@@ -21,6 +21,8 @@
 #define CH 64          // chunk of the contraction / output dimension staged per pass
 #define LDA_ 66        // A-type stride for a 64-wide chunk   (66 % 32 == 2)
 #define LDB_ 80        // B-type stride for a 64-wide chunk   (80 % 32 == 16)
+#define NTW 6          // key tiles of 16 per wave: 4 waves x 6 x 16 = up to 384 keys
+#define ATTN_MAX_L2 384
 
 int* ruart_nan_flag_ptr = nullptr;   // host copy of the device flag address, passed to kernels as an argument
 
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const int ntile = L2p / 16;
 
   // ---- scores: S[16][L2p] = a_tile . k^T, accumulated over chunks of h
-  f32x4_t acc[4];
+  f32x4_t acc[NTW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTW; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < h; c0 += CH) {
     __syncthreads();
     stage(a_s, LDA_, 16, ab, h, i0, L1, c0, h, Act{relu, diag, diag_len});
@@ -95,13 +97,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     __syncthreads();
     const int kc = min(CH, (h - c0 + 3) & ~3);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTW; ++t) {
       const int jt = wave + 4 * t;
       if (jt < ntile) acc[t] = mma16(a_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const int jt = wave + 4 * t;
     if (jt < ntile) {
 #pragma unroll
@@ -176,9 +178,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   const float* gb = gout + (size_t)b * L1 * D3;
   const int ntile = L2p / 16;
 
-  f32x4_t acc[4];
+  f32x4_t acc[NTW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTW; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < D3; c0 += CH) {     // dP = gO . v^T
     __syncthreads();
     stage(g_s, LDA_, 16, gb, D3, i0, L1, c0, D3);
@@ -186,13 +188,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     __syncthreads();
     const int kc = min(CH, (D3 - c0 + 3) & ~3);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTW; ++t) {
       const int jt = wave + 4 * t;
       if (jt < ntile) acc[t] = mma16(g_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const int jt = wave + 4 * t;
     if (jt < ntile) {
 #pragma unroll
@@ -360,6 +362,12 @@ __global__ __launch_bounds__(256) void wln_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+static void attn_allow_big_lds() {
+  static bool done = (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)done;
+}
+
 static size_t attn_lds_bytes(int L2) {
   const int L2p = (L2 + 15) & ~15;
   const int ldS = ((L2p + 31) / 32) * 32 + 2;
@@ -368,9 +376,10 @@ static size_t attn_lds_bytes(int L2) {
 
 extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
                               int diag_len, int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream) {
-  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
   const dim3 grid(ceil_div(L1, 16), B), block(256);
+  attn_allow_big_lds();
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
                      ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len);
   RUART_CHECK_LAUNCH();
@@ -380,10 +389,11 @@ extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, co
 extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
                               const float* diag, int diag_len, int relu, float* grad_a, float* grad_k, float* grad_v,
                               float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream) {
-  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > 256 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
+  if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
   const bool act = relu || diag_len;
   const float* dg = diag_len ? diag : nullptr;
+  attn_allow_big_lds();
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
                      grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,
                      (diag_len > 1) ? grad_diag : nullptr);

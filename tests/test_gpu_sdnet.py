@@ -218,3 +218,31 @@ def test_full_size_properties():
     # every one of 6 464 outputs of this random-weight model (the trunk amplifies BERT feature noise ~10x); the exact
     # fp32 mode does.  Mean error, the 99th percentile and the worst case are pinned here.
     assert float(d16.mean()) < 1e-4 and frac < 0.02 and float(d16.max()) < 2e-2
+
+
+def test_stress_config_bert_large_and_edge_batches():
+    """BASELINE config 4 shapes (300 OCR items, 100 objects, bert-large 24 x 1024) run through the same path, and a degenerate
+    batch (B=1, one object) does too.  Functional check: finite probabilities that sum to 1, gradients flow."""
+    from ruart_amd.sdnet import SDNet
+    import ruart_amd.layers as L
+    dev = "cuda:0"
+    L.set_dropout_prob(0.0)
+    cfg = synth.bert_config(vocab_size=1200, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    opt = default_opt(vocab_size=800, cuda=True, device=dev, BERT_LARGE=True, max_ocr_num=300, max_od_num=100,
+                      BERT_large_model_file="unused")
+    opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=2, w_std=0.03), cfg
+    sw = synth.make_sdnet_weights(opt, seed=2)
+    assert sw["alphaBERT"].shape == (24,) and sw["multi2one.rnns.0.weight_ih_l0"].shape[1] == 300 + 1024 + 12 + 8 + 300
+    net = SDNet(opt, {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    net.load_state_dict({k: T(v) for k, v in sw.items()})
+    net.to(dev).train()
+    net.drop_emb = False
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, 2, seed=8, n_q=30, n_ocr=300, n_od=100, bert_vocab=1200)
+    scores, _ = net(q, ocr, od)
+    net.check_nan()
+    assert scores.shape == (2, 301) and torch.isfinite(scores).all() and float((scores.sum(1) - 1).abs().max()) < 1e-5
+    torch.nn.functional.binary_cross_entropy_with_logits(scores, gt.to(dev)).backward()
+    assert torch.isfinite(net.alphaBERT.grad).all() and float(net.multi2one.rnns[0].weight_ih_l0.grad.abs().max()) > 0
+    b1 = synth.synthetic_batch(opt, 1, seed=9, n_q=3, n_ocr=12, n_od=1, bert_vocab=1200)
+    s1, _ = net(b1[0], b1[1], b1[2])
+    assert s1.shape == (1, 301) and torch.isfinite(s1).all()
