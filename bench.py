@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
     return ap.parse_args()
 
 
@@ -180,7 +181,9 @@ def main():
     def step(i):
         b = batches[i % len(batches)]
         if a.mode == "train":
-            tr.update(b, i)
+            # steady-state pipeline: the frozen encoder pass of the NEXT batch overlaps this step's trunk; every timed step
+            # still launches exactly one encoder pass and one full trunk forward/backward/optimizer step
+            tr.update(b, i, next_batch=None if a.no_prefetch else batches[(i + 1) % len(batches)])
         else:
             tr.network.eval()
             tr.network.drop_emb = False

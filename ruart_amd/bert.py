@@ -16,6 +16,7 @@ MI355X-first differences from the reference, all result-preserving:
     the softmax(alpha) * gamma layer mix of ``SDNet.linear_sum`` (Models/SDNet.py:573-581).
 """
 import ctypes
+import os
 from ctypes import c_void_p
 
 import numpy as np
@@ -321,6 +322,63 @@ class Bert(nn.Module):
                                                                               self.bert_layer, self.bert_dim))
         self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "fp16"))
         self.pack = not opt.get("bert_no_pack", False)
+        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 224))
+        self._init_pipeline()
+
+    # -- encoder pipelining across steps ---------------------------------------------------------------------
+    # BERT is frozen, so the encoder pass of batch t+1 depends on nothing step t produces.  ``prefetch`` launches it on a
+    # separate normal-priority stream while step t's SDNet trunk (hundreds of small, latency-bound kernels on high-priority
+    # streams) runs: the big MFMA GEMMs fill the CUs the trunk leaves idle.  Two buffer sets alternate so the layer outputs
+    # step t's backward still reads (pool_mix_bwd) are not overwritten.
+    def _init_pipeline(self):
+        self._bufsets = [_Buffers(), _Buffers()]
+        self._pending = None                 # PackedTokens whose prefetched pass has not been consumed yet
+        self._in_use = 1                     # set whose layer outputs the current step's forward/backward reads
+        # CUs the prefetch pass may occupy; the rest stay free for the trunk (0 = all).  28 of every XCD's 32 by default.
+        self._pf_cus = int(os.environ.get("RUART_PREFETCH_CUS", self._opt_prefetch_cus))
+        self._pf_stream = None
+
+    def prefetch(self, packed, after_stream=None):
+        """Encode ``packed`` asynchronously into the buffer set the current step does NOT use; ``layers_for`` returns the
+        result.  ``after_stream``: the stream whose already enqueued work (the previous consumers of that set) must finish
+        first.  Call it after ``layers_for`` of the current batch."""
+        if getattr(packed, "_layers", None) is not None:
+            return
+        dev = self._device
+        if self._pf_stream is None or self._pf_stream.device != dev:
+            self._pf_stream = hip.cu_masked_stream(self._pf_cus, dev)
+        st = self._pf_stream
+        # the set being recycled was last read by the step BEFORE the current one: waiting for the point where the current
+        # step picked up its own layers (layers_for) is enough, wherever in the step the prefetch is launched
+        if after_stream is not None:
+            st.wait_stream(after_stream)
+        elif getattr(self, "_pickup_event", None) is not None:
+            st.wait_event(self._pickup_event)
+        else:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        if self._pending is not None and self._pending is not packed:
+            self._pending._layers = None     # only one pass can be in flight: an older unconsumed one is dropped
+        self._pending = packed
+        with torch.cuda.stream(st):
+            packed._set = self._in_use ^ 1
+            packed._layers = bert_encode(self.weights, packed, self._bufsets[packed._set])
+            packed._event = st.record_event()
+
+    def layers_for(self, packed):
+        """All-layer encoder output of ``packed``: the prefetched one (the current stream waits for it) or computed now."""
+        layers = getattr(packed, "_layers", None)
+        if layers is not None:
+            torch.cuda.current_stream(self._device).wait_event(packed._event)
+            packed._layers = None            # consumed: a later forward on the same batch re-encodes
+            self._pending = None
+            self._in_use = packed._set
+            self._pickup_event = torch.cuda.current_stream(self._device).record_event()
+            return layers
+        pend = self._pending
+        if pend is None or getattr(pend, "_layers", None) is None or pend._set != self._in_use ^ 1:
+            self._in_use ^= 1                # else: the other set holds a pass still to be consumed - reuse the current one
+        self._pickup_event = torch.cuda.current_stream(self._device).record_event()
+        return bert_encode(self.weights, packed, self._bufsets[self._in_use])
 
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
     def encode(self, groups):

@@ -425,6 +425,29 @@ extern "C" int ruart_whole_ln_bwd(const float* y, const float* grad_y, const flo
   return 0;
 }
 
+extern "C" int ruart_stream_create_cu_masked(int n_cus, void** stream_out) {
+  if (!stream_out) return -1;
+  int dev = 0, total = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -2;
+  if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -2;
+  hipStream_t s = nullptr;
+  hipError_t e;
+  if (n_cus <= 0 || n_cus >= total) {
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  } else {
+    uint32_t mask[16] = {0};
+    for (int i = 0; i < n_cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+  }
+  if (e != hipSuccess) return -3;
+  *stream_out = (void*)s;
+  return 0;
+}
+
+extern "C" int ruart_stream_destroy(void* stream) {
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int ruart_set_nan_flag(int* flag) {
   ruart_nan_flag_ptr = flag;
   return 0;

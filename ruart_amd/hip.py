@@ -61,6 +61,8 @@ _SIGNATURES = {
     "ruart_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
+    "ruart_stream_create_cu_masked": (_I, [_I, POINTER(ctypes.c_void_p)]),
+    "ruart_stream_destroy": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),
     "ruart_gemm_set_variant": (_I, [_I]),
     "ruart_prof_enable": (_I, [_I]),
@@ -118,3 +120,13 @@ def require_gpu(t, dtype=None):
     if not t.is_contiguous():
         raise HipError("tensor must be contiguous")
     return t
+
+
+def cu_masked_stream(n_cus, device):
+    """torch view of a HIP stream limited to ``n_cus`` compute units (ruart_stream_create_cu_masked)."""
+    import torch
+    lib = load()
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(lib.ruart_stream_create_cu_masked(int(n_cus), ctypes.byref(out)), "ruart_stream_create_cu_masked")
+    return torch.cuda.ExternalStream(out.value, device=device)

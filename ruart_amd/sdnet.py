@@ -146,6 +146,17 @@ class SDNet(nn.Module):
             q_list["_ruart_index"] = bi
         return bi
 
+    def prefetch_bert(self, q_list, ocr_list, od_list):
+        """Ask the next ``forward`` to start the (frozen) BERT pass of this FUTURE batch on the encoder's own stream, right
+        after it has picked up its own encoder output (see Bert.prefetch)."""
+        self._next_batch = (q_list, ocr_list, od_list)
+
+    def launch_prefetch(self):
+        """Start the encoder pass registered by ``prefetch_bert`` (no-op when none is pending)."""
+        nxt, self._next_batch = getattr(self, "_next_batch", None), None
+        if nxt is not None:
+            self.Bert.prefetch(self.prepare(*nxt).packed)
+
     def _layer_weights(self):
         """softmax(alpha)_l * gamma - the scalar each BERT layer is mixed with (SDNet.py:574-576)."""
         return F.softmax(self.alphaBERT, dim=0) * self.gammaBERT.view(1)
@@ -228,7 +239,8 @@ class SDNet(nn.Module):
             L.mask_bank.begin_step(dev)
 
         # ---- BERT: one packed pass, then pooled + mixed per group --------------------------------------------
-        layers = bert_encode(self.Bert.weights, bi.packed)
+        layers = self.Bert.layers_for(bi.packed)
+        self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
         lw = self._layer_weights()
         H = self.Bert.weights.hidden
         mixes = []
@@ -297,7 +309,7 @@ class SDNet(nn.Module):
     def _side_streams(self, dev):
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != dev:
-            st = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            st = (torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1))
             self._streams = st
         return st
 

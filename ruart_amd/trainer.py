@@ -117,10 +117,27 @@ class SDNetTrainer(BaseTrainer):
         return loss
 
     # -- one optimizer step -----------------------------------------------------------------------------------
-    def update(self, batch, batch_i=0):
+    def update(self, batch, batch_i=0, next_batch=None):
+        """One optimizer step.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
+        concurrently with this step's SDNet trunk; the whole step itself runs on a high-priority stream so the trunk's small
+        kernels are dispatched ahead of the encoder's big GEMM workgroups."""
+        dev = self.device
+        if dev.type == "cuda":
+            if getattr(self, "_step_stream", None) is None:
+                self._step_stream = torch.cuda.Stream(device=dev, priority=-1)
+            self._step_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._step_stream):
+                out = self._update(batch, batch_i, next_batch)
+            torch.cuda.current_stream(dev).wait_stream(self._step_stream)
+            return out
+        return self._update(batch, batch_i, next_batch)
+
+    def _update(self, batch, batch_i, next_batch):
         self.network.train()
         self.network.drop_emb = True
         q_list, ocr_list, od_list, targets, extra_info = batch
+        if next_batch is not None:
+            self.network.prefetch_bert(next_batch[0], next_batch[1], next_batch[2])
         scores, _ = self.network(q_list, ocr_list, od_list)
         if self.opt["loss"] == "CE":
             targets = torch.nonzero(targets)[:, 1]
@@ -196,13 +213,20 @@ class SDNetTrainer(BaseTrainer):
     def train(self, train_loader, val_loader=None, eval_every=1500, log_every=30):
         """The outer loop of Models/SDNetTrainer.py:107-123 over any iterable of collated batches."""
         self.isTrain = True
-        for batch_i, batch in enumerate(train_loader):
-            batch = self.ToCUDA(batch)
+        it = iter(train_loader)
+        nxt = next(it, None)
+        nxt = self.ToCUDA(nxt) if nxt is not None else None
+        batch_i = 0
+        while nxt is not None:
+            batch = nxt
+            nxt = next(it, None)
+            nxt = self.ToCUDA(nxt) if nxt is not None else None       # one batch of lookahead feeds the BERT prefetch
             if val_loader is not None and batch_i % eval_every == 0:
                 self.evaluate(val_loader, batch_i)
-            loss = self.update(batch, batch_i)
+            loss = self.update(batch, batch_i, next_batch=nxt)
             if batch_i % log_every == 0:
                 log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
+            batch_i += 1
 
     # -- checkpoints ------------------------------------------------------------------------------------------
     def load_model(self, model_path):

@@ -115,6 +115,37 @@ def test_trainer_update_and_predict(golden):
     assert torch.equal(tr.network.alphaBERT.detach(), before)
 
 
+def test_encoder_prefetch_is_bitwise_equivalent():
+    """update(batch, next_batch=...) runs the frozen encoder of the following batch one step ahead on its own CU-masked stream
+    (two alternating buffer sets).  The losses and the trained parameters must equal the inline schedule bit for bit, also
+    when a step without lookahead, an evaluation pass or a repeated batch falls between prefetched steps."""
+    from ruart_amd.trainer import SDNetTrainer
+
+    def run(prefetch):
+        opt = default_opt(vocab_size=1500, cuda=True, DROPOUT=0.0, dropout_emb=0.0)
+        cfg = synth.bert_config(vocab_size=2000)
+        opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=1033), cfg
+        sw = synth.make_sdnet_weights(opt, seed=1033)
+        tr = SDNetTrainer(opt, device="cuda:0")
+        tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+        bs = [tr.ToCUDA(synth.synthetic_batch(opt, 3 + (i % 2), seed=20 + i, n_q=10, n_ocr=20 + 3 * i, n_od=5, bert_vocab=2000,
+                                              ragged=True)) for i in range(4)]
+        order = [0, 1, 2, 2, 3, 0, 1]                       # includes a repeated batch
+        losses = []
+        for k, i in enumerate(order):
+            nxt = bs[order[k + 1]] if prefetch and k + 1 < len(order) and k != 3 else None      # step 3: no lookahead
+            losses.append(tr.update(bs[i], k, next_batch=nxt))
+            if k == 4:
+                losses.append(tr.predict(bs[1])[0])          # an inline encoder pass between two prefetched steps
+        return losses, {n: p.detach().clone() for n, p in tr.network.named_parameters() if p.requires_grad}
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert la == lb, (la, lb)
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+
+
 def test_variational_dropout_contract():
     """Layers.py:23-30: one mask per (row, feature) shared over time, scaled by 1/(1-p)."""
     import ruart_amd.layers as L
