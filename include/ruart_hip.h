@@ -177,10 +177,10 @@ int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* a
  * once per step instead of one device->host sync per op.  Pass NULL to disable. */
 int ruart_set_nan_flag(int* flag);
 
-/* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits, which the driver spreads evenly
- * over the 8 XCDs).  The frozen encoder pass of the NEXT batch runs on such a stream beside the current step's SDNet trunk:
- * the CUs left out of the mask are always free for the trunk's short latency-bound kernels, which otherwise queue behind the
- * encoder's 256-workgroup GEMM rounds.  n_cus <= 0 or >= the device's CU count creates an ordinary stream. */
+/* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
+ * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for
+ * the trunk's short kernels.  Off by default - it did not pay on MI355X.  n_cus <= 0 or >= the device's CU count creates an
+ * ordinary stream.  Destroy with ruart_stream_destroy before the process exits. */
 int ruart_stream_create_cu_masked(int n_cus, void** stream_out);
 int ruart_stream_destroy(void* stream);
 

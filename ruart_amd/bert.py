@@ -322,7 +322,7 @@ class Bert(nn.Module):
                                                                               self.bert_layer, self.bert_dim))
         self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "fp16"))
         self.pack = not opt.get("bert_no_pack", False)
-        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 224))
+        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 0))
         self._init_pipeline()
 
     # -- encoder pipelining across steps ---------------------------------------------------------------------
@@ -334,7 +334,7 @@ class Bert(nn.Module):
         self._bufsets = [_Buffers(), _Buffers()]
         self._pending = None                 # PackedTokens whose prefetched pass has not been consumed yet
         self._in_use = 1                     # set whose layer outputs the current step's forward/backward reads
-        # CUs the prefetch pass may occupy; the rest stay free for the trunk (0 = all).  28 of every XCD's 32 by default.
+        # CUs the prefetch pass may occupy; the rest stay free for the trunk (0 = all, the default).
         self._pf_cus = int(os.environ.get("RUART_PREFETCH_CUS", self._opt_prefetch_cus))
         self._pf_stream = None
 
@@ -346,7 +346,9 @@ class Bert(nn.Module):
             return
         dev = self._device
         if self._pf_stream is None or self._pf_stream.device != dev:
-            self._pf_stream = hip.cu_masked_stream(self._pf_cus, dev)
+            # an ordinary stream by default; a CU-masked one (ruart_stream_create_cu_masked) only on request - measured on
+            # MI355X, keeping 32-96 CUs out of the encoder's reach did not shorten the step
+            self._pf_stream = hip.cu_masked_stream(self._pf_cus, dev) if self._pf_cus > 0 else torch.cuda.Stream(device=dev)
         st = self._pf_stream
         # the set being recycled was last read by the step BEFORE the current one: waiting for the point where the current
         # step picked up its own layers (layers_for) is enough, wherever in the step the prefetch is launched

@@ -129,4 +129,13 @@ def cu_masked_stream(n_cus, device):
     out = ctypes.c_void_p()
     with torch.cuda.device(device):
         check(lib.ruart_stream_create_cu_masked(int(n_cus), ctypes.byref(out)), "ruart_stream_create_cu_masked")
+    import atexit
+
+    def _destroy(handle=out.value):
+        try:
+            torch.cuda.synchronize(device)
+            lib.ruart_stream_destroy(handle)
+        except Exception:
+            pass
+    atexit.register(_destroy)
     return torch.cuda.ExternalStream(out.value, device=device)

@@ -45,3 +45,32 @@ for i in range(len(marks) - 1):
           (t_union / 1e6, len(t_in), (union_of(t_in) if t_in else 0) / 1e6, (sum(e - s for s, e in t_in) / max(len(t_in), 1)) / 1e3))
     print("pass %d: period %.2f ms  encoder busy %.2f (span %.2f)  trunk busy %.2f  gpu-any-busy %.2f  idle %.2f" %
           (i, (hi - lo) / 1e6, e_busy, e_span, t_busy, union / 1e6, (hi - lo - union) / 1e6))
+
+# which trunk kernels stretch while an encoder pass is running?
+import bisect
+e_int = sorted((s, e) for s, e, n, *_ in rows if any(t in n for t in enc))
+e_starts = [s for s, _ in e_int]
+def overlaps_encoder(s, e):
+    i = bisect.bisect_right(e_starts, e) - 1
+    while i >= 0 and e_int[i][0] > s - 2_000_000:
+        if e_int[i][1] > s and e_int[i][0] < e:
+            return True
+        i -= 1
+    return False
+stat = defaultdict(lambda: [0, 0.0, 0, 0.0])
+for s, e, n, q, st in rows[len(rows) // 3:]:
+    if any(t in n for t in enc):
+        continue
+    k = n[:60]
+    if overlaps_encoder(s, e):
+        stat[k][0] += 1; stat[k][1] += (e - s) / 1e3
+    else:
+        stat[k][2] += 1; stat[k][3] += (e - s) / 1e3
+print("\n%-60s %8s %10s %8s %10s %8s" % ("trunk kernel", "n_in", "us_in", "n_out", "us_out", "extra_ms"))
+out = []
+for k, (a, ta, b, tb) in stat.items():
+    if a and b:
+        out.append((a * (ta / a - tb / b) / 1e3, k, a, ta / a, b, tb / b))
+for extra, k, a, ma, b, mb in sorted(out, reverse=True)[:18]:
+    print("%-60s %8d %10.1f %8d %10.1f %8.2f" % (k, a, ma, b, mb, extra))
+print("total extra ms over the analysed window: %.2f" % sum(o[0] for o in out))
