@@ -244,7 +244,7 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")       # PMC passes cannot run inside this process:
             if os.path.exists(tf) and a.batch == 64:                            # the committed rocprofv3 summary of this shape
                 traffic = json.load(open(tf)).get("avg_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "gemm_16_nt_256sq", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": "gemm_16_nt_256p8", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "launches": n_i,
                     "avg_launch_us": round(ms_i * 1e3 / n_i, 2),
                     "schedule": "encoder inline (each GEMM alone on the device), same K steps",

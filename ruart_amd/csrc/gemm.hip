@@ -20,6 +20,7 @@
 //  * gemm_f32_nt_64: exact-fp32 path on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), any M,N,K,
 //    used for the fp32 validation mode and the small SDNet projections.
 #include "common.h"
+#include <type_traits>
 #include "ruart_hip.h"
 
 #define BM 128
@@ -513,6 +514,231 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256x256x64, four phases per K-tile with the prefetch in flight ACROSS barriers (the "8-phase" schedule of the CDNA4
+// playbook: 2 K-tiles = 8 phases per loop iteration).  Same tile, wave layout, swizzle and epilogue as gemm_16_nt_256sq.
+//
+//  * Each operand K-tile is staged as two half-tiles of 128 rows (16 KB, two global_load_lds per thread).  Half h of A holds,
+//    for BOTH wave rows wm, rows wm*128 + h*64 .. +64; half h of W holds, for every wave column wn, rows wn*64 + h*32 .. +32.
+//    So every wave reads its first 64x32 quadrant operands from halves 0, and a half-tile is dead for ALL waves at a known
+//    phase:  W-h0 after phase 0 (its 4 reads are retired by lgkmcnt(8) before phase 0's first barrier), A-h0 after phase 0,
+//    W-h1 after phase 1, A-h1 after phase 2.
+//  * Phase p of K-tile t:  ds_read the fragments the quadrant needs | issue ONE half-tile prefetch | s_barrier |
+//    lgkmcnt(0) | 16 MFMA (one 64x32 quadrant x K=64) | s_barrier.  Prefetch order: phase 0 -> (t+1, A-h1); phase 1 ->
+//    (t+2, W-h0); phase 2 -> (t+2, A-h0); phase 3 -> (t+2, W-h1): every slot is restaged >= 2 phases after its last read
+//    (1 phase for W-h0, whose reads were retired before the barrier).
+//  * vmcnt is counted, never 0 in the steady state: phase 3 waits vmcnt(6) = the three youngest half-tiles stay in flight
+//    across the barriers, everything older - all of K-tile t+1 - has landed; it is read one phase later (after a barrier every
+//    wave passed following its own wait).
+//  * Waves 4-7 (wm = 1) run one barrier behind waves 0-3: while one group issues MFMAs the other does its LDS reads and
+//    prefetch issue, so each SIMD's matrix pipe alternates between its two resident waves instead of idling while both read.
+// Needs K % 128 == 0 (even number of K-tiles), M % 256 == 0, N % 256 == 0.
+// ------------------------------------------------------------------------------------------------
+#define RUART_BAR()                          \
+  do {                                       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kHalf = 128 * BK * 2;            // 16 KB half-tile
+  constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
+  constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * kBuf = 128 KB, the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: wave-dependent offsets stay in SGPRs
+  const int wm = wave >> 2, wn = wave & 3;
+#ifndef RUART_P8_ABLATE
+#define RUART_P8_ABLATE 0
+#endif
+  // diagnostic builds only (hipcc -DRUART_P8_ABLATE=n): 1 no prefetch issue in the loop, 2 no fragment reads after the first
+  // K-tile, 4 no stagger, 16 prefetch issued between the MFMAs instead of in the read segment.  0 in production.
+  constexpr int ab = RUART_P8_ABLATE;
+  const int ntn = N / BN4, ntm = M / BM4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+  const int m0 = tm * BM4, n0 = tn * BN4;
+
+  // staging: wave w fills local rows 16w .. 16w+15 of a half-tile (two 1 KB pieces of 8 rows x 128 B, lane-linear)
+  // Addresses = uniform 64-bit base (SGPR pair) + ONE 32-bit per-lane offset per operand (global_load_lds saddr form).
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const unsigned a_lane = (unsigned)(srow * lda + schunk * 8), w_lane = (unsigned)(srow * ldw + schunk * 8);
+  const T16* a_src = A + (size_t)(m0 + (wave >> 2) * 128 + (wave & 3) * 16) * lda;
+  const T16* w_src = W + (size_t)(n0 + (wave >> 1) * 64 + (wave & 1) * 16) * ldw;
+  const size_t a8 = (size_t)8 * lda, w8 = (size_t)8 * ldw, a_h = (size_t)64 * lda, w_h = (size_t)32 * ldw;
+  char* const st_base = smem + wave * 2048;
+  auto stage_a = [&](int d, int h, int kt) {
+    char* dst = st_base + d * kBuf + h * kHalf;
+    const T16* src = a_src + h * a_h + kt * BK;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + a_lane), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + a8 + a_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+  };
+  auto stage_w = [&](int d, int h, int kt) {
+    char* dst = st_base + d * kBuf + kOper + h * kHalf;
+    const T16* src = w_src + h * w_h + kt * BK;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + w_lane), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + w8 + w_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+  frag_t af[4][2], wf0[2][2], wf1[2][2];
+  auto read_a = [&](int d, int h) {
+    const char* sa = smem + d * kBuf + h * kHalf;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[j][ks] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + j * 16 + fr, ks * 4 + fq));
+  };
+  auto read_w = [&](int d, int h, frag_t (&wf)[2][2]) {
+    const char* sw = smem + d * kBuf + kOper + h * kHalf;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) wf[i][ks] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 32 + i * 16 + fr, ks * 4 + fq));
+  };
+  // 16 MFMAs of one quadrant.  Diagnostic build RUART_P8_ABLATE=16 issues the phase's prefetch (``pre``) between them
+  // instead of in the read segment: measured 4 % SLOWER on the BERT shapes and 2.5 % slower at 4096^3, so it is off.
+  auto quad = [&](int hc, int hr, frag_t (&wf)[2][2], auto pre) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[hc * 2 + i][hr * 4 + j] = mfma_16x16x32(wf[i][ks], af[j][ks], acc[hc * 2 + i][hr * 4 + j]);
+      if (ks == 0 && (ab & 16)) {
+        __builtin_amdgcn_sched_barrier(0);
+        pre();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto nothing = [] {};
+  // one K-tile = four phases.  D: LDS buffer of this tile; N1: K-tile t+1 exists; N2: K-tile t+2 exists.
+  auto tile = [&](auto dtag, auto n1tag, auto n2tag, int t) {
+    constexpr int D = decltype(dtag)::value;
+    constexpr bool N1 = decltype(n1tag)::value, N2 = decltype(n2tag)::value;
+    constexpr bool S1 = N1 && !(ab & 1), S2 = N2 && !(ab & 1);
+    const bool rd = !(ab & 2) || t == 0;
+    // phase 0: quadrant (rows h0, cols h0); prefetch (t+1, A-h1)
+    if (rd) read_w(D, 0, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (rd) read_a(D, 0);
+    if (S1 && !(ab & 16)) stage_a(D ^ 1, 1, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W-h0 reads (issued first) are back: its slot may be restaged
+    RUART_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (S1) quad(0, 0, wf0, [&] { stage_a(D ^ 1, 1, t + 1); }); else quad(0, 0, wf0, nothing);
+    RUART_BAR();
+    // phase 1: (rows h0, cols h1); prefetch (t+2, W-h0)
+    if (rd) read_w(D, 1, wf1);
+    if (S2 && !(ab & 16)) stage_w(D, 0, t + 2);
+    RUART_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (S2) quad(1, 0, wf1, [&] { stage_w(D, 0, t + 2); }); else quad(1, 0, wf1, nothing);
+    RUART_BAR();
+    // phase 2: (rows h1, cols h1); prefetch (t+2, A-h0)
+    if (rd) read_a(D, 1);
+    if (S2 && !(ab & 16)) stage_a(D, 0, t + 2);
+    RUART_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (S2) quad(1, 1, wf1, [&] { stage_a(D, 0, t + 2); }); else quad(1, 1, wf1, nothing);
+    RUART_BAR();
+    // phase 3: (rows h1, cols h0) - operands already in registers; prefetch (t+2, W-h1)
+    if (N2) {
+      if (!(ab & 16)) {
+        if (S2) stage_w(D, 1, t + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile t+1 complete; the 3 youngest half-tiles stay in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (diagnostic placement: this phase's prefetch follows the wait)
+      }
+    } else if (N1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // last prefetch: (t+1, A-h1) from phase 0
+    }
+    RUART_BAR();
+    if (S2) quad(0, 1, wf0, [&] { stage_w(D, 1, t + 2); }); else quad(0, 1, wf0, nothing);
+    RUART_BAR();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+  const int nt = K / BK;                         // even, >= 2
+  stage_w(0, 0, 0);
+  stage_a(0, 0, 0);
+  stage_w(0, 1, 0);
+  stage_a(0, 1, 0);
+  stage_w(1, 0, 1);
+  stage_a(1, 0, 1);
+  stage_w(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile 0 landed (this wave's share)
+  RUART_BAR();
+  if (wave >= 4 && !(ab & 4)) RUART_BAR();   // stagger: waves 4-7 run one barrier behind
+  int t = 0;
+  for (; t + 2 < nt; t += 2) {
+    tile(I0{}, Tt{}, Tt{}, t);
+    tile(I1{}, Tt{}, Tt{}, t + 1);
+  }
+  tile(I0{}, Tt{}, Ff{}, t);
+  tile(I1{}, Ff{}, Ff{}, t + 1);
+  if (wave < 4 && !(ab & 4)) RUART_BAR();    // waves 0-3 pair the lagging group's last barrier
+  RUART_BAR();                                                  // every wave is done reading operand tiles
+
+  constexpr int ERS = 272;
+  char* my = smem + wave * (32 * ERS);
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + wn * 64 + rcol;
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = rr * 4 + rrow;
+      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
+      const int m = m0 + wm * 128 + hh * 32 + lr;
+      if (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
+      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256x256x64, "A in registers" pipeline: see the comment above the main loop.  Same tile, staging and epilogue as
 // gemm_16_nt_256sq; only the K loop differs.
 // ------------------------------------------------------------------------------------------------
@@ -763,7 +989,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {
-  if (v < 0 || v > 4) return (int)hipErrorInvalidValue;
+  if (v < 0 || v > 5) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
@@ -797,13 +1023,21 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
   return 0;
 }
 
-int g_gemm_variant = 3;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128, 3: 256x256 2-stage (M, N % 256 == 0)
+int g_gemm_variant = 5;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128, 3: 256x256 2-stage, 4: 256x256 A-in-registers,
+                                 // 5: 256x256 four phases per K-tile, counted vmcnt, staggered wave groups (M, N % 256 == 0, K % 128 == 0; else 3)
 int g_gemm_persist_blocks = 512; // persistent grid: 2 workgroups x 256 CUs
 
 template <typename T16, bool OF, int RS, int AC>
 static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr,
                        void* C, int ldc, int M, int N, int K, hipStream_t s) {
-  if (g_gemm_variant == 4 && M % BM4 == 0 && N % BN4 == 0) {
+  if (g_gemm_variant == 5 && M % BM4 == 0 && N % BN4 == 0 && K % (2 * BK) == 0) {
+    auto kern = gemm_16_nt_256p8<T16, OF, RS, AC>;
+    constexpr int lds = 2 * 2 * BM4 * BK * 2;
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)done;
+    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       g_tile_order);
+  } else if (g_gemm_variant == 4 && M % BM4 == 0 && N % BN4 == 0) {
     auto kern = gemm_16_nt_256ar<T16, OF, RS, AC>;
     constexpr int lds = 2 * 2 * BM4 * BK * 2;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);

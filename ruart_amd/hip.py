@@ -82,7 +82,8 @@ def load(build_if_missing=True):
             raise OSError("libruart_hip.so not built: run `python -m ruart_amd.build`")
         from . import build as _build
         _build.build(verbose=False)
-    lib = ctypes.CDLL(LIB_PATH)
+    # RUART_HIP_LIB: load an experimental build of the same ABI instead (kernel A/B runs, tools/build_variant.sh)
+    lib = ctypes.CDLL(os.environ.get("RUART_HIP_LIB") or LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res

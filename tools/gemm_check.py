@@ -17,7 +17,7 @@ for dt in (hip.DT_F16, hip.DT_BF16):
         if res: ref = ref + R.double()
         Ad, Wd, bd = A.to(d), W.to(d), bias.to(d); Rd = R.to(d) if res else None
         outs = {}
-        for v in (0, 1, 2, 3, 4):
+        for v in (0, 1, 2, 3, 4, 5):
             lib.ruart_gemm_set_variant(v)
             C = torch.full((M, N), float("nan"), dtype=torch.float32 if res else td, device=d)
             rc = lib.ruart_gemm_16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, dt, hip.ptr(C), N, hip.DT_F32 if res else dt, M, N, K, act, dt, hip.stream_ptr())
@@ -29,5 +29,25 @@ for dt in (hip.DT_F16, hip.DT_BF16):
             flag = "OK " if (rc == 0 and err < tol) else "BAD"
             ok &= flag == "OK "
             print("%s dt %d M %5d N %5d K %5d act %d res %d variant %d: rc %d max err %.3e bitwise==v0 %s" % (flag, dt, M, N, K, act, int(res), v, rc, err, same), flush=True)
-lib.ruart_gemm_set_variant(0)
+# race screen for the counted-vmcnt / staggered schedule (variant 5): many launches at several sizes, bitwise against variant 3
+for dt in (hip.DT_F16, hip.DT_BF16):
+    td = hip.TORCH_DTYPE[dt]
+    for (M, N, K) in [(4096, 768, 768), (43008, 2304, 768), (8192, 3072, 768), (8192, 768, 3072), (2048, 256, 128), (512, 512, 256)]:
+        g = torch.Generator().manual_seed(M + N + K + 1)
+        Ad = torch.randn(M, K, generator=g).to(td).to(d); Wd = (torch.randn(N, K, generator=g) * 0.05).to(td).to(d)
+        bd = torch.randn(N, generator=g).to(d)
+        lib.ruart_gemm_set_variant(3)
+        C3 = torch.empty((M, N), dtype=td, device=d)
+        lib.ruart_gemm_16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), None, N, dt, hip.ptr(C3), N, dt, M, N, K, 0, dt, hip.stream_ptr())
+        lib.ruart_gemm_set_variant(5)
+        bad = 0
+        C5 = torch.empty((M, N), dtype=td, device=d)
+        for it in range(30):
+            C5.fill_(float("nan"))
+            lib.ruart_gemm_16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), None, N, dt, hip.ptr(C5), N, dt, M, N, K, 0, dt, hip.stream_ptr())
+            bad += int(not torch.equal(C5, C3))
+        torch.cuda.synchronize()
+        ok &= bad == 0
+        print("%s race screen dt %d M %5d N %5d K %5d: %d / 30 launches differ from variant 3" % ("OK " if bad == 0 else "BAD", dt, M, N, K, bad), flush=True)
+lib.ruart_gemm_set_variant(5)
 sys.exit(0 if ok else 1)
