@@ -47,6 +47,33 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
+// GELU for the 16-bit epilogues:  gelu(x) = x * Phi(x) = x / (1 + exp(-x q(x^2))),  x q(x^2) = logit(Phi(x)), q = degree-4
+// polynomial in x^2 fitted (weighted minimax, tools/fit_gelu.py) on |x| <= 7.  q stays positive and grows beyond the fitted
+// range, so the logistic saturates to exactly 0 / 1 for large |x| (and through inf) without a clamp.  Max abs error 3.4e-6 in
+// fp32 evaluation - at or below the half-ulp of an f16 output wherever |gelu| > 0.01, 70x below it at |gelu| ~ 0.5.
+// The epilogue is VALU-issue bound (PMC + instruction count: ~12 lane-passes per element here vs ~19 for the A&S erf form; the
+// packed v_pk_*_f32 forms take two passes, so they save instructions, not cycles).  Coefficients carry the -log2(e) of the exp2.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_pk(f32x2_t x) {
+  const f32x2_t x2 = x * x;
+  f32x2_t p = x2 * -3.228988589e-06f + 8.823813550e-05f;
+  p = p * x2 + 3.602745419e-04f;
+  p = p * x2 + -1.052266881e-01f;
+  p = p * x2 + -2.302045345e+00f;
+  p = p * x;
+  f32x2_t d;
+  d.x = 1.0f + __builtin_amdgcn_exp2f(p.x);
+  d.y = 1.0f + __builtin_amdgcn_exp2f(p.y);
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(d.x);
+  r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * r;
+}
+__device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
+  const f32x2_t lo = gelu_pk((f32x2_t){v[0], v[1]}), hi = gelu_pk((f32x2_t){v[2], v[3]});
+  return (f32x4_t){lo.x, lo.y, hi.x, hi.y};
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -140,10 +167,7 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wm * 64 + j * 16 + fr;
       f32x4_t v = acc[i][j] + bv;
-      if (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
+      if (ACT == 1) v = gelu4(v);
       if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
       if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
       if (OUT_F32)
@@ -382,10 +406,7 @@ __global__ __launch_bounds__(512) void gemm_16_nt_256(const T16* __restrict__ A,
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wm * 64 + j * 16 + fr;
       f32x4_t v = acc[i][j] + bv;
-      if (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
+      if (ACT == 1) v = gelu4(v);
       if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
       if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
       if (OUT_F32)
@@ -494,21 +515,30 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
+    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
+    f32x4_t v[8], res[8];
+    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    if (RES != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    if (ACT == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int lr = rr * 4 + rrow;
-      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
-      const int m = m0 + wm * 128 + hh * 32 + lr;
-      if (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
-      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
-      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
+      if (RES != 0) v[rr] += res[rr];
       if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
       else
-        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
     }
   }
 }
@@ -719,21 +749,30 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
+    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
+    f32x4_t v[8], res[8];
+    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    if (RES != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    if (ACT == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int lr = rr * 4 + rrow;
-      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
-      const int m = m0 + wm * 128 + hh * 32 + lr;
-      if (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
-      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
-      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
+      if (RES != 0) v[rr] += res[rr];
       if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
       else
-        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
     }
   }
 }
@@ -856,21 +895,30 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256ar(const T16* __restrict
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
+    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
+    f32x4_t v[8], res[8];
+    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    if (RES != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    if (ACT == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int lr = rr * 4 + rrow;
-      f32x4_t v = *reinterpret_cast<const f32x4_t*>(my + lr * ERS + rcol * 4) + bv;
-      const int m = m0 + wm * 128 + hh * 32 + lr;
-      if (ACT == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
-      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + ncol);
-      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + ncol);
+      if (RES != 0) v[rr] += res[rr];
       if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
       else
-        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + ncol, v);
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
     }
   }
 }

@@ -15,7 +15,8 @@ a = ap.parse_args()
 lib = hip.load(); d = torch.device("cuda:0")
 dt = hip.PRECISION[a.dtype]; td = hip.TORCH_DTYPE[dt]
 N, K, act, res = {"qkv": (2304, 768, hip.ACT_NONE, False), "ao": (768, 768, hip.ACT_NONE, True), "ff1": (3072, 768, hip.ACT_GELU, False),
-                  "ff2": (768, 3072, hip.ACT_NONE, True), "sq4k": (4096, 4096, hip.ACT_NONE, False)}[a.shape]
+                  "ff2": (768, 3072, hip.ACT_NONE, True), "sq4k": (4096, 4096, hip.ACT_NONE, False),
+                  "ff1n": (3072, 768, hip.ACT_NONE, False), "aon": (768, 768, hip.ACT_NONE, False), "ff2n": (768, 3072, hip.ACT_NONE, False)}[a.shape]
 M = 4096 if a.shape == "sq4k" else a.rows
 g = torch.Generator().manual_seed(0)
 A = torch.randn(M, K, generator=g).to(td).to(d); W = (torch.randn(N, K, generator=g) * 0.05).to(td).to(d)
