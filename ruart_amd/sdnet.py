@@ -31,6 +31,114 @@ _UNSUPPORTED = ("img_feature", "fixed_answers", "ModelParallel", "PRE_ALIGN_afte
                 "no_DeepAttention")
 
 
+def _record(t, stream):
+    """``t`` (allocated on another stream) is read on ``stream``: tell the caching allocator - except while a graph is being
+    captured, where the private pool keeps every block until the graph dies and record_stream is not allowed."""
+    if isinstance(t, torch.Tensor) and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        t.record_stream(stream)
+
+
+def _fork(main, sides, tensors):
+    """side streams may start once everything enqueued on ``main`` so far is done; tensors made on ``main`` and read on a
+    side stream are registered with the caching allocator."""
+    for s in sides:
+        if s is main:
+            continue
+        s.wait_stream(main)
+        for t in tensors:
+            _record(t, s)
+
+
+def _join(main, sides, tensors):
+    for s in sides:
+        if s is not main:
+            main.wait_stream(s)
+    for t in tensors:
+        _record(t, main)
+
+
+class _Trunk(nn.Module):
+    """The fixed-shape part of SDNet.forward (Models/SDNet.py:339-436): question / OCR / object RNN stacks, deep attention,
+    self attention, high-level RNNs, object->OCR attention, answer scores.  Every tensor is dense (B, L, D), so for a given
+    batch size the whole forward (and its backward) is one fixed launch sequence - which is what lets it be captured in a
+    hipGraph.  Holds the SAME submodule objects as the SDNet it was built from (shared parameters); it is never registered as
+    a child of that SDNet, so checkpoints keep the reference's keys."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.opt = net.opt
+        for name in ("ques_rnn", "high_lvl_ques_rnn", "ques_self_attn", "ques_merger", "context_rnn", "deep_attn",
+                     "highlvl_self_att", "high_lvl_context_rnn", "get_answer"):
+            setattr(self, name, getattr(net, name))
+        for name in ("od_ocr_attn", "position_attn"):
+            if hasattr(net, name):
+                setattr(self, name, getattr(net, name))
+        self._net_streams = net._side_streams       # eager mode shares the SDNet's two side streams (few HW queues)
+        self._bank = L.MaskBank()
+
+    def _side_streams(self, dev):
+        if torch.cuda.is_current_stream_capturing():
+            # side streams of a capture must be fresh ones forked from the capturing stream
+            st = self.__dict__.get("_cap_streams")
+            if st is None:
+                st = self.__dict__["_cap_streams"] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            return st
+        return self._net_streams(dev)
+
+    def forward(self, q_input, q_raw, q_mask, x_ocr, x_od, ocr_mask, od_mask, ocr_pos, od_pos):
+        opt = self.opt
+        dev = q_input.device
+        prev_bank, L.mask_bank = L.mask_bank, self._bank       # masks of the trunk are drawn inside it (capturable)
+        try:
+            if self.training:
+                self._bank.begin_step(dev)
+            # The question, OCR and object branches are independent until they meet in deep_attn / od_ocr_attn.  Their kernels
+            # are small (B=64 rows), so they run on three HIP streams and overlap on the 256 CUs; autograd replays each backward
+            # on its forward's stream, so the backward overlaps the same way.
+            main = torch.cuda.current_stream(dev)
+            use_streams = bool(opt.get("ruart_streams", True))
+            s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
+            _fork(main, (s_q, s_od), [q_input, q_raw, q_mask, x_od, od_mask])
+
+            with torch.cuda.stream(s_q):                                        # ---- question branch (SDNet.py:339, 350)
+                _, q_rnn_layers = self.ques_rnn(q_input, q_mask, return_list=True, LN=True)
+                q_highlvl = self.high_lvl_ques_rnn(torch.cat(q_rnn_layers, 2), q_mask, LN=True)
+                q_rnn_layers = q_rnn_layers + [q_highlvl]
+                ev_q_layers = s_q.record_event() if use_streams else None
+                q_final = self.ques_self_attn(q_highlvl, q_highlvl, q_mask)    # SDNet.py:411-415
+                q_merged = self.ques_merger.merge(q_final, q_mask)
+            q_long = [q_raw]
+
+            def context_branch(x, mask):
+                """context_rnn, deep_attn, self-attention, high-level rnn for OCR tokens or objects"""
+                _, rnn_layers = self.context_rnn(x, mask, return_list=True, LN=True)
+                if ev_q_layers is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev_q_layers)
+                    for t in q_rnn_layers:
+                        _record(t, torch.cuda.current_stream(dev))
+                h, pre = self.deep_attn([x], rnn_layers, q_long, q_rnn_layers, mask, q_mask, return_bef_rnn=True)
+                sa_in = torch.cat([h, pre, x], 2)
+                sa = self.highlvl_self_att(sa_in, sa_in, mask, x3=h)
+                return self.high_lvl_context_rnn(torch.cat([h, sa], 2), mask, LN=True)
+
+            with torch.cuda.stream(s_od):                                       # ---- object branch
+                od_hl = context_branch(x_od, od_mask)
+            ocr_hl = context_branch(x_ocr, ocr_mask)                            # ---- OCR branch on the main stream
+            _join(main, (s_od, s_q), [od_hl, q_merged])
+
+            if "position_dim" in opt:
+                if opt["position_mod"] == "qk+":
+                    x_od_ocr = self.od_ocr_attn(ocr_hl, od_hl, od_mask) + self.position_attn(ocr_pos, od_pos, od_mask, x3=od_hl)
+                else:
+                    x_od_ocr = self.od_ocr_attn(torch.cat([ocr_hl, ocr_pos], 2), torch.cat([od_hl, od_pos], 2), od_mask)
+            mode = opt["pos_att_merge_mod"]
+            ocr_final = torch.cat([ocr_hl, x_od_ocr], 2) if mode == "cat" else (x_od_ocr if mode == "atted" else ocr_hl)
+            es_len = opt["ES_ocr_len"] if "useES" in opt else None
+            return self.get_answer(ocr_final, q_merged, ocr_mask, es_len, mask_flag="mask_score" in opt)
+        finally:
+            L.mask_bank = prev_bank
+
+
 class SDNet(nn.Module):
     def __init__(self, opt, embedding):
         super().__init__()
@@ -251,59 +359,65 @@ class SDNet(nn.Module):
         q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev)
         ocr_mask, od_mask = bi.ocr_mask, bi.od_mask
 
-        # The question, OCR and object branches are independent until they meet in deep_attn / od_ocr_attn.  Their
-        # kernels are small (B=64 rows), so they run on three HIP streams and overlap on the 256 CUs; autograd replays
-        # each backward on its forward's stream, so the backward overlaps the same way.
+        # ---- front: variable-size part (real words of this batch): embeddings, pre-align, multi2one -----------
+        # The OCR and object groups are independent: objects on a side stream, OCR on the main one.
         main = torch.cuda.current_stream(dev)
         use_streams = bool(opt.get("ruart_streams", True))
         s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
-
         q_input, q_raw = self._embed_question(q_list, q_bert)
         if "PRE_ALIGN_befor_rnn" in opt:
             q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
-        self._fork(main, (s_q, s_od), [q_input, q_raw, q_mask, mixes[2], od_mask])
 
-        with torch.cuda.stream(s_q):                                            # ---- question branch (SDNet.py:339, 350)
-            _, q_rnn_layers = self.ques_rnn(q_input, q_mask, return_list=True, LN=True)
-            q_highlvl = self.high_lvl_ques_rnn(torch.cat(q_rnn_layers, 2), q_mask, LN=True)
-            q_rnn_layers = q_rnn_layers + [q_highlvl]
-            ev_q_layers = s_q.record_event() if use_streams else None
-            q_final = self.ques_self_attn(q_highlvl, q_highlvl, q_mask)        # SDNet.py:411-415
-            q_merged = self.ques_merger.merge(q_final, q_mask)
-        q_long = [q_raw]
-
-        def context_branch(items, idx, mix, mask):
-            """embedding, pre-align, multi2one, context_rnn, deep_attn, self-attention, high-level rnn for OCR or objects"""
+        def front(items, idx, mix):
             words, raw = self._embed_items(items, idx, mix)
             if "PRE_ALIGN_befor_rnn" in opt:
                 words = torch.cat([words, self._prealign(raw, idx, q_raw, q_mask)], -1)
-            x = self._multi2one_last(words, idx)                                # (B, max_num, 300)
-            _, rnn_layers = self.context_rnn(x, mask, return_list=True, LN=True)
-            if ev_q_layers is not None:
-                torch.cuda.current_stream(dev).wait_event(ev_q_layers)
-                for t in q_rnn_layers:
-                    t.record_stream(torch.cuda.current_stream(dev))
-            h, pre = self.deep_attn([x], rnn_layers, q_long, q_rnn_layers, mask, q_mask, return_bef_rnn=True)
-            sa_in = torch.cat([h, pre, x], 2)
-            sa = self.highlvl_self_att(sa_in, sa_in, mask, x3=h)
-            return self.high_lvl_context_rnn(torch.cat([h, sa], 2), mask, LN=True)
+            return self._multi2one_last(words, idx)                             # (B, max_num, 300)
 
-        with torch.cuda.stream(s_od):                                           # ---- object branch
-            od_hl = context_branch(od_list, bi.od, mixes[2], od_mask)
-        ocr_hl = context_branch(ocr_list, bi.ocr, mixes[1], ocr_mask)           # ---- OCR branch on the main stream
-        self._join(main, (s_od, s_q), [od_hl, q_merged])
+        _fork(main, (s_od,), [q_raw, q_mask, mixes[2]])
+        with torch.cuda.stream(s_od):
+            x_od = front(od_list, bi.od, mixes[2])
+        x_ocr = front(ocr_list, bi.ocr, mixes[1])
+        _join(main, (s_od,), [x_od])
 
+        # ---- trunk: fixed-shape part (B, L, D) - eager, or one hipGraph replay per direction ------------------
         if "position_dim" in opt:
             ocr_pos, od_pos = ocr_list["position"].to(dev), od_list["position"].to(dev)
-            if opt["position_mod"] == "qk+":
-                x_od_ocr = self.od_ocr_attn(ocr_hl, od_hl, od_mask) + self.position_attn(ocr_pos, od_pos, od_mask, x3=od_hl)
-            else:
-                x_od_ocr = self.od_ocr_attn(torch.cat([ocr_hl, ocr_pos], 2), torch.cat([od_hl, od_pos], 2), od_mask)
-        mode = opt["pos_att_merge_mod"]
-        ocr_final = torch.cat([ocr_hl, x_od_ocr], 2) if mode == "cat" else (x_od_ocr if mode == "atted" else ocr_hl)
-        es_len = opt["ES_ocr_len"] if "useES" in opt else None
-        score_s = self.get_answer(ocr_final, q_merged, ocr_mask, es_len, mask_flag="mask_score" in opt)
+        else:
+            ocr_pos = od_pos = q_mask.new_zeros(1)
+        trunk = self._trunk_callable(q_input, q_raw, q_mask, x_ocr, x_od, ocr_mask, od_mask, ocr_pos, od_pos)
+        score_s = trunk(q_input, q_raw, q_mask, x_ocr, x_od, ocr_mask, od_mask, ocr_pos, od_pos)
         return score_s, None
+
+    # -- the dense trunk and its graph capture -------------------------------------------------------------------
+    def _trunk_module(self):
+        t = self.__dict__.get("_trunk")
+        if t is None:
+            t = _Trunk(self)
+            self.__dict__["_trunk"] = t          # not a registered child: the state dict keeps the reference's keys
+        return t
+
+    def _trunk_callable(self, *args):
+        """Eager trunk, or - opt['ruart_graph_trunk'] - a captured forward/backward pair for this shape signature
+        (torch.cuda.make_graphed_callables): the trunk is ~850 small launches whose host enqueue time exceeds their GPU time."""
+        trunk = self._trunk_module()
+        trunk.train(self.training)
+        if not (self.opt.get("ruart_graph_trunk", False) and self.training and torch.is_grad_enabled()):
+            return trunk
+        key = tuple((tuple(a.shape), a.dtype, a.requires_grad) for a in args)
+        cache = self.__dict__.setdefault("_trunk_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = {"seen": 0, "fn": None}
+        if ent["fn"] is None:
+            ent["seen"] += 1
+            if ent["seen"] <= int(self.opt.get("ruart_graph_after", 2)) or len([e for e in cache.values() if e["fn"]]) >= 4:
+                return trunk                      # eager until the shape has recurred (and for a 5th distinct shape)
+            torch.cuda.synchronize(self.device)
+            sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+            ent["fn"] = torch.cuda.make_graphed_callables(trunk, sample, num_warmup_iters=3, allow_unused_input=True)
+            self.zero_grad(set_to_none=True)
+        return ent["fn"]
 
     # -- stream plumbing -----------------------------------------------------------------------------------
     def _side_streams(self, dev):
@@ -312,27 +426,6 @@ class SDNet(nn.Module):
             st = (torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1))
             self._streams = st
         return st
-
-    @staticmethod
-    def _fork(main, sides, tensors):
-        """side streams may start once everything enqueued on ``main`` so far is done; tensors made on ``main`` and
-        read on a side stream are registered with the caching allocator."""
-        for s in sides:
-            if s is main:
-                continue
-            s.wait_stream(main)
-            for t in tensors:
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(s)
-
-    @staticmethod
-    def _join(main, sides, tensors):
-        for s in sides:
-            if s is not main:
-                main.wait_stream(s)
-        for t in tensors:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(main)
 
     def check_nan(self):
         """One host sync honouring every ``assert torch.sum(torch.isnan(.)) == 0`` of the reference's forward."""
