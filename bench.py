@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
+    ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
     return ap.parse_args()
 
 
@@ -163,6 +164,8 @@ def main():
     if a.mode == "bert512":
         return bert512(a, device, lib)
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
+    if a.graph_trunk is not None:
+        opt["ruart_graph_trunk"] = bool(a.graph_trunk)
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
     note("building model")
     tr, _ = build_trainer(opt, cfg, device)

@@ -17,8 +17,11 @@ def _np(x):
 
 
 class VQA_collate:
-    def __init__(self, opt):
+    def __init__(self, opt, prepare_index=False):
+        """``prepare_index``: also build the hot path's host-side batch index (BatchIndex, numpy only) here - i.e. inside the
+        DataLoader workers - and attach it as ``q_list['_ruart_host_index']``; ``SDNetTrainer.ToCUDA`` then only copies."""
         self.opt = opt
+        self.prepare_index = prepare_index
 
     def VQA_collate_fun(self, batch):
         o = self.opt
@@ -26,6 +29,8 @@ class VQA_collate:
         ocr_list = self.item_collate([t["ocr"] for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"])
         od_list = self.item_collate([t["od"] for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"])
         gt_list = self.gt_collate([t["gt"] for t in batch])
+        if self.prepare_index:
+            q_list["_ruart_host_index"] = BatchIndex(q_list, ocr_list, od_list, o)
         return q_list, ocr_list, od_list, gt_list, [t["extra_info"] for t in batch]
 
     def gt_collate(self, gt_list):
@@ -139,29 +144,31 @@ class ItemIndex:
 
 
 class BatchIndex:
-    """Everything ``SDNet.forward`` needs besides the reference's own batch tensors."""
+    """Everything ``SDNet.forward`` needs besides the reference's own batch tensors.
 
-    def __init__(self, q_list, ocr_list, od_list, opt, device, bert=None):
+    Two stages: the constructor does the HOST work (numpy: index vectors, the packed BERT stream, pooling spans) and leaves a
+    picklable object - ``VQA_collate(opt, prepare_index=True)`` runs it inside DataLoader workers; ``to(device)`` ships the
+    three flat buffers (three H2D copies) and builds the device views.  Passing ``device`` to the constructor does both."""
+
+    def __init__(self, q_list, ocr_list, od_list, opt, device=None, bert=None, pack=None, mfma_long=None):
         wk_o, wk_q = opt["ocr_emb_initial"], opt["q_emb_initial"]
         self.ocr = ItemIndex(ocr_list, wk_o, ocr_list["position"].size(1))
         self.od = ItemIndex(od_list, wk_o, od_list["position"].size(1))
-        self.device = torch.device(device)
-        host = self.ocr.pack_host() + self.od.pack_host()
-        sizes = [len(a) for a in host]
-        buf = torch.from_numpy(np.concatenate(host)).to(self.device, non_blocking=True) if sum(sizes) else torch.zeros(0, dtype=torch.long, device=self.device)
-        parts = list(torch.split(buf, sizes))
-        n = len(ItemIndex._FIELDS)
-        self.ocr.bind(parts[:n])
-        self.od.bind(parts[n:])
-        self.ocr_mask = torch.from_numpy(self.ocr.mask).to(self.device, non_blocking=True)
-        self.od_mask = torch.from_numpy(self.od.mask).to(self.device, non_blocking=True)
+        self.device = None
+        self.ocr_mask = self.od_mask = None
         # BERT: one packed pass over question + OCR items + object items, and the pooling descriptors
         self.packed = None
         self.spans = None
+        self._spans_host = None
         if bert is not None:
+            pack, mfma_long = bert.pack, bert.weights.dtype != 0
+        if "BERT" in opt or bert is not None:
             from .bert import PackedTokens, word_spans
+            pack = (not opt.get("bert_no_pack", False)) if pack is None else pack
+            mfma_long = (opt.get("bert_precision", "fp16") != "fp32") if mfma_long is None else mfma_long
+            self.plan = (bool(pack), bool(mfma_long))
             groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
-            self.packed = PackedTokens(groups, self.device, pack=bert.pack, mfma_long=bert.weights.dtype != 0)
+            self.packed = PackedTokens(groups, None, pack=pack, mfma_long=mfma_long)
             spans = []
             for g, (items, wk) in enumerate(((q_list, wk_q), (ocr_list, wk_o), (od_list, wk_o))):
                 wm = _np(items[wk + "_mask"])
@@ -178,14 +185,35 @@ class BatchIndex:
                     keep = d >= 0                      # words beyond len_cnt never reach multi2one's consumed state
                     s, l, d, rows = s[keep], l[keep], d[keep].astype(np.int32), idx.W
                 spans.append((s, l, d, rows))
-            cat = np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32)
+            self._spans_host = (np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32),
+                                [(len(t[0]), t[3]) for t in spans])
+            self.packed.group_index = None             # (N, L) maps were only needed for the spans: keep the pickle small
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        if self.device is not None and self.device == torch.device(device):
+            return self
+        self.device = torch.device(device)
+        host = self.ocr.pack_host() + self.od.pack_host()
+        sizes = [len(a) for a in host]
+        buf = torch.from_numpy(np.concatenate(host)).to(self.device, non_blocking=True) if sum(sizes) else torch.zeros(0, dtype=torch.long, device=self.device)
+        parts = list(torch.split(buf, sizes))
+        n = len(ItemIndex._FIELDS)
+        self.ocr.bind(parts[:n])
+        self.od.bind(parts[n:])
+        self.ocr_mask = torch.from_numpy(self.ocr.mask).to(self.device, non_blocking=True)
+        self.od_mask = torch.from_numpy(self.od.mask).to(self.device, non_blocking=True)
+        if self.packed is not None:
+            self.packed.bind(self.device)
+            cat, shapes = self._spans_host
             dev = torch.from_numpy(cat).to(self.device, non_blocking=True)
             o = 0
             self.spans = []
-            for s, l, d, rows in spans:
-                W = len(s)
+            for W, rows in shapes:
                 self.spans.append((dev[o:o + W], dev[o + W:o + 2 * W], dev[o + 2 * W:o + 3 * W], rows))
                 o += 3 * W
+        return self
 
 
 def to_device(batch, device):

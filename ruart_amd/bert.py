@@ -107,7 +107,8 @@ class PackedTokens:
     ``pack=True`` keeps only mask==1 positions; ``pack=False`` keeps every position and turns the mask into the
     reference's additive -10000 key bias (exact reference semantics for arbitrary masks)."""
 
-    def __init__(self, groups, device, pack=True, mfma_long=True):
+    def __init__(self, groups, device=None, pack=True, mfma_long=True):
+        """Host part (numpy only; picklable, so it can run in DataLoader workers) + ``bind(device)`` when a device is given."""
         ids_l, pos_l, len_l, bias_l = [], [], [], []
         self.group_index = []            # per group: (N, L) int32 packed index of each kept position, -1 if dropped
         base = 0
@@ -149,7 +150,25 @@ class PackedTokens:
         self.n_seq = len(lens)
         self.max_len = int(lens.max())
         self.sum_len_sq = float((lens.astype(np.float64) ** 2).sum())
-        dev = torch.from_numpy(host).to(device, non_blocking=True)
+        self.host = host
+        self.bias_host = np.concatenate(bias_l) if not pack else None
+        self.buf = None
+        if device is not None:
+            self.bind(device)
+
+    _DEVICE_FIELDS = ("buf", "ids", "pos", "tok_lo", "tok_hi", "blk", "lblk", "key_bias", "c_batch", "_layers", "_event", "_set")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._DEVICE_FIELDS}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.buf = None
+
+    def bind(self, device):
+        """One H2D copy of the int32 descriptor buffer; builds the C struct the encoder entry point takes."""
+        T, Tp, nb, nlb = self.T, self.Tp, self.n_blocks, self.n_long_blocks
+        dev = torch.from_numpy(self.host).to(device, non_blocking=True)
         self.buf = dev
         o = 0
         self.ids = dev[o:o + Tp]; o += Tp
@@ -160,8 +179,8 @@ class PackedTokens:
         o += 4 * nb
         self.lblk = [dev[o + i * nlb:o + (i + 1) * nlb] for i in range(4)]
         self.key_bias = None
-        if not pack:
-            self.key_bias = torch.from_numpy(np.concatenate(bias_l)).to(device)
+        if self.bias_host is not None:
+            self.key_bias = torch.from_numpy(self.bias_host).to(device)
         b = hip.BertBatchC()
         b.n_tokens, b.n_rows, b.n_blocks = T, Tp, nb
         b.ids, b.pos_ids = self.ids.data_ptr(), self.pos.data_ptr()
@@ -171,6 +190,7 @@ class PackedTokens:
         b.n_long_blocks = nlb
         b.lblk_q0, b.lblk_q1, b.lblk_k0, b.lblk_k1 = [t.data_ptr() if nlb else None for t in self.lblk]
         self.c_batch = b
+        return self
 
     @staticmethod
     def _plan_blocks(lens, cu, mfma_long=True):

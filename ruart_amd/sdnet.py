@@ -250,7 +250,12 @@ class SDNet(nn.Module):
         """Build (or fetch) the per-batch index vectors and the packed BERT stream; cached on the batch dict."""
         bi = q_list.get("_ruart_index")
         if bi is None or bi.device != self.device:
-            bi = BatchIndex(q_list, ocr_list, od_list, self.opt, self.device, bert=self.Bert)
+            host = q_list.get("_ruart_host_index")          # built by VQA_collate(prepare_index=True) in a loader worker
+            want = (self.Bert.pack, self.Bert.weights.dtype != 0)
+            if host is not None and getattr(host, "plan", None) == want:
+                bi = host.to(self.device)
+            else:
+                bi = BatchIndex(q_list, ocr_list, od_list, self.opt, self.device, bert=self.Bert)
             q_list["_ruart_index"] = bi
         return bi
 

@@ -99,8 +99,9 @@ class SDNetTrainer(BaseTrainer):
             self.grad_sync.broadcast_parameters()
 
     def ToCUDA(self, batch):
-        """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host
-        copies, before the tensors move."""
+        """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host copies,
+        before the tensors move - unless the batch already carries them (``VQA_collate(opt, prepare_index=True)`` builds the
+        host part in the DataLoader workers; then this is copies only)."""
         q, ocr, od = batch[0], batch[1], batch[2]
         if hasattr(self, "network"):
             self.network.prepare(q, ocr, od)

@@ -146,6 +146,23 @@ def test_encoder_prefetch_is_bitwise_equivalent():
         assert torch.equal(pa[n], pb[n]), n
 
 
+def test_host_index_from_collate_gives_the_same_forward(golden):
+    """A batch whose index was prepared by VQA_collate(prepare_index=True) (and pickled, as a DataLoader worker would) must
+    produce bit-identical scores to one prepared inside ToCUDA."""
+    import pickle
+    from ruart_amd.batch import BatchIndex
+    net, opt = build(golden, "fp16")
+    net.eval()
+    b1 = synth.synthetic_batch(opt, 3, seed=5, n_q=9, n_ocr=17, n_od=4, bert_vocab=2000, ragged=True)
+    b2 = synth.synthetic_batch(opt, 3, seed=5, n_q=9, n_ocr=17, n_od=4, bert_vocab=2000, ragged=True)
+    b2[0]["_ruart_host_index"] = pickle.loads(pickle.dumps(BatchIndex(b2[0], b2[1], b2[2], opt)))
+    with torch.no_grad():
+        s1, _ = net(b1[0], b1[1], b1[2])
+        s2, _ = net(b2[0], b2[1], b2[2])
+    assert b2[0]["_ruart_index"] is b2[0]["_ruart_host_index"]
+    assert torch.equal(s1, s2)
+
+
 def test_variational_dropout_contract():
     """Layers.py:23-30: one mask per (row, feature) shared over time, scaled by 1/(1-p)."""
     import ruart_amd.layers as L

@@ -187,3 +187,25 @@ def test_word_spans_follow_reference_pooling_rules():
     assert s.tolist() == [1, 2] and n.tolist() == [1, 2] and d.tolist() == [0, 1] and rows == 8
     with pytest.raises(ValueError):
         word_spans(p, 0, [[[4, 7]], [1, 1]], np.array([[1, 0, 0, 0], [0, 0, 0, 0]], dtype=bool))   # span runs into padding
+
+
+def test_collate_can_prepare_the_batch_index_in_a_worker():
+    """VQA_collate(prepare_index=True) builds the host part of BatchIndex (numpy only): it must survive pickling (DataLoader
+    workers hand batches over that way) and equal the index SDNet.prepare would build itself."""
+    import pickle
+    from ruart_amd.batch import BatchIndex
+    opt = default_opt()
+    samples = _samples_like_generator(opt, 3, 5)
+    q, ocr, od, gt, extra = VQA_collate(opt, prepare_index=True).VQA_collate_fun(samples)
+    host = pickle.loads(pickle.dumps(q["_ruart_host_index"]))
+    q2, ocr2, od2, _, _ = VQA_collate(opt).VQA_collate_fun(samples)
+    ref = BatchIndex(q2, ocr2, od2, opt)
+    assert host.plan == ref.plan == (True, True)
+    assert np.array_equal(host.packed.host, ref.packed.host) and host.packed.T == ref.packed.T
+    assert np.array_equal(host._spans_host[0], ref._spans_host[0]) and host._spans_host[1] == ref._spans_host[1]
+    for a, b in ((host.ocr, ref.ocr), (host.od, ref.od)):
+        for f in a._FIELDS:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert a.n_active == b.n_active and np.array_equal(a.mask, b.mask)
+    dev = host.to("cpu")                                            # binding works on any torch device
+    assert dev.packed.ids.numel() == dev.packed.Tp and len(dev.spans) == 3 and dev.ocr.dev["flat_word"].dtype == torch.int64

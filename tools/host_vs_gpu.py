@@ -52,3 +52,12 @@ t1 = time.perf_counter()
 tr.ToCUDA(b); torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("synthetic batch gen %.1f ms; ToCUDA (index prep + packing + H2D) %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+# the same with the host index already built (what VQA_collate(opt, prepare_index=True) does inside a DataLoader worker)
+from ruart_amd.batch import BatchIndex
+b = synth.synthetic_batch(opt, 64, seed=98, n_q=30, n_ocr=100, n_od=36)
+t0 = time.perf_counter()
+b[0]["_ruart_host_index"] = BatchIndex(b[0], b[1], b[2], opt)
+t1 = time.perf_counter()
+tr.ToCUDA(b); torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host index in the collate worker %.1f ms; ToCUDA with it (H2D only) %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
