@@ -177,6 +177,16 @@ int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* a
  * once per step instead of one device->host sync per op.  Pass NULL to disable. */
 int ruart_set_nan_flag(int* flag);
 
+/* fp32 GEMM of the SDNet trunk on the 16-bit matrix cores (csrc/sdnet_gemm.hip): C[M,N] = A(M,K) . B(K,N) (+ bias[N]), every
+ * fp32 element split into two bf16 (hi + lo) and the product taken as hi.hi + hi.lo + lo.hi with fp32 accumulation (relative
+ * error ~2^-16 per product).  Replaces the library GEMMs behind torch.mm / addmm at Models/Layers.py:155, 166, 226-227 and in
+ * their backward.  A element (m,k) at A[m*sam + k*sak], B element (k,n) at B[k*sbk + n*sbn]; each operand needs ONE unit
+ * stride, so x.W^T, dY.W and dY^T.X all fit.  Products with a small output and a long reduction are split along K: ask
+ * ruart_gemm_x3_plan for the workspace size first (0 when not split) and pass a workspace of at least that many bytes. */
+int ruart_gemm_x3_plan(int M, int N, int K, int* splitk, size_t* ws_bytes);
+int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
+                  float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, void* stream);
+
 /* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
  * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for
  * the trunk's short kernels.  Off by default - it did not pay on MI355X.  n_cus <= 0 or >= the device's CU count creates an

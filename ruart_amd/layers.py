@@ -152,7 +152,7 @@ def lstm_layer_wide(x, w_ih, w_hh, b_ih, b_hh, *reverse_params):
     is called through the generic module API).  T is short (<= max words per item)."""
     def run(w_ih, w_hh, b_ih, b_hh, rev):
         B, T, _ = x.shape
-        xp = torch.addmm(b_ih + b_hh, x.reshape(B * T, -1), w_ih.t()).view(B, T, -1)
+        xp = ops.linear(x, w_ih, b_ih + b_hh)
         h = x.new_zeros(B, w_hh.shape[1])
         c = x.new_zeros(B, w_hh.shape[1])
         ys = [None] * T
@@ -185,7 +185,7 @@ class AttentionScore(nn.Module):
         """W x1, W x2 (after input dropout); the ReLU and the diagonal are applied inside the fused attention kernel."""
         x1 = dropout(x1, p=dropout_p, training=self.training)
         x2 = dropout(x2, p=dropout_p, training=self.training)
-        return self.linear(x1), self.linear(x2)
+        return ops.linear(x1, self.linear.weight), ops.linear(x2, self.linear.weight)
 
     def forward(self, x1, x2):
         p1, p2 = self.project_raw(x1, x2)

@@ -4,6 +4,8 @@ Each Function's forward AND backward launch hand-written HIP kernels through the
 projections around them (x W^T) go to torch.matmul (rocBLAS), as the design allows for library GEMMs.
 There is no CPU path: a CPU tensor raises ``hip.HipError``.
 """
+import ctypes
+
 import torch
 
 from . import hip
@@ -11,8 +13,8 @@ from . import hip
 _WS = {}
 
 
-def _scratch(device, n):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)      # per stream: branches run concurrently
+def _scratch(device, n, tag=""):
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)      # per stream: branches run concurrently
     t = _WS.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 4096), dtype=torch.float32, device=device)
@@ -127,6 +129,74 @@ def whole_layer_norm(x, eps=1e-5):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# Dense projections of the trunk.  "x3": fp32 operands split into bf16 hi + lo inside the kernel, three 16-bit MFMA products
+# (ruart_gemm_x3, relative error ~2^-16 per product, ~5x the fp32-MFMA rate); "fp32": torch.mm / addmm (rocBLAS, exact fp32
+# MFMA) - the validation mode (SDNet sets it when opt['bert_precision'] == 'fp32') and the fallback for tiny products.
+trunk_gemm = "x3"
+_X3_MIN_FLOP = 2 * 64 * 64 * 64
+
+
+def _one_unit_stride(t):
+    """A 2-D view whose memory is row- or column-contiguous (what ruart_gemm_x3 addresses); copies only when it is neither."""
+    r, c = t.shape
+    if t.stride(1) == 1 and (t.stride(0) >= c or r == 1):
+        return t
+    if t.stride(0) == 1 and (t.stride(1) >= r or c == 1):
+        return t
+    return t.contiguous()
+
+
+def mm(a, b, bias=None, mode=None):
+    """a (M,K) . b (K,N) (+ bias (N,)) -> (M,N) fp32, on the split-bf16 MFMA kernel when the product is big enough.
+    ``mode``: 'x3' | 'fp32'; default = the module-level ``trunk_gemm`` (autograd Functions pass the mode of their forward)."""
+    M, K = a.shape
+    N = b.shape[1]
+    if (mode or trunk_gemm) != "x3" or not a.is_cuda or a.dtype != torch.float32 or b.dtype != torch.float32 or 2 * M * N * K < _X3_MIN_FLOP:
+        return torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
+    lib = hip.load()
+    a, b = _one_unit_stride(a), _one_unit_stride(b)
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    nbytes = ctypes.c_size_t(0)
+    hip.check(lib.ruart_gemm_x3_plan(M, N, K, None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
+    ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
+    sam, sak = (a.stride(0), 1) if a.stride(1) == 1 else (1, a.stride(1))
+    sbk, sbn = (1, b.stride(1)) if b.stride(0) == 1 and b.stride(1) != 1 else (b.stride(0), 1)
+    if b.stride(0) == 1 and b.stride(1) == 1:            # K == 1 or N == 1: either description is valid
+        sbk, sbn = b.stride(0), 1
+    hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(out), N, M, N, K, hip.ptr(ws),
+                                nbytes.value, hip.stream_ptr()), "ruart_gemm_x3")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b) with x (rows, K), W (N, K): forward, dX = dY W and dW = dY^T X all on ruart_gemm_x3."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.mode = trunk_gemm
+        return mm(x, w.t(), b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = mm(gy, w, mode=ctx.mode) if ctx.needs_input_grad[0] else None
+        gw = mm(gy.t(), x, mode=ctx.mode) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def linear(x, w, b=None):
+    """F.linear for fp32 device tensors of any leading shape, through ``mm``."""
+    if trunk_gemm != "x3" or not x.is_cuda:
+        return torch.nn.functional.linear(x, w, b)
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b)
+    return y.view(*lead, w.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------
 class _LstmRecurrence(torch.autograd.Function):
     """Sequential part of one (Bi)LSTM layer.  xproj (B,T,ndir*4h) already holds x W_ih^T + b_ih + b_hh."""
 
@@ -145,6 +215,7 @@ class _LstmRecurrence(torch.autograd.Function):
         hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), B, T, h, ndir,
                                      hip.stream_ptr()), "ruart_lstm_fwd")
         ctx.ndir, ctx.h = ndir, h
+        ctx.mode = trunk_gemm
         ctx.save_for_backward(w_hh, gates, cells, y)
         return y
 
@@ -169,7 +240,7 @@ class _LstmRecurrence(torch.autograd.Function):
                 else:
                     hprev[:, :-1] = hd[:, 1:]
             da = gx[:, :, d * 4 * h:(d + 1) * 4 * h].reshape(B * T, 4 * h)
-            gw[d] = da.t() @ hprev.reshape(B * T, h)
+            gw[d] = mm(da.t(), hprev.reshape(B * T, h), mode=ctx.mode)
         return gx, gw, None
 
 
@@ -183,7 +254,7 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None,
         whh = torch.stack([w_hh, w_hh_r], 0)
     else:
         w, b, whh = w_ih, b_ih + b_hh, w_hh.unsqueeze(0)
-    xproj = torch.addmm(b, x.reshape(-1, x.shape[-1]), w.t()).view(x.shape[0], x.shape[1], -1)
+    xproj = linear(x, w, b)
     return _LstmRecurrence.apply(xproj.contiguous(), whh.contiguous(), 2 if bidir else 1)
 
 

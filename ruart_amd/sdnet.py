@@ -333,7 +333,7 @@ class SDNet(nn.Module):
         rnn = self.multi2one.rnns[0]
         if L.dropout_p > 0:
             x_words = row_dropout(x_words, d["item_of_word"], idx.N, L.dropout_p, self.training)
-        xproj = torch.addmm(rnn.bias_ih_l0 + rnn.bias_hh_l0, x_words, rnn.weight_ih_l0.t())
+        xproj = ops.linear(x_words, rnn.weight_ih_l0, rnn.bias_ih_l0 + rnn.bias_hh_l0)
         Hh = rnn.weight_hh_l0.shape[1]
         steps = torch.split(xproj[d["step_rows"]], idx.n_active)
         h0 = x_words.new_zeros(idx.N, Hh)
@@ -347,6 +347,8 @@ class SDNet(nn.Module):
             raise NotImplementedError("att_score output is not part of the hot path")
         opt = self.opt
         dev = self.device
+        # trunk projections: split-bf16 MFMA kernel, or the library's exact fp32 GEMM in the fp32 validation mode
+        ops.trunk_gemm = opt.get("ruart_trunk_gemm", "fp32" if opt.get("bert_precision", "fp16") == "fp32" else "x3")
         bi = self.prepare(q_list, ocr_list, od_list)
         if self.training or self.drop_emb:
             L.mask_bank.begin_step(dev)

@@ -385,3 +385,59 @@ def test_wide_lstm_module_path():
     yr.backward(gy)
     y.backward(gy.to(d))
     assert maxerr(y, yr) < 1e-5 and maxerr(x.grad, xc.grad) < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(6400, 250, 300), (500, 125, 6400), (300, 300, 14336), (1107, 1200, 300), (129, 131, 33),
+                                   (64, 500, 250), (2304, 1000, 1250), (17, 5, 4097)])
+def test_gemm_x3_all_layouts(M, N, K):
+    """ruart_gemm_x3 (fp32 GEMM as three bf16 MFMA products) against float64, for the four stride combinations the trunk uses
+    (x W^T, dY W, dY^T X and the remaining one), odd sizes (scalar load path, partial tiles, K tail), split-K shapes and a bias.
+    Error bound: each product carries <= 2^-16 relative error -> |err| <= ~2e-5 * sum_k |a||b|; repeated launches are
+    bit-identical (split-K sums its slices in a fixed order)."""
+    from ruart_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ b.double() + bias.double()
+    bound = 2.5e-5 * (a.abs().double() @ b.abs().double()) + 1e-6
+    ad, bd, biasd = a.cuda(), b.cuda(), bias.cuda()
+    assert ops.trunk_gemm == "x3"
+    outs = []
+    for a_t in (False, True):
+        for b_t in (False, True):
+            av = ad.t().contiguous().t() if a_t else ad              # same values, column-major memory
+            bv = bd.t().contiguous().t() if b_t else bd
+            c = ops.mm(av, bv, biasd)
+            c2 = ops.mm(av, bv, biasd)
+            assert torch.equal(c, c2)
+            err = (c.double().cpu() - ref).abs()
+            assert bool((err <= bound).all()), (a_t, b_t, float((err / bound).max()))
+            outs.append(c)
+    for c in outs[1:]:
+        assert torch.equal(c, outs[0])                               # the memory layout does not change the arithmetic
+    # views with a row stride larger than the row (slices of a wider matrix) and an unaligned base
+    wide = torch.randn(M, K + 7, generator=g).cuda()
+    av = wide[:, 3:3 + K]
+    c = ops.mm(av, bd)
+    err = (c.double().cpu() - av.double().cpu() @ b.double()).abs()
+    assert bool((err <= 2.5e-5 * (av.abs().double().cpu() @ b.abs().double()) + 1e-6).all())
+
+
+def test_linear_x3_autograd_matches_fp32():
+    from ruart_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 100, 300, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(1000, 300, generator=g) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(1000, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(64, 100, 1000, generator=g).cuda()
+    y = ops.linear(x, w, b)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    y2 = torch.nn.functional.linear(x, w, b)
+    y2.backward(gy)
+    for name, a_, r_ in zip(("y", "gx", "gw", "gb"), got, (y2.detach(), x.grad, w.grad, b.grad)):
+        scale = float(r_.abs().max())
+        assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
