@@ -182,8 +182,10 @@ int ruart_set_nan_flag(int* flag);
  * error ~2^-16 per product).  Replaces the library GEMMs behind torch.mm / addmm at Models/Layers.py:155, 166, 226-227 and in
  * their backward.  A element (m,k) at A[m*sam + k*sak], B element (k,n) at B[k*sbk + n*sbn]; each operand needs ONE unit
  * stride, so x.W^T, dY.W and dY^T.X all fit.  Products with a small output and a long reduction are split along K: ask
- * ruart_gemm_x3_plan for the workspace size first (0 when not split) and pass a workspace of at least that many bytes. */
-int ruart_gemm_x3_plan(int M, int N, int K, int* splitk, size_t* ws_bytes);
+ * ruart_gemm_x3_plan (same M, N, K and operand layouts) for the workspace size first (0 when not split) and pass a workspace of
+ * at least that many bytes. */
+int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, int b_k_contiguous /* sbk == 1 */, int* splitk,
+                       size_t* ws_bytes);
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
                   float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, void* stream);
 

@@ -9,8 +9,8 @@
 // with A element (m,k) at A[m*sam + k*sak] and B element (k,n) at B[k*sbk + n*sbn] - the forward x.W^T (both K-contiguous),
 // dX = dY.W (B is N-contiguous) and dW = dY^T.X (A is M-contiguous, B is N-contiguous) all go through one entry point.
 //
-// Tile 128x128x32, 4 waves of 64x64 (4x4 MFMA tiles, 64 accumulator VGPRs), register-staged loads (the split happens on
-// the way to LDS), two LDS stages, two workgroups per CU.  A K-contiguous operand is stored [row][32 k] with two rows per
+// Tile 128x128x32 (4 waves of 64x64, two workgroups per CU) or 256x256x32 (8 waves of 128x64, one per CU) chosen per
+// problem, register-staged loads (the split happens on the way to LDS), two LDS stages.  A K-contiguous operand is stored [row][32 k] with two rows per
 // 128-byte line and the XOR swizzle of gemm.hip (conflict-free ds_read_b128); an M/N-contiguous operand is stored as it
 // comes, [k][128 m], and its fragments are fetched with ds_read_b64_tr_b16 (the hardware transpose), so neither layout
 // needs a transposing store.  Small outputs with a long reduction (the weight gradients: e.g. 500x125 over K = 6400) are
@@ -19,11 +19,16 @@
 #include "common.h"
 #include "ruart_hip.h"
 
-#define XBM 128
-#define XBN 128
 #define XBK 32
-#define X_ARR 8704                 // bytes per LDS operand image: max(128 rows * 64 B, 32 k-rows * 272 B)
-#define X_TRS 272                  // row stride of the [k][m] image (256 B + 16 B pad)
+// Square tiles of TM = 128 (4 waves, two workgroups per CU) or 256 (8 waves, one workgroup per CU: twice the flops per
+// byte pulled from L2 - the 128 tile is bound by that delivery, ~35 GB/s per CU, at 220 TFLOP/s-equivalent).
+template <int TM> struct XT {
+  static constexpr int THREADS = TM * 2;                 // 64 x (2 waves along M) x (TM/64 waves along N)
+  static constexpr int WN = TM / 64;                     // waves along N, 64 columns each
+  static constexpr int JT = TM / 32;                     // 16-row MFMA tiles per wave along M (wave = TM/2 rows)
+  static constexpr int TRS = TM * 2 + 16;                // row stride of the [k][rows] image (+16 B pad)
+  static constexpr int ARR = 32 * TRS;                   // bytes per LDS operand image (>= TM rows * 64 B)
+};
 
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short xtr16x4_t;
 typedef __attribute__((address_space(3))) xtr16x4_t* xtr_ptr_t;
@@ -35,15 +40,16 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   lo = (bf16_t)(x - (float)hi);
 }
 
-// byte offset of element (row r, k) in the swizzled [row][32 k] image: two rows share a 128-byte line
-__device__ __forceinline__ int kc_off(int r, int chunk /*16-byte chunk of the row, 0..3*/) {
+// byte offset of 16-byte chunk `chunk` (8 k values) of row r in the swizzled [row][32 k] image: two rows share a 128-byte
+// line, chunk XOR line as in gemm.hip - conflict-free for ds_read_b128 fragment reads.
+__device__ __forceinline__ int kc_off(int r, int chunk /*0..3*/) {
   const int line = r >> 1;
   return line * 128 + ((((r & 1) * 4 + chunk) ^ (line & 7)) << 4);
 }
 
 // MODE 0: the operand's K index is contiguous in memory (element (row, k) at P[row*srow + k]);
 // MODE 1: its row index is contiguous (element (row, k) at P[k*sk + row]).
-template <int MODE, bool VEC>
+template <int TM, int MODE, bool VEC>
 struct Stager {
   float v[16];
 
@@ -53,7 +59,7 @@ struct Stager {
       const int kq = (tid & 7) * 4;                   // 4 consecutive k
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int r = r0 + p * 32 + (tid >> 3), k = k0 + kq;
+        const int r = r0 + p * (TM / 4) + (tid >> 3), k = k0 + kq;
         const float* src = P + (long)r * srow + k;
         if (r < rows && VEC && k + 3 < K) {
           const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
@@ -64,10 +70,10 @@ struct Stager {
         }
       }
     } else {
-      const int m4 = (tid & 31) * 4;                  // 4 consecutive rows
+      const int m4 = (tid % (TM / 4)) * 4;            // 4 consecutive rows
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int k = k0 + 2 * (tid >> 5) + (p & 1) + 16 * (p >> 1), r = r0 + m4;
+        const int k = k0 + 2 * (tid / (TM / 4)) + (p & 1) + 16 * (p >> 1), r = r0 + m4;
         const float* src = P + (long)k * sk + r;
         if (k < K && VEC && r + 3 < rows) {
           const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
@@ -93,11 +99,11 @@ struct Stager {
       }
       int off;
       if (MODE == 0) {
-        const int r = p * 32 + (tid >> 3), kq = tid & 7;                 // 4 k values = 8 bytes inside chunk kq >> 1
+        const int r = p * (TM / 4) + (tid >> 3), kq = tid & 7;           // 4 k values = 8 bytes inside chunk kq >> 1
         off = kc_off(r, kq >> 1) + (kq & 1) * 8;
       } else {
-        const int k = 2 * (tid >> 5) + (p & 1) + 16 * (p >> 1);          // 4 rows = 8 bytes of k-row k
-        off = k * X_TRS + (tid & 31) * 8;
+        const int k = 2 * (tid / (TM / 4)) + (p & 1) + 16 * (p >> 1);    // 4 rows = 8 bytes of k-row k
+        off = k * XT<TM>::TRS + (tid % (TM / 4)) * 8;
       }
       *reinterpret_cast<bf16x4_t*>(hi_img + off) = h;
       *reinterpret_cast<bf16x4_t*>(lo_img + off) = l;
@@ -105,46 +111,49 @@ struct Stager {
   }
 };
 
-// fragment of MFMA tile `t16` (16 rows starting at row base) for lane (fr, fq): 8 consecutive k = 8 fq .. 8 fq + 7
-template <int MODE>
+// Fragment of one 16-row MFMA tile for lane (fr = lane & 15, fq = lane >> 4): 8 consecutive k = 8 fq .. 8 fq + 7.
+// (Tried: the permuted order k = {4g.., 16+4g..} with a 32-mod-256 row stride makes the transposed reads conflict-free, but
+// turns the row read into two ds_read_b64 - measured 7 % slower over the trunk's shapes, so the natural order stays.)
+template <int TM, int MODE>
 __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, int fq) {
   if (MODE == 0) {
     return *reinterpret_cast<const bf16x8_t*>(img + kc_off(row_base + fr, fq));
   } else {
     // transposed fetch: lane 4q+p of a 16-lane group supplies k-row q, rows 4p..4p+3, and receives row (lane & 15), k-rows 0..3
-    const char* base = img + (8 * fq + (fr >> 2)) * X_TRS + (row_base + (fr & 3) * 4) * 2;
+    const char* base = img + (8 * fq + (fr >> 2)) * XT<TM>::TRS + (row_base + (fr & 3) * 4) * 2;
     union { struct { xtr16x4_t a, b; } s; bf16x8_t f; } u;
     u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xtr_ptr_t)base);
-    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xtr_ptr_t)(base + 4 * X_TRS));
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xtr_ptr_t)(base + 4 * XT<TM>::TRS));
     return u.f;
   }
 }
 
-template <int AMODE, int BMODE, bool VECA, bool VECB>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
-                                                         long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
-                                                         int ldc, int M, int N, int K, int splitk, float* __restrict__ ws) {
+template <int TM, int AMODE, int BMODE, bool VECA, bool VECB>
+__global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
+                                                            long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
+                                                            int ldc, int M, int N, int K, int splitk, float* __restrict__ ws) {
+  typedef XT<TM> T;
+  constexpr int ARR = T::ARR, JT = T::JT;
   extern __shared__ __attribute__((aligned(1024))) char smem[];          // 2 stages x (A_hi, A_lo, B_hi, B_lo)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / T::WN, wn = wave % T::WN;                        // 2 x WN waves; a wave owns (TM/2) rows x 64 columns
   const int fr = lane & 15, fq = lane >> 4;
-  const int ntn = (N + XBN - 1) / XBN, ntm = (M + XBM - 1) / XBM;
-  const int ntiles = ntm * ntn;
+  const int ntn = (N + TM - 1) / TM;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id / splitk, slice = id - tile * splitk;             // the slices of a tile are neighbours: same XCD / L2
-  const int m0 = (tile / ntn) * XBM, n0 = (tile % ntn) * XBN;
+  const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * TM;
   const int ksteps = (K + XBK - 1) / XBK;
   const int per = (ksteps + splitk - 1) / splitk;
   const int kbeg = slice * per, kend = min(ksteps, kbeg + per);
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][JT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  Stager<AMODE, VECA> sa;
-  Stager<BMODE, VECB> sb;
+  Stager<TM, AMODE, VECA> sa;
+  Stager<TM, BMODE, VECB> sb;
   // operand A: rows = m (stride sam) in MODE 0 / k-rows of stride sak in MODE 1; operand B: "rows" = n
   const long a_srow = sam, a_sk = sak, b_srow = sbn, b_sk = sbk;
   if (kbeg < kend) {
@@ -152,40 +161,44 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict
     sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid);
   }
   for (int t = kbeg; t < kend; ++t) {
-    char* st = smem + ((t - kbeg) & 1) * (4 * X_ARR);
-    sa.store(st, st + X_ARR, tid);
-    sb.store(st + 2 * X_ARR, st + 3 * X_ARR, tid);
+    char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
+    sa.store(st, st + ARR, tid);
+    sb.store(st + 2 * ARR, st + 3 * ARR, tid);
     __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
     if (t + 1 < kend) {
       sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid);
       sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid);
     }
-    bf16x8_t ah[4], al[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ah[j] = frag<AMODE>(st, wm * 64 + j * 16, fr, fq);
-      al[j] = frag<AMODE>(st + X_ARR, wm * 64 + j * 16, fr, fq);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8_t bh = frag<BMODE>(st + 2 * X_ARR, wn * 64 + i * 16, fr, fq);
-      const bf16x8_t bl = frag<BMODE>(st + 3 * X_ARR, wn * 64 + i * 16, fr, fq);
+    for (int jh = 0; jh < JT / 4; ++jh) {             // four m-tiles at a time keeps the fragment registers at 40
+      bf16x8_t ah[4], al[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[i][j] = mfma_16x16x32(bl, ah[j], acc[i][j]);      // small terms first
-        acc[i][j] = mfma_16x16x32(bh, al[j], acc[i][j]);
-        acc[i][j] = mfma_16x16x32(bh, ah[j], acc[i][j]);
+        ah[j] = frag<TM, AMODE>(st, wm * (TM / 2) + (jh * 4 + j) * 16, fr, fq);
+        al[j] = frag<TM, AMODE>(st + ARR, wm * (TM / 2) + (jh * 4 + j) * 16, fr, fq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t bh = frag<TM, BMODE>(st + 2 * ARR, wn * 64 + i * 16, fr, fq);
+        const bf16x8_t bl = frag<TM, BMODE>(st + 3 * ARR, wn * 64 + i * 16, fr, fq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4_t& c = acc[i][jh * 4 + j];
+          c = mfma_16x16x32(bl, ah[j], c);            // small terms first
+          c = mfma_16x16x32(bh, al[j], c);
+          c = mfma_16x16x32(bh, ah[j], c);
+        }
       }
     }
   }
 
   if (splitk > 1) {
     // park the partial tile, thread-major ([i][j][tid] x 4 floats): x3_reduce_kernel re-reads it with the same mapping
-    float* slab = ws + ((size_t)tile * splitk + slice) * (XBM * XBN);
+    float* slab = ws + ((size_t)tile * splitk + slice) * (TM * TM);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * 4 + j) * 256 + tid) * 4) = acc[i][j];
+      for (int j = 0; j < JT; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * JT + j) * T::THREADS + tid) * 4) = acc[i][j];
     return;
   }
   // lane owns rows m = .. + j*16 + fr and four consecutive columns n = .. + i*16 + fq*4 + r
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict
       for (int r = 0; r < 4; ++r) bv[r] = (n + r < N) ? bias[n + r] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + fr;
+    for (int j = 0; j < JT; ++j) {
+      const int m = m0 + wm * (TM / 2) + j * 16 + fr;
       if (m >= M || n >= N) continue;
       const f32x4_t v = acc[i][j] + bv;
       float* dst = C + (size_t)m * ldc + n;
@@ -213,56 +226,81 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const float* __restrict
       }
     }
   }
-  (void)ntiles;
 }
 
 // second launch of a split-K product: one thread per 4 output floats adds the slices in slice order and writes C (+ bias)
-__global__ __launch_bounds__(256) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ C,
-                                                        int ldc, int M, int N, int splitk) {
+template <int TM>
+__global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                           float* __restrict__ C, int ldc, int M, int N, int splitk) {
+  typedef XT<TM> T;
+  constexpr int JT = T::JT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-  const int ntn = (N + XBN - 1) / XBN;
-  const int tile = blockIdx.x >> 4, ij = blockIdx.x & 15, i = ij >> 2, j = ij & 3;
-  const int m = (tile / ntn) * XBM + wm * 64 + j * 16 + fr, n = (tile % ntn) * XBN + wn * 64 + i * 16 + fq * 4;
+  const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 15, fq = lane >> 4;
+  const int ntn = (N + TM - 1) / TM;
+  const int tile = blockIdx.x / (4 * JT), ij = blockIdx.x % (4 * JT), i = ij / JT, j = ij % JT;
+  const int m = (tile / ntn) * TM + wm * (TM / 2) + j * 16 + fr, n = (tile % ntn) * TM + wn * 64 + i * 16 + fq * 4;
   if (m >= M || n >= N) return;
-  const float* p = ws + (size_t)tile * splitk * (XBM * XBN) + (ij * 256 + tid) * 4;
+  const float* p = ws + (size_t)tile * splitk * (TM * TM) + (ij * T::THREADS + tid) * 4;
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-  for (int sl = 0; sl < splitk; ++sl) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)sl * (XBM * XBN));
+  for (int sl = 0; sl < splitk; ++sl) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)sl * (TM * TM));
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (n + r < N) C[(size_t)m * ldc + n + r] = s[r] + (bias ? bias[n + r] : 0.f);
 }
 
-int pick_splitk(int M, int N, int K) {
-  const int tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
+struct Plan { int tm, tiles, splitk; };
+
+// Tile size and K split.  The 256 tile wins when it still fills the chip (>= ~200 workgroups after the split); products with a
+// small output and a long reduction (weight gradients) are split along K, at least 4 steps of 32 per slice.
+Plan make_plan(int M, int N, int K, int amode, int bmode) {
   const int ksteps = (K + XBK - 1) / XBK;
-  if (tiles >= 160 || ksteps < 16) return 1;
-  int s = (448 + tiles - 1) / tiles;                   // aim at ~2 workgroups per CU
-  if (s > ksteps / 4) s = ksteps / 4;                  // at least 4 steps per slice
-  if (s > 64) s = 64;
-  return s < 1 ? 1 : s;
+  auto split_for = [&](int tiles) {
+    if (tiles >= 160 || ksteps < 16) return 1;
+    int s = (448 + tiles - 1) / tiles;                 // aim at ~2 workgroups of the small tile per CU
+    if (s > ksteps / 4) s = ksteps / 4;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+  };
+  const int t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  Plan p;
+  int s256 = 1;
+  if (t256 < 200 && ksteps >= 16) {
+    s256 = (256 + t256 - 1) / t256;
+    if (s256 > ksteps / 8) s256 = ksteps / 8;
+    if (s256 < 1) s256 = 1;
+  }
+  // padding waste of the big tile must stay moderate, and it needs enough workgroups
+  const double waste = (double)t256 * 65536.0 / ((double)M * N);
+  // (measured: with a transposed-read B operand the big tile re-reads B's fragments twice per step and loses: 231 vs 203 us)
+  if (bmode == 0 && (long long)M * N >= 4096LL * 1024 && t256 * s256 >= 192 && waste < 1.25) {
+    (void)amode;
+    p.tm = 256; p.tiles = t256; p.splitk = s256;
+  } else {
+    p.tm = 128; p.tiles = t128; p.splitk = split_for(t128);
+  }
+  return p;
 }
 
-template <int AM, int BM_, bool VA, bool VB>
+template <int TM, int AM, int BM_, bool VA, bool VB>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
-               int N, int K, int splitk, float* ws, hipStream_t s) {
-  auto kern = gemm_x3_kernel<AM, BM_, VA, VB>;
-  constexpr int lds = 2 * 4 * X_ARR;
+               int N, int K, const Plan& p, float* ws, hipStream_t s) {
+  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB>;
+  constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
-  const int tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
-  hipLaunchKernelGGL(kern, dim3(tiles * splitk), dim3(256), lds, s, A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws);
-  if (splitk > 1) hipLaunchKernelGGL(x3_reduce_kernel, dim3(tiles * 16), dim3(256), 0, s, ws, bias, C, ldc, M, N, splitk);
+  hipLaunchKernelGGL(kern, dim3(p.tiles * p.splitk), dim3(XT<TM>::THREADS), lds, s, A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K,
+                     p.splitk, ws);
+  if (p.splitk > 1)
+    hipLaunchKernelGGL(x3_reduce_kernel<TM>, dim3(p.tiles * 4 * XT<TM>::JT), dim3(XT<TM>::THREADS), 0, s, ws, bias, C, ldc, M, N, p.splitk);
 }
 
 }  // namespace
 
-extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int* splitk, size_t* ws_bytes) {
+extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b_k_contiguous, int* splitk, size_t* ws_bytes) {
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
-  const int s = pick_splitk(M, N, K);
-  const int tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
-  if (splitk) *splitk = s;
-  if (ws_bytes) *ws_bytes = s > 1 ? (size_t)tiles * s * XBM * XBN * sizeof(float) : 0;
+  const Plan p = make_plan(M, N, K, a_k_contiguous ? 0 : 1, b_k_contiguous ? 0 : 1);
+  if (splitk) *splitk = p.splitk;
+  if (ws_bytes) *ws_bytes = p.splitk > 1 ? (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float) : 0;
   return 0;
 }
 
@@ -272,25 +310,30 @@ extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const
   const int amode = (sak == 1) ? 0 : (sam == 1 ? 1 : -1);
   const int bmode = (sbk == 1) ? 0 : (sbn == 1 ? 1 : -1);
   if (amode < 0 || bmode < 0) return (int)hipErrorInvalidValue;        // one unit stride per operand
-  int splitk = pick_splitk(M, N, K);
-  const int tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
-  if (splitk > 1 && (!ws || ws_bytes < (size_t)tiles * splitk * XBM * XBN * sizeof(float))) return (int)hipErrorInvalidValue;
+  const Plan p = make_plan(M, N, K, amode, bmode);
+  if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) return (int)hipErrorInvalidValue;
   // 16-byte vector loads need an aligned base and a non-unit stride that is a multiple of 4 floats
   const bool va = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((amode == 0 ? sam : sak) & 3) == 0);
   const bool vb = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((bmode == 0 ? sbn : sbk) & 3) == 0);
   hipStream_t s = (hipStream_t)stream;
-#define X3(AM, BM_)                                                                                                               \
+#define X3V(TM, AM, BM_)                                                                                                          \
   do {                                                                                                                            \
-    if (va && vb) launch_x3<AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, s);       \
-    else if (va) launch_x3<AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, s);       \
-    else if (vb) launch_x3<AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, s);       \
-    else launch_x3<AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, s);              \
+    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
+    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
+    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
+    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                         \
+  } while (0)
+#define X3(AM, BM_)                 \
+  do {                              \
+    if (p.tm == 256) X3V(256, AM, BM_); \
+    else X3V(128, AM, BM_);         \
   } while (0)
   if (amode == 0 && bmode == 0) X3(0, 0);
   else if (amode == 0 && bmode == 1) X3(0, 1);
   else if (amode == 1 && bmode == 0) X3(1, 0);
   else X3(1, 1);
 #undef X3
+#undef X3V
   RUART_CHECK_LAUNCH();
   return 0;
 }

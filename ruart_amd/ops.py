@@ -156,13 +156,13 @@ def mm(a, b, bias=None, mode=None):
     lib = hip.load()
     a, b = _one_unit_stride(a), _one_unit_stride(b)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    nbytes = ctypes.c_size_t(0)
-    hip.check(lib.ruart_gemm_x3_plan(M, N, K, None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
-    ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
     sam, sak = (a.stride(0), 1) if a.stride(1) == 1 else (1, a.stride(1))
     sbk, sbn = (1, b.stride(1)) if b.stride(0) == 1 and b.stride(1) != 1 else (b.stride(0), 1)
     if b.stride(0) == 1 and b.stride(1) == 1:            # K == 1 or N == 1: either description is valid
         sbk, sbn = b.stride(0), 1
+    nbytes = ctypes.c_size_t(0)
+    hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
+    ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
     hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(out), N, M, N, K, hip.ptr(ws),
                                 nbytes.value, hip.stream_ptr()), "ruart_gemm_x3")
     return out

@@ -389,10 +389,11 @@ def test_wide_lstm_module_path():
 
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(6400, 250, 300), (500, 125, 6400), (300, 300, 14336), (1107, 1200, 300), (129, 131, 33),
-                                   (64, 500, 250), (2304, 1000, 1250), (17, 5, 4097)])
+                                   (64, 500, 250), (2304, 1000, 1250), (17, 5, 4097), (12800, 1200, 1388), (4096, 1100, 2048)])
 def test_gemm_x3_all_layouts(M, N, K):
     """ruart_gemm_x3 (fp32 GEMM as three bf16 MFMA products) against float64, for the four stride combinations the trunk uses
-    (x W^T, dY W, dY^T X and the remaining one), odd sizes (scalar load path, partial tiles, K tail), split-K shapes and a bias.
+    (x W^T, dY W, dY^T X and the remaining one), odd sizes (scalar load path, partial tiles, K tail), split-K shapes, both tile
+    sizes (the last two shapes take the 256x256 tile, the last one with a K split) and a bias.
     Error bound: each product carries <= 2^-16 relative error -> |err| <= ~2e-5 * sum_k |a||b|; repeated launches are
     bit-identical (split-K sums its slices in a fixed order)."""
     from ruart_amd import ops
@@ -415,8 +416,8 @@ def test_gemm_x3_all_layouts(M, N, K):
             err = (c.double().cpu() - ref).abs()
             assert bool((err <= bound).all()), (a_t, b_t, float((err / bound).max()))
             outs.append(c)
-    for c in outs[1:]:
-        assert torch.equal(c, outs[0])                               # the memory layout does not change the arithmetic
+    # (the tile size and the K split are chosen per layout, so different layouts may sum in a different order: each is held to
+    #  the bound above and to run-to-run bit equality, not to equality with the others)
     # views with a row stride larger than the row (slices of a wider matrix) and an unaligned base
     wide = torch.randn(M, K + 7, generator=g).cuda()
     av = wide[:, 3:3 + K]
