@@ -152,9 +152,11 @@ int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, 
  *   y     : (B, T, ndir*h)   direction d at column offset d*h; direction 1 runs t = T-1 .. 0
  *   gates : (B, T, ndir*4h)  post-activation i,f,g,o   } saved for backward when non-NULL
  *   cells : (B, T, ndir*h)   c_t                       }
+ *   hprev : (B, T, ndir*h)   h of the previous step of the same direction (0 at its first step): the right-hand operand of
+ *                            grad_W_hh = grad_xproj^T . hprev, so the caller needs no shifted copy of y
  * h <= 128, ndir in {1, 2}. */
-int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, int B, int T, int h, int ndir,
-                   void* stream);
+int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, float* hprev, int B, int T, int h,
+                   int ndir, void* stream);
 /* BPTT for the op above: grad_y (B,T,ndir*h) -> grad_xproj (B,T,ndir*4h) (gradient w.r.t. the gate pre-activations).
  * grad_W_hh = grad_xproj^T . h_prev, grad_W_ih = grad_xproj^T . x, grad_x = grad_xproj . W_ih are plain GEMMs done
  * by the caller. */

@@ -19,7 +19,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 __global__ __launch_bounds__(512) void lstm_fwd_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                        float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cells,
-                                                       int T, int h, int ndir, int* __restrict__ nan_flag) {
+                                                       float* __restrict__ hprev, int T, int h, int ndir, int* __restrict__ nan_flag) {
   __shared__ __attribute__((aligned(16))) float h_s[HP];
   __shared__ float pre_s[4 * HP];
   const int b = blockIdx.x, d = blockIdx.y, g = threadIdx.x;
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const float* __restrict__
       c = fg * c + ig * gg;
       const float tc = 2.0f / (1.0f + __expf(-2.0f * c)) - 1.0f;
       const float hh = og * tc;
+      if (hprev) hprev[o * ldy + (size_t)d * h + g] = h_s[g];      // h of the previous step of THIS direction (0 at its start)
       h_s[g] = hh;
       y[o * ldy + (size_t)d * h + g] = hh;
       bad |= !(hh == hh);
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 
 extern int* ruart_nan_flag_ptr;
 
-extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, int B, int T, int h,
-                              int ndir, void* stream) {
+extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, float* hprev, int B, int T,
+                              int h, int ndir, void* stream) {
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells, T, h, ndir,
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells, hprev, T, h, ndir,
                      ruart_nan_flag_ptr);
   RUART_CHECK_LAUNCH();
   return 0;

@@ -56,7 +56,7 @@ _SIGNATURES = {
     "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_whole_ln_fwd": (_I, [_P, _P, _P, _P, _LL, _F, _P]),
     "ruart_whole_ln_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
-    "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

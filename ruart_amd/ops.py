@@ -146,16 +146,21 @@ def _one_unit_stride(t):
     return t.contiguous()
 
 
-def mm(a, b, bias=None, mode=None):
+def mm(a, b, bias=None, mode=None, out=None):
     """a (M,K) . b (K,N) (+ bias (N,)) -> (M,N) fp32, on the split-bf16 MFMA kernel when the product is big enough.
-    ``mode``: 'x3' | 'fp32'; default = the module-level ``trunk_gemm`` (autograd Functions pass the mode of their forward)."""
+    ``mode``: 'x3' | 'fp32'; default = the module-level ``trunk_gemm`` (autograd Functions pass the mode of their forward).
+    ``out``: optional contiguous (M, N) destination."""
     M, K = a.shape
     N = b.shape[1]
     if (mode or trunk_gemm) != "x3" or not a.is_cuda or a.dtype != torch.float32 or b.dtype != torch.float32 or 2 * M * N * K < _X3_MIN_FLOP:
-        return torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
+        r = torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
+        return r if out is None else out.copy_(r)
     lib = hip.load()
     a, b = _one_unit_stride(a), _one_unit_stride(b)
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    elif not (out.is_contiguous() and out.shape == (M, N) and out.dtype == torch.float32):
+        raise ValueError("mm(out=): a contiguous fp32 (M, N) tensor is required")
     sam, sak = (a.stride(0), 1) if a.stride(1) == 1 else (1, a.stride(1))
     sbk, sbn = (1, b.stride(1)) if b.stride(0) == 1 and b.stride(1) != 1 else (b.stride(0), 1)
     if b.stride(0) == 1 and b.stride(1) == 1:            # K == 1 or N == 1: either description is valid
@@ -212,35 +217,32 @@ class _LstmRecurrence(torch.autograd.Function):
         need = xproj.requires_grad or w_hh.requires_grad
         gates = torch.empty_like(xproj) if need else None
         cells = torch.empty_like(y) if need else None
-        hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), B, T, h, ndir,
-                                     hip.stream_ptr()), "ruart_lstm_fwd")
+        hprev = torch.empty_like(y) if w_hh.requires_grad else None
+        hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), hip.ptr(hprev), B, T, h,
+                                     ndir, hip.stream_ptr()), "ruart_lstm_fwd")
         ctx.ndir, ctx.h = ndir, h
         ctx.mode = trunk_gemm
-        ctx.save_for_backward(w_hh, gates, cells, y)
+        ctx.save_for_backward(w_hh, gates, cells, hprev)
+        ctx.shape = y.shape
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = hip.load()
-        w_hh, gates, cells, y = ctx.saved_tensors
+        w_hh, gates, cells, hprev = ctx.saved_tensors
         ndir, h = ctx.ndir, ctx.h
-        B, T, _ = y.shape
+        B, T, _ = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty_like(gates)
         hip.check(lib.ruart_lstm_bwd(hip.ptr(gy), hip.ptr(w_hh), hip.ptr(gates), hip.ptr(cells), hip.ptr(gx), B, T, h, ndir,
                                      hip.stream_ptr()), "ruart_lstm_bwd")
-        # grad_W_hh[d] = sum_{b,t} da[b,t,d] (x) h_prev[b,t,d]  - one plain GEMM per direction
-        gw = torch.empty_like(w_hh)
-        for d in range(ndir):
-            hd = y[:, :, d * h:(d + 1) * h]
-            hprev = torch.zeros_like(hd)
-            if T > 1:
-                if d == 0:
-                    hprev[:, 1:] = hd[:, :-1]
-                else:
-                    hprev[:, :-1] = hd[:, 1:]
-            da = gx[:, :, d * 4 * h:(d + 1) * 4 * h].reshape(B * T, 4 * h)
-            gw[d] = mm(da.t(), hprev.reshape(B * T, h), mode=ctx.mode)
+        # grad_W_hh[d] = sum_{b,t} da[b,t,d] (x) h_prev[b,t,d]: one GEMM per direction on column slices (strided views, no copies)
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w_hh)
+            gx2, hp2 = gx.view(B * T, -1), hprev.view(B * T, -1)
+            for d in range(ndir):
+                mm(gx2[:, d * 4 * h:(d + 1) * 4 * h].t(), hp2[:, d * h:(d + 1) * h], mode=ctx.mode, out=gw[d])
         return gx, gw, None
 
 
