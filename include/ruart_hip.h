@@ -188,8 +188,14 @@ int ruart_set_nan_flag(int* flag);
  * at least that many bytes. */
 int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, int b_k_contiguous /* sbk == 1 */, int* splitk,
                        size_t* ws_bytes);
+/* Optional fused variational dropout (Models/Layers.py:23-30: one mask row per batch row, shared by `rows_per_scale_row`
+ * consecutive time steps, already scaled by 1/(1-p)); NULL = none:
+ *   a_scale (M / rows_per_scale_row, K): A(m,k) *= a_scale[m / rpm][k]      (needs sak == 1)   - forward  (x*mask) W^T
+ *   c_scale (M / rows_per_scale_row, N): C(m,n) *= c_scale[m / rpm][n]                          - dX = (dY W) * mask
+ *   b_scale (K / rows_per_scale_row, N): B(k,n) *= b_scale[k / rpm][n]      (needs sbn == 1)   - dW = dY^T (x*mask) */
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
-                  float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, void* stream);
+                  float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale,
+                  const float* c_scale, int rows_per_scale_row, void* stream);
 
 /* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
  * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for

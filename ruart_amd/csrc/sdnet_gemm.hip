@@ -53,8 +53,11 @@ template <int TM, int MODE, bool VEC>
 struct Stager {
   float v[16];
 
-  // rows = M or N (limit of the row index), r0 = first row of the tile, k0 = first k of this step
-  __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid) {
+  // rows = M or N (limit of the row index), r0 = first row of the tile, k0 = first k of this step.
+  // S (optional): variational-dropout mask fused into the load.  MODE 0: element (row, k) *= S[(row / rpm) * K + k];
+  // MODE 1: element (row, k) *= S[(k / rpm) * rows + row]  (rpm = time steps that share one mask row).
+  __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid,
+                                       const float* __restrict__ S = nullptr, int rpm = 1) {
     if (MODE == 0) {
       const int kq = (tid & 7) * 4;                   // 4 consecutive k
 #pragma unroll
@@ -67,6 +70,12 @@ struct Stager {
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[p * 4 + i] = (r < rows && k + i < K) ? src[i] : 0.f;
+        }
+        if (S && r < rows) {
+          const float* sp = S + (size_t)(r / rpm) * K + k;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k + i < K) v[p * 4 + i] *= sp[i];
         }
       }
     } else {
@@ -81,6 +90,12 @@ struct Stager {
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[p * 4 + i] = (k < K && r + i < rows) ? src[i] : 0.f;
+        }
+        if (S && k < K) {
+          const float* sp = S + (size_t)(k / rpm) * rows + r;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (r + i < rows) v[p * 4 + i] *= sp[i];
         }
       }
     }
@@ -131,7 +146,9 @@ __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, 
 template <int TM, int AMODE, int BMODE, bool VECA, bool VECB>
 __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
                                                             long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
-                                                            int ldc, int M, int N, int K, int splitk, float* __restrict__ ws) {
+                                                            int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
+                                                            const float* __restrict__ a_scale, const float* __restrict__ b_scale,
+                                                            const float* __restrict__ c_scale, int rpm) {
   typedef XT<TM> T;
   constexpr int ARR = T::ARR, JT = T::JT;
   extern __shared__ __attribute__((aligned(1024))) char smem[];          // 2 stages x (A_hi, A_lo, B_hi, B_lo)
@@ -157,8 +174,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
   // operand A: rows = m (stride sam) in MODE 0 / k-rows of stride sak in MODE 1; operand B: "rows" = n
   const long a_srow = sam, a_sk = sak, b_srow = sbn, b_sk = sbk;
   if (kbeg < kend) {
-    sa.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid);
-    sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid);
+    sa.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
+    sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
   }
   for (int t = kbeg; t < kend; ++t) {
     char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
@@ -166,8 +183,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
     sb.store(st + 2 * ARR, st + 3 * ARR, tid);
     __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
     if (t + 1 < kend) {
-      sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid);
-      sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid);
+      sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm);
+      sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm);
     }
 #pragma unroll
     for (int jh = 0; jh < JT / 4; ++jh) {             // four m-tiles at a time keeps the fragment registers at 40
@@ -215,7 +232,13 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
     for (int j = 0; j < JT; ++j) {
       const int m = m0 + wm * (TM / 2) + j * 16 + fr;
       if (m >= M || n >= N) continue;
-      const f32x4_t v = acc[i][j] + bv;
+      f32x4_t v = acc[i][j] + bv;
+      if (c_scale) {
+        const float* sp = c_scale + (size_t)(m / rpm) * N + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) v[r] *= sp[r];
+      }
       float* dst = C + (size_t)m * ldc + n;
       if (vec_out && n + 3 < N) {
         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -231,7 +254,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
 // second launch of a split-K product: one thread per 4 output floats adds the slices in slice order and writes C (+ bias)
 template <int TM>
 __global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                           float* __restrict__ C, int ldc, int M, int N, int splitk) {
+                                                           float* __restrict__ C, int ldc, int M, int N, int splitk,
+                                                           const float* __restrict__ c_scale, int rpm) {
   typedef XT<TM> T;
   constexpr int JT = T::JT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -245,7 +269,11 @@ __global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restri
   for (int sl = 0; sl < splitk; ++sl) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)sl * (TM * TM));
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (n + r < N) C[(size_t)m * ldc + n + r] = s[r] + (bias ? bias[n + r] : 0.f);
+    if (n + r < N) {
+      float v = s[r] + (bias ? bias[n + r] : 0.f);
+      if (c_scale) v *= c_scale[(size_t)(m / rpm) * N + n + r];
+      C[(size_t)m * ldc + n + r] = v;
+    }
 }
 
 struct Plan { int tm, tiles, splitk; };
@@ -283,15 +311,17 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
 
 template <int TM, int AM, int BM_, bool VA, bool VB>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
-               int N, int K, const Plan& p, float* ws, hipStream_t s) {
+               int N, int K, const Plan& p, float* ws, const float* a_scale, const float* b_scale, const float* c_scale, int rpm,
+               hipStream_t s) {
   auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB>;
   constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3(p.tiles * p.splitk), dim3(XT<TM>::THREADS), lds, s, A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K,
-                     p.splitk, ws);
+                     p.splitk, ws, a_scale, b_scale, c_scale, rpm);
   if (p.splitk > 1)
-    hipLaunchKernelGGL(x3_reduce_kernel<TM>, dim3(p.tiles * 4 * XT<TM>::JT), dim3(XT<TM>::THREADS), 0, s, ws, bias, C, ldc, M, N, p.splitk);
+    hipLaunchKernelGGL(x3_reduce_kernel<TM>, dim3(p.tiles * 4 * XT<TM>::JT), dim3(XT<TM>::THREADS), 0, s, ws, bias, C, ldc, M, N, p.splitk,
+                       c_scale, rpm);
 }
 
 }  // namespace
@@ -305,8 +335,11 @@ extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b
 }
 
 extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
-                             const float* bias, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, void* stream) {
+                             const float* bias, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, const float* a_scale,
+                             const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
+  const int rpm = rows_per_scale_row > 0 ? rows_per_scale_row : 1;
+  if ((a_scale && sak != 1) || (b_scale && sbn != 1)) return (int)hipErrorInvalidValue;    // see the header
   const int amode = (sak == 1) ? 0 : (sam == 1 ? 1 : -1);
   const int bmode = (sbk == 1) ? 0 : (sbn == 1 ? 1 : -1);
   if (amode < 0 || bmode < 0) return (int)hipErrorInvalidValue;        // one unit stride per operand
@@ -318,10 +351,10 @@ extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const
   hipStream_t s = (hipStream_t)stream;
 #define X3V(TM, AM, BM_)                                                                                                          \
   do {                                                                                                                            \
-    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
-    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
-    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                  \
-    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, s);                         \
+    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
+    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
+    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
+    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                         \
   } while (0)
 #define X3(AM, BM_)                 \
   do {                              \

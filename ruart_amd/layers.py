@@ -68,6 +68,14 @@ def seq_dropout(x, p=0, training=False):
     return mask_bank.take(x.size(0), x.size(2), p, x).unsqueeze(1) * x
 
 
+def seq_dropout_mask(x, p=0, training=False):
+    """The (B, D) mask ``seq_dropout`` would multiply a 3-D x with, or None - for consumers that fuse the multiply
+    (ops.linear(mask=)).  Draws from the bank exactly like ``dropout`` would, so the random stream is the same."""
+    if not training or p == 0 or not do_seq_dropout or x.dim() != 3:
+        return None
+    return mask_bank.take(x.size(0), x.size(2), p, x)
+
+
 def dropout(x, p=0, training=False):
     """Layers.py:32-39."""
     if do_seq_dropout and x.dim() == 3:
@@ -121,11 +129,15 @@ class StackedBRNN(nn.Module):
             rnn_input = hiddens[-1]
             if i == 1 and x_additional is not None:
                 rnn_input = torch.cat((rnn_input, x_additional), 2)
-            if dropout_p > 0:
-                rnn_input = dropout(rnn_input, p=dropout_p, training=self.training)
             if self.hidden_size <= 128:
-                out = ops.lstm_layer(rnn_input, *self.layer_params(i))
+                # the input dropout (Layers.py:160-164) is folded into the input projection and its two gradient GEMMs
+                mask = seq_dropout_mask(rnn_input, p=dropout_p, training=self.training)
+                if mask is None and dropout_p > 0:
+                    rnn_input = dropout(rnn_input, p=dropout_p, training=self.training)
+                out = ops.lstm_layer(rnn_input, *self.layer_params(i), mask=mask)
             else:
+                if dropout_p > 0:
+                    rnn_input = dropout(rnn_input, p=dropout_p, training=self.training)
                 out = lstm_layer_wide(rnn_input, *self.layer_params(i))
             if LN:
                 out = ops.whole_layer_norm(out)
@@ -183,9 +195,13 @@ class AttentionScore(nn.Module):
 
     def project_raw(self, x1, x2):
         """W x1, W x2 (after input dropout); the ReLU and the diagonal are applied inside the fused attention kernel."""
-        x1 = dropout(x1, p=dropout_p, training=self.training)
-        x2 = dropout(x2, p=dropout_p, training=self.training)
-        return ops.linear(x1, self.linear.weight), ops.linear(x2, self.linear.weight)
+        out = []
+        for x in (x1, x2):
+            mask = seq_dropout_mask(x, p=dropout_p, training=self.training)
+            if mask is None:
+                x = dropout(x, p=dropout_p, training=self.training)
+            out.append(ops.linear(x, self.linear.weight, mask=mask))
+        return out[0], out[1]
 
     def forward(self, x1, x2):
         p1, p2 = self.project_raw(x1, x2)

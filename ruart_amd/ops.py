@@ -146,17 +146,29 @@ def _one_unit_stride(t):
     return t.contiguous()
 
 
-def mm(a, b, bias=None, mode=None, out=None):
+def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale=None, rpm=1):
     """a (M,K) . b (K,N) (+ bias (N,)) -> (M,N) fp32, on the split-bf16 MFMA kernel when the product is big enough.
     ``mode``: 'x3' | 'fp32'; default = the module-level ``trunk_gemm`` (autograd Functions pass the mode of their forward).
-    ``out``: optional contiguous (M, N) destination."""
+    ``out``: optional contiguous (M, N) destination.
+    ``a_scale`` (M/rpm, K) / ``b_scale`` (K/rpm, N) / ``c_scale`` (M/rpm, N): variational-dropout masks fused into the operand
+    loads / the output (each mask row is shared by ``rpm`` consecutive rows)."""
     M, K = a.shape
     N = b.shape[1]
-    if (mode or trunk_gemm) != "x3" or not a.is_cuda or a.dtype != torch.float32 or b.dtype != torch.float32 or 2 * M * N * K < _X3_MIN_FLOP:
+    use_x3 = (mode or trunk_gemm) == "x3" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and 2 * M * N * K >= _X3_MIN_FLOP
+    if use_x3:
+        a, b = _one_unit_stride(a), _one_unit_stride(b)
+        if (a_scale is not None and a.stride(1) != 1) or (b_scale is not None and b.stride(1) != 1):
+            use_x3 = False                                  # the fused masks follow the operand's natural orientation only
+    if not use_x3:
+        if a_scale is not None:
+            a = a * a_scale.repeat_interleave(rpm, 0)
+        if b_scale is not None:
+            b = b * b_scale.repeat_interleave(rpm, 0)
         r = torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
+        if c_scale is not None:
+            r = r * c_scale.repeat_interleave(rpm, 0)
         return r if out is None else out.copy_(r)
     lib = hip.load()
-    a, b = _one_unit_stride(a), _one_unit_stride(b)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     elif not (out.is_contiguous() and out.shape == (M, N) and out.dtype == torch.float32):
@@ -165,39 +177,58 @@ def mm(a, b, bias=None, mode=None, out=None):
     sbk, sbn = (1, b.stride(1)) if b.stride(0) == 1 and b.stride(1) != 1 else (b.stride(0), 1)
     if b.stride(0) == 1 and b.stride(1) == 1:            # K == 1 or N == 1: either description is valid
         sbk, sbn = b.stride(0), 1
+    for sc, shape in ((a_scale, (M // rpm, K)), (b_scale, (K // rpm, N)), (c_scale, (M // rpm, N))):
+        if sc is not None and not (sc.is_contiguous() and tuple(sc.shape) == shape and sc.dtype == torch.float32):
+            raise ValueError("mm: a fused mask must be a contiguous fp32 %s tensor" % (shape,))
     nbytes = ctypes.c_size_t(0)
     hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
     ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
     hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(out), N, M, N, K, hip.ptr(ws),
-                                nbytes.value, hip.stream_ptr()), "ruart_gemm_x3")
+                                nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm), hip.stream_ptr()),
+              "ruart_gemm_x3")
     return out
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T (+ b) with x (rows, K), W (N, K): forward, dX = dY W and dW = dY^T X all on ruart_gemm_x3."""
+    """y = (x * mask) W^T (+ b) with x (rows, K), W (N, K), mask (rows / rpm, K) or None, on ruart_gemm_x3.
+    The masked input is materialised once (it is also the operand of dW = dY^T (x * mask)); the backward multiply is fused:
+    dX = (dY W) * mask comes out of the GEMM epilogue.  (Fusing the mask into the OPERAND loads as well - a_scale / b_scale of
+    the kernel - was measured 1.5-2x slower than the separate multiply: the mask is a second load stream per element.)"""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, mask, rpm):
+        xm = x if mask is None else (x.view(-1, rpm, x.shape[1]) * mask.unsqueeze(1)).view(x.shape)
+        ctx.save_for_backward(xm, w, mask)
         ctx.has_bias = b is not None
         ctx.mode = trunk_gemm
-        return mm(x, w.t(), b)
+        ctx.rpm = rpm
+        return mm(xm, w.t(), b)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gx = mm(gy, w, mode=ctx.mode) if ctx.needs_input_grad[0] else None
-        gw = mm(gy.t(), x, mode=ctx.mode) if ctx.needs_input_grad[1] else None
+        xm, w, mask = ctx.saved_tensors
+        gx = mm(gy, w, mode=ctx.mode, c_scale=mask, rpm=ctx.rpm) if ctx.needs_input_grad[0] else None
+        gw = mm(gy.t(), xm, mode=ctx.mode) if ctx.needs_input_grad[1] else None
         gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb
+        return gx, gw, gb, None, None
 
 
-def linear(x, w, b=None):
-    """F.linear for fp32 device tensors of any leading shape, through ``mm``."""
+def linear(x, w, b=None, mask=None):
+    """F.linear for fp32 device tensors of any leading shape, through ``mm``.  ``mask`` (B, K) with x (B, T, K): variational
+    dropout (x * mask[:, None, :]) applied inside the op - one multiply in the forward, none in the backward."""
     if trunk_gemm != "x3" or not x.is_cuda:
+        if mask is not None:
+            x = x * mask.unsqueeze(1)
         return torch.nn.functional.linear(x, w, b)
     lead = x.shape[:-1]
-    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b)
+    rpm = 1
+    if mask is not None:
+        if x.dim() != 3 or mask.shape != (x.shape[0], x.shape[2]):
+            raise ValueError("linear(mask=): x (B, T, K) with mask (B, K)")
+        rpm = x.shape[1]
+        mask = mask.contiguous()
+    x2 = x.reshape(-1, x.shape[-1])
+    y = _Linear.apply(x2, w, b, mask, rpm)
     return y.view(*lead, w.shape[0])
 
 
@@ -246,7 +277,7 @@ class _LstmRecurrence(torch.autograd.Function):
         return gx, gw, None
 
 
-def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None):
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None, mask=None):
     """One nn.LSTM layer (batch_first, zero state), uni- or bidirectional, on the persistent HIP recurrence.
     Parameters use torch's nn.LSTM layout so checkpoints load unchanged."""
     bidir = w_ih_r is not None
@@ -256,7 +287,7 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None,
         whh = torch.stack([w_hh, w_hh_r], 0)
     else:
         w, b, whh = w_ih, b_ih + b_hh, w_hh.unsqueeze(0)
-    xproj = linear(x, w, b)
+    xproj = linear(x, w, b, mask=mask)            # mask: the input's variational-dropout mask, fused into the projection
     return _LstmRecurrence.apply(xproj.contiguous(), whh.contiguous(), 2 if bidir else 1)
 
 

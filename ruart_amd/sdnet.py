@@ -363,7 +363,7 @@ class SDNet(nn.Module):
             mixes.append(_PoolMix.apply(lw, layers, s, l, dst, rows, self.Bert.weights.dtype))
         Bq, Q = q_list[opt["q_emb_initial"]].shape
         q_bert = mixes[0].view(Bq, Q, H)
-        q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev)
+        q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev).to(torch.uint8)    # once: the attention kernels take uint8
         ocr_mask, od_mask = bi.ocr_mask, bi.od_mask
 
         # ---- front: variable-size part (real words of this batch): embeddings, pre-align, multi2one -----------

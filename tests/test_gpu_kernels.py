@@ -442,3 +442,26 @@ def test_linear_x3_autograd_matches_fp32():
     for name, a_, r_ in zip(("y", "gx", "gw", "gb"), got, (y2.detach(), x.grad, w.grad, b.grad)):
         scale = float(r_.abs().max())
         assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
+
+
+def test_linear_x3_fused_dropout_mask():
+    """ops.linear(x, w, b, mask=) folds the variational-dropout multiply (one mask row per batch row, shared over time) into
+    the forward GEMM and both gradient GEMMs: same values and gradients as multiplying first."""
+    from ruart_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, K, N = 64, 37, 250, 500
+    x = torch.randn(B, T, K, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(N, generator=g).cuda().requires_grad_(True)
+    mask = (torch.bernoulli(torch.full((B, K), 0.7), generator=g) / 0.7).cuda()
+    gy = torch.randn(B, T, N, generator=g).cuda()
+    y = ops.linear(x, w, b, mask=mask)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    y2 = torch.nn.functional.linear(x * mask.unsqueeze(1), w, b)
+    y2.backward(gy)
+    for name, a_, r_ in zip(("y", "gx", "gw", "gb"), got, (y2.detach(), x.grad, w.grad, b.grad)):
+        scale = float(r_.abs().max())
+        assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
+    assert bool((got[1][mask.unsqueeze(1).expand_as(x) == 0] == 0).all())      # dropped features get exactly zero gradient
