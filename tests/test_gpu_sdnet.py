@@ -266,6 +266,11 @@ def test_full_size_properties():
     # every one of 6 464 outputs of this random-weight model (the trunk amplifies BERT feature noise ~10x); the exact
     # fp32 mode does.  Mean error, the 99th percentile and the worst case are pinned here.
     assert float(d16.mean()) < 1e-4 and frac < 0.02 and float(d16.max()) < 2e-2
+    # ---- the split-bf16 trunk GEMM alone: fp32 encoder, x3 projections vs the library's exact fp32 GEMMs -------------
+    net_x3, _ = make("fp32", ruart_trunk_gemm="x3")
+    dx3 = (run(net_x3, batch) - s32).abs()
+    print("full size, fp32 encoder: max |p_x3 - p_fp32gemm| = %.2e, mean %.2e" % (float(dx3.max()), float(dx3.mean())))
+    assert float(dx3.max()) < 1e-3 and float(dx3.mean()) < 5e-6          # ~2^-16 per product: far inside the 1e-3 budget
 
 
 def test_stress_config_bert_large_and_edge_batches():
