@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "x3"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "bert512"])
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--n-batches", type=int, default=2, help="distinct pre-staged synthetic batches cycled through")
@@ -132,7 +132,7 @@ def bert512(a, device, lib):
     lib.ruart_prof_enable(0)
     out = {"metric": "BERT-base + attention forward, (B=%d, L=%d), achieved TFLOP/s" % (a.batch, L), "value": round(flops / dt / 1e12, 1),
            "unit": "TFLOP/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3),
-           "higher_is_better": True, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+           "higher_is_better": True, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA"}[a.precision], "data": "synthetic",
            "config": {"workload": "north-star shape: bert-base forward over %d x %d valid tokens" % (a.batch, L)},
            "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / dt / 1e12 / PEAK_TFLOPS, 4), "traffic": None,
@@ -221,7 +221,7 @@ def main():
     #  * "timed": the schedule of the timed region (encoder of the next batch beside the trunk).  There a GEMM shares the CUs
     #    with the trunk's kernels, so its launch-to-finish time also contains the trunk's work (roofline.timed_region).
     roof = None
-    if not a.no_roofline and a.precision != "fp32":
+    if not a.no_roofline and a.precision in ("fp16", "bf16"):
         def gemm_pass(prefetch):
             saved = a.no_prefetch
             a.no_prefetch = not prefetch
@@ -260,7 +260,7 @@ def main():
         out = {"metric": "VQA samples/sec fwd+bwd (B=64, q=30, ocr=100)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=100)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[a.precision], "data": "synthetic",
+               "vs_baseline": None, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA"}[a.precision], "data": "synthetic",
                "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, 100 OCR items, "
                                       "36 objects, bert-base 12x768 frozen, SDNet trunk fwd+bwd, Adamax" % a.batch,
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),

@@ -106,6 +106,8 @@ typedef struct {
   const void* const* w_ff1;   const float* const* b_ff1;
   const void* const* w_ff2;   const float* const* b_ff2;
   const float* const* ln2_g;  const float* const* ln2_b;
+  int f32_gemm;   /* dtype == F32 only: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), 1 = fp32 operands split into bf16 hi + lo and
+                     multiplied as three 16-bit MFMA products (ruart_gemm_x3: ~2^-16 per product, ~2.5x faster) */
 } ruart_bert_model;
 
 typedef struct {
@@ -185,7 +187,8 @@ int ruart_set_nan_flag(int* flag);
  * their backward.  A element (m,k) at A[m*sam + k*sak], B element (k,n) at B[k*sbk + n*sbn]; each operand needs ONE unit
  * stride, so x.W^T, dY.W and dY^T.X all fit.  Products with a small output and a long reduction are split along K: ask
  * ruart_gemm_x3_plan (same M, N, K and operand layouts) for the workspace size first (0 when not split) and pass a workspace of
- * at least that many bytes. */
+ * at least that many bytes; with a smaller (or no) workspace the product is computed unsplit - same result up to fp32
+ * summation order, fewer workgroups. */
 int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, int b_k_contiguous /* sbk == 1 */, int* splitk,
                        size_t* ws_bytes);
 /* Optional fused variational dropout (Models/Layers.py:23-30: one mask row per batch row, shared by `rows_per_scale_row`
@@ -193,9 +196,11 @@ int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, i
  *   a_scale (M / rows_per_scale_row, K): A(m,k) *= a_scale[m / rpm][k]      (needs sak == 1)   - forward  (x*mask) W^T
  *   c_scale (M / rows_per_scale_row, N): C(m,n) *= c_scale[m / rpm][n]                          - dX = (dY W) * mask
  *   b_scale (K / rows_per_scale_row, N): B(k,n) *= b_scale[k / rpm][n]      (needs sbn == 1)   - dW = dY^T (x*mask) */
+/* Epilogue: C = act(A.B + bias) [* c_scale] + residual;  act = RUART_ACT_NONE | RUART_ACT_GELU (exact erf form), residual (M, N)
+ * fp32 with row stride ldr or NULL - the encoder's dense+bias(+GELU)(+residual) steps in its split-operand precision mode. */
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
-                  float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale,
-                  const float* c_scale, int rows_per_scale_row, void* stream);
+                  const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
+                  const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
 
 /* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
  * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for

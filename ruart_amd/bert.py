@@ -83,6 +83,7 @@ class BertEncoderWeights:
         m = hip.BertModelC()
         m.hidden, m.n_heads, m.n_layers, m.intermediate = H, nh, nl, cfg["intermediate_size"]
         m.dtype, m.ln_eps = self.dtype, 1e-12
+        m.f32_gemm = 1 if dtype == "x3" else 0
         for k in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"):
             setattr(m, k, getattr(self, k).data_ptr())
         for k in keys:

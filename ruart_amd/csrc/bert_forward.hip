@@ -59,6 +59,9 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
   auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act) {
     if (dt != RUART_DT_F32)
       return ruart_gemm_16_nt(A, K, W, K, bias, res, N, dt, C, N, out_dt, R, N, K, act, dt, stream);
+    if (m->f32_gemm == 1)                                        // fp32 storage, split-bf16 products (no K split at these sizes)
+      return ruart_gemm_x3((const float*)A, K, 1, (const float*)W, 1, K, bias, (const float*)res, N, act, (float*)C, N, R, N, K,
+                           nullptr, 0, nullptr, nullptr, nullptr, 1, stream);
     return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, R, N, K, act, stream);
   };
 

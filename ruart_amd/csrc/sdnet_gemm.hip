@@ -151,7 +151,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
                                                             long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
                                                             int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
                                                             const float* __restrict__ a_scale, const float* __restrict__ b_scale,
-                                                            const float* __restrict__ c_scale, int rpm) {
+                                                            const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
+                                                            int ldr, int act) {
   typedef XT<TM> T;
   constexpr int ARR = T::ARR, JT = T::JT;
   extern __shared__ __attribute__((aligned(1024))) char smem[];          // 2 stages x (A_hi, A_lo, B_hi, B_lo)
@@ -236,11 +237,21 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
       const int m = m0 + wm * (TM / 2) + j * 16 + fr;
       if (m >= M || n >= N) continue;
       f32x4_t v = acc[i][j] + bv;
+      if (act == RUART_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
+      }
       if (c_scale) {
         const float* sp = c_scale + (size_t)(m / rpm) * N + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < N) v[r] *= sp[r];
+      }
+      if (R) {
+        const float* rp = R + (size_t)m * ldr + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) v[r] += rp[r];
       }
       float* dst = C + (size_t)m * ldc + n;
       if (vec_out && n + 3 < N) {
@@ -258,7 +269,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
 template <int TM>
 __global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                            float* __restrict__ C, int ldc, int M, int N, int splitk,
-                                                           const float* __restrict__ c_scale, int rpm) {
+                                                           const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
+                                                           int ldr, int act) {
   typedef XT<TM> T;
   constexpr int JT = T::JT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,7 +286,9 @@ __global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restri
   for (int r = 0; r < 4; ++r)
     if (n + r < N) {
       float v = s[r] + (bias ? bias[n + r] : 0.f);
+      if (act == RUART_ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
       if (c_scale) v *= c_scale[(size_t)(m / rpm) * N + n + r];
+      if (R) v += R[(size_t)m * ldr + n + r];
       C[(size_t)m * ldc + n + r] = v;
     }
 }
@@ -315,16 +329,16 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
 template <int TM, int AM, int BM_, bool VA, bool VB>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
                int N, int K, const Plan& p, float* ws, const float* a_scale, const float* b_scale, const float* c_scale, int rpm,
-               hipStream_t s) {
+               const float* R, int ldr, int act, hipStream_t s) {
   auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB>;
   constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3(p.tiles * p.splitk), dim3(XT<TM>::THREADS), lds, s, A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K,
-                     p.splitk, ws, a_scale, b_scale, c_scale, rpm);
+                     p.splitk, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act);
   if (p.splitk > 1)
     hipLaunchKernelGGL(x3_reduce_kernel<TM>, dim3(p.tiles * 4 * XT<TM>::JT), dim3(XT<TM>::THREADS), 0, s, ws, bias, C, ldc, M, N, p.splitk,
-                       c_scale, rpm);
+                       c_scale, rpm, R, ldr, act);
 }
 
 }  // namespace
@@ -338,26 +352,29 @@ extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b
 }
 
 extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
-                             const float* bias, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes, const float* a_scale,
-                             const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream) {
+                             const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
+                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
+                             int rows_per_scale_row, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
+  if ((residual && ldr < N) || (act != RUART_ACT_NONE && act != RUART_ACT_GELU)) return (int)hipErrorInvalidValue;
+  const float* R = residual;
   const int rpm = rows_per_scale_row > 0 ? rows_per_scale_row : 1;
   if ((a_scale && sak != 1) || (b_scale && sbn != 1)) return (int)hipErrorInvalidValue;    // see the header
   const int amode = (sak == 1) ? 0 : (sam == 1 ? 1 : -1);
   const int bmode = (sbk == 1) ? 0 : (sbn == 1 ? 1 : -1);
   if (amode < 0 || bmode < 0) return (int)hipErrorInvalidValue;        // one unit stride per operand
-  const Plan p = make_plan(M, N, K, amode, bmode);
-  if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) return (int)hipErrorInvalidValue;
+  Plan p = make_plan(M, N, K, amode, bmode);
+  if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) p.splitk = 1;   // no room: unsplit
   // 16-byte vector loads need an aligned base and a non-unit stride that is a multiple of 4 floats
   const bool va = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((amode == 0 ? sam : sak) & 3) == 0);
   const bool vb = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((bmode == 0 ? sbn : sbk) & 3) == 0);
   hipStream_t s = (hipStream_t)stream;
 #define X3V(TM, AM, BM_)                                                                                                          \
   do {                                                                                                                            \
-    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
-    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
-    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                  \
-    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, s);                         \
+    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                         \
   } while (0)
 #define X3(AM, BM_)                 \
   do {                              \

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libruart_hip.so")
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 TORCH_DTYPE = {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}
-PRECISION = {"fp32": DT_F32, "bf16": DT_BF16, "fp16": DT_F16}
+PRECISION = {"fp32": DT_F32, "bf16": DT_BF16, "fp16": DT_F16, "x3": DT_F32}     # x3: fp32 storage, split-bf16 MFMA products
 
 
 class BertModelC(Structure):
@@ -29,7 +29,7 @@ class BertModelC(Structure):
                 ("ln1_g", POINTER(c_void_p)), ("ln1_b", POINTER(c_void_p)),
                 ("w_ff1", POINTER(c_void_p)), ("b_ff1", POINTER(c_void_p)),
                 ("w_ff2", POINTER(c_void_p)), ("b_ff2", POINTER(c_void_p)),
-                ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p))]
+                ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p)), ("f32_gemm", c_int)]
 
 
 class BertBatchC(Structure):
@@ -62,8 +62,8 @@ _SIGNATURES = {
     "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
     "ruart_gemm_x3_plan": (_I, [_I, _I, _I, _I, _I, POINTER(ctypes.c_int), POINTER(ctypes.c_size_t)]),
-    "ruart_gemm_x3": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _I, _I,
-                           _P, ctypes.c_size_t, _P, _P, _P, _I, _P]),
+    "ruart_gemm_x3": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _P, _I, _I,
+                           _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _I, _P]),
     "ruart_stream_create_cu_masked": (_I, [_I, POINTER(ctypes.c_void_p)]),
     "ruart_stream_destroy": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),
@@ -91,6 +91,8 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("RUART_GEMM_VARIANT"):             # experiments only: tile variant of the encoder GEMM (default 5)
+        lib.ruart_gemm_set_variant(int(os.environ["RUART_GEMM_VARIANT"]))
     _lib = lib
     return lib
 

@@ -183,9 +183,9 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     nbytes = ctypes.c_size_t(0)
     hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
     ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
-    hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(out), N, M, N, K, hip.ptr(ws),
-                                nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm), hip.stream_ptr()),
-              "ruart_gemm_x3")
+    hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), None, 0, hip.ACT_NONE, hip.ptr(out), N,
+                                M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm),
+                                hip.stream_ptr()), "ruart_gemm_x3")
     return out
 
 
