@@ -46,10 +46,10 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
                      void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
-/* Tile variant of ruart_gemm_16_nt: 0 = 128x128 tile / 2 LDS stages, 1 = 256x128 tile / 3 stages with counted vmcnt
- * (M % 256 == 0), 2 = persistent 128x128, 3 (default) = 256x256 tile / 2 stages, one workgroup per CU (M, N % 256 == 0,
- * else falls back to 0).  All variants sum in the same order and are bitwise identical (tools/gemm_check.py); measured
- * rates per BERT shape are in DESIGN.md section 5. */
+/* Tile variant of ruart_gemm_16_nt: 5 (default) = 256x256 tile, four phases per K-tile with the prefetch in flight across
+ * barriers (needs M, N % 256 == 0 and K % 128 == 0); 3 = 256x256 tile, plain two-stage loop (M, N % 256 == 0); 0 = 128x128
+ * tile.  A shape a variant cannot take falls back to the next one.  All variants sum in the same order and are bitwise
+ * identical (tools/gemm_check.py).  Other values are rejected. */
 int ruart_gemm_set_variant(int v);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,

@@ -179,245 +179,6 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent form of the 128x128x64 kernel: 2 workgroups per CU walk the (XCD-remapped, grouped) tile list with a
-// stride of gridDim.x, and the K loop is flattened over (tile, k-step): the first stage of the NEXT tile is already in
-// flight while the current tile's last MFMAs and its epilogue run, so the ~2 us load latency of a prologue and the
-// store tail of an epilogue - 30-40 % of a K=768 tile's life - overlap instead of serialising.
-// ------------------------------------------------------------------------------------------------
-template <typename T16, bool OUT_F32, int RES, int ACT>
-__global__ __launch_bounds__(256) void gemm_16_nt_128p(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
-                                                       const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                       void* __restrict__ C, int ldc, int M, int N, int K, int order) {
-  constexpr int kTile = BM * BK * 2;
-  constexpr int kStage = 2 * kTile;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * kStage];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = N / BN, ntm = M / BM;
-  const int ntiles = ntn * ntm;
-  const int nt = K / BK;
-  const int G = gridDim.x;
-  // this workgroup's tiles: logical ids xcd_remap(b), then +G, +2G ... (G is a multiple of 8, so the XCD class is kept)
-  const int first = blockIdx.x;
-  const int my_tiles = (ntiles - first + G - 1) / G;
-  if (my_tiles <= 0) return;
-
-  auto tile_origin = [&](int j, int& m0, int& n0) {
-    const int lin = first + j * G;
-    const int round0 = (lin / G) * G;
-    const int cnt = min(G, ntiles - round0);                   // tiles in this round (the last round may be partial)
-    const int id = round0 + xcd_remap(lin - round0, cnt);      // bijective on [round0, round0 + cnt)
-    int tm, tn;
-    if (order == 0) {
-      tm = id / ntn;
-      tn = id % ntn;
-    } else {
-      const int per_group = order * ntn;
-      const int g = id / per_group, f0 = g * order;
-      const int gsz = min(ntm - f0, order);
-      const int r = id - g * per_group;
-      tm = f0 + r % gsz;
-      tn = r / gsz;
-    }
-    m0 = tm * BM;
-    n0 = tn * BN;
-  };
-
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
-  auto stage = [&](int buf, int m0, int n0, int k0) {
-    const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8 + k0;
-    const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8 + k0;
-    char* base = smem + buf * kStage + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step), (lptr_t)(base + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step), (lptr_t)(base + kTile + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[4][4];
-  const int fr = lane & 15, fq = lane >> 4;
-  typedef typename Vec8<T16>::type frag_t;
-  int m0, n0, nm0, nn0;
-  tile_origin(0, m0, n0);
-  stage(0, m0, n0, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int j = 0; j < my_tiles; ++j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bool has_next = j + 1 < my_tiles;
-    if (has_next) tile_origin(j + 1, nm0, nn0);
-    for (int t = 0; t < nt; ++t) {
-      // prefetch the next flattened step: next k-step of this tile, or k-step 0 of the next tile
-      if (t + 1 < nt) stage(buf ^ 1, m0, n0, (t + 1) * BK);
-      else if (has_next) stage(buf ^ 1, nm0, nn0, 0);
-      const char* sa = smem + buf * kStage;
-      const char* sw = sa + kTile;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        frag_t wf[4], af[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-          af[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_16x16x32(wf[i], af[jj], acc[i][jj]);
-      }
-      if (t + 1 == nt) {
-        // epilogue of this tile, with the next tile's first stage in flight
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int n = n0 + wn * 64 + i * 16 + fq * 4;
-          f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-          if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int m = m0 + wm * 64 + jj * 16 + fr;
-            f32x4_t v = acc[i][jj] + bv;
-            if (ACT == 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-            }
-            if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
-            if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
-            if (OUT_F32)
-              store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
-            else
-              store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
-          }
-        }
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
-    m0 = nm0;
-    n0 = nn0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 per wave), THREE LDS stages of 48 KB.
-// Why: PMC on the 128x128 kernel (profiles/r01_gemm_pmc.md) shows it is bound by global->LDS latency/throughput
-// (~36 GB/s per CU delivered; MFMA pipe 24 % busy, LDS conflicts 0).  This variant moves 25 % fewer bytes per flop
-// (85 flop/B instead of 64) and keeps two K-steps of LDS-DMA in flight across the barrier: the next-next stage is issued
-// before the MFMAs of the current one, the wait is a COUNTED s_waitcnt vmcnt(6) (= the 6 global_load_lds of the newest
-// stage stay outstanding) and the barrier is a raw s_barrier, which - unlike __syncthreads() - does not drain the DMA
-// queue (cdna_hip_programming.md, "Pipelining across barriers").  RAW: a stage is read one barrier after the wait that
-// retires it; WAR: stage (t+2)%3 was last read in step t-1 and every wave has passed that step's barrier.
-// ------------------------------------------------------------------------------------------------
-#define BM2 256
-template <typename T16, bool OUT_F32, int RES, int ACT>
-__global__ __launch_bounds__(512) void gemm_16_nt_256(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
-                                                      const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                      void* __restrict__ C, int ldc, int M, int N, int K, int order) {
-  constexpr int kTileA = BM2 * BK * 2;           // 32 KB
-  constexpr int kTileW = BN * BK * 2;            // 16 KB
-  constexpr int kStage = kTileA + kTileW;        // 48 KB
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 3 * kStage
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = N / BN, ntm = M / BM2;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  if (order == 0) {
-    tm = id / ntn;
-    tn = id % ntn;
-  } else {
-    const int per_group = order * ntn;
-    const int g = id / per_group, first = g * order;
-    const int gsz = min(ntm - first, order);
-    const int r = id - g * per_group;
-    tm = first + r % gsz;
-    tn = r / gsz;
-  }
-  const int m0 = tm * BM2, n0 = tn * BN;
-
-  // staging: A tile = 32 wave-instructions of 1 KB (8 rows), 4 per wave; W tile = 16, 2 per wave
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
-  const T16* w_src = W + (size_t)(n0 + wave * 16 + srow) * ldw + schunk * 8;
-  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
-  auto stage = [&](int buf, int k0) {
-    char* base = smem + buf * kStage;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + wave * 4096 + i * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + kTileA + wave * 2048 + i * 1024), 16, 0, 0);
-  };
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fq = lane >> 4;
-  typedef typename Vec8<T16>::type frag_t;
-  auto compute = [&](int buf) {
-    const char* sa = smem + buf * kStage;
-    const char* sw = sa + kTileA;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      frag_t wf[4], af[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        af[i] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_16x16x32(wf[i], af[j], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
-  const int nt = K / BK;
-  stage(0, 0);
-  if (nt > 1) stage(1, BK);
-  if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int nxt2 = cur == 0 ? 2 : cur - 1;           // (cur + 2) % 3
-    if (t + 2 < nt) stage(nxt2, (t + 2) * BK);
-    compute(cur);
-    // retire stage t+1 (issued one step ago); the stage just issued (6 DMAs per lane-wave) may stay in flight
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    cur = cur == 2 ? 0 : cur + 1;
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + fq * 4;
-    f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + fr;
-      f32x4_t v = acc[i][j] + bv;
-      if (ACT == 1) v = gelu4(v);
-      if (RES == 1) v += load4(reinterpret_cast<const T16*>(R) + (size_t)m * ldr + n);
-      if (RES == 2) v += load4(reinterpret_cast<const float*>(R) + (size_t)m * ldr + n);
-      if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)m * ldc + n, v);
-      else
-        store4(reinterpret_cast<T16*>(C) + (size_t)m * ldc + n, v);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves (2 along M x 4 along N, 128x64 per wave = 8x4 MFMA tiles, 128 accumulator VGPRs), two LDS
 // stages of 64 KB, one workgroup per CU.  The 128x128 kernel is bound by how many bytes a CU can pull from L2 into LDS
 // per unit time (PMC: ~36 GB/s/CU, MFMA pipe 24 % busy); this tile needs HALF the bytes per flop (128 flop/B), so the same
@@ -778,152 +539,6 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256x256x64, "A in registers" pipeline: see the comment above the main loop.  Same tile, staging and epilogue as
-// gemm_16_nt_256sq; only the K loop differs.
-// ------------------------------------------------------------------------------------------------
-template <typename T16, bool OUT_F32, int RES, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_16_nt_256ar(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
-                                                           const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
-  constexpr int kTile = BM4 * BK * 2;            // 32 KB per operand tile
-  constexpr int kStage = 2 * kTile;              // 64 KB
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * kStage = 128 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntn = N / BN4, ntm = M / BM4;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  if (order == 0) {
-    tm = id / ntn;
-    tn = id % ntn;
-  } else {
-    const int per_group = order * ntn;
-    const int g = id / per_group, first = g * order;
-    const int gsz = min(ntm - first, order);
-    const int r = id - g * per_group;
-    tm = first + r % gsz;
-    tn = r / gsz;
-  }
-  const int m0 = tm * BM4, n0 = tn * BN4;
-
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const T16* a_src = A + (size_t)(m0 + wave * 32 + srow) * lda + schunk * 8;
-  const T16* w_src = W + (size_t)(n0 + wave * 32 + srow) * ldw + schunk * 8;
-  const size_t a_step = (size_t)8 * lda, w_step = (size_t)8 * ldw;
-
-  // staging split by operand: A tile (4 DMAs per wave) and W tile (4 DMAs per wave) are issued at different times
-  auto stage_a = [&](int buf, int k0) {
-    char* base = smem + buf * kStage + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(a_src + i * a_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
-  };
-  auto stage_w = [&](int buf, int k0) {
-    char* base = smem + buf * kStage + kTile + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(w_src + i * w_step + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
-  };
-
-  f32x4_t acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fq = lane >> 4;
-  typedef typename Vec8<T16>::type frag_t;
-
-  // Pipeline ("A in registers"): at the top of K-tile t every wave pulls ALL its A fragments of the tile (16 x b128 = 64 VGPRs)
-  // into registers; after one barrier the A half of that LDS buffer is dead and is refilled with A(t+2) right away, while
-  // the MFMAs of tile t still run out of registers + the W half.  W(t+1) is issued at the very top of tile t.  So up to
-  // 96 KB of LDS-DMA are in flight per CU (A(t+1), W(t+1), A(t+2)) instead of 64 KB, with two LDS buffers only.
-  // Waits are counted: at the end of tile t only the 4 DMAs of A(t+2) may remain outstanding (vmcnt(4)); barriers are raw
-  // s_barrier so they do not drain the DMA queue.
-  const int nt = K / BK;
-  stage_a(0, 0);
-  stage_w(0, 0);
-  if (nt > 1) {
-    stage_a(1, BK);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    const char* sa = smem + buf * kStage;
-    const char* sw = sa + kTile;
-    if (t + 1 < nt) stage_w(buf ^ 1, (t + 1) * BK);           // W half of the other buffer was released by the last barrier
-    frag_t af[2][8];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) af[ks][j] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 128 + j * 16 + fr, ks * 4 + fq));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                               // every wave holds its A fragments: A[buf] is dead
-    if (t + 2 < nt) stage_a(buf, (t + 2) * BK);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      frag_t wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const frag_t*>(sw + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mfma_16x16x32(wf[i], af[ks][j], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                               // tile t+1 is complete in LDS; W[buf] is dead
-  }
-
-  // Epilogue through LDS: the MFMA accumulator layout gives a lane 4 consecutive columns of 16 DIFFERENT rows, i.e. 64-byte
-  // pieces of 16 cache lines per store instruction (PMC/TA-bound: 5x the line touches of a row-wise store).  Each wave parks
-  // its 128x64 tile in its own 8.5 KB of the (now idle) staging memory, 32 rows at a time, and reads it back row-wise:
-  // one instruction then covers 4 whole rows x 256 B (fp32) / 128 B (16-bit) for the residual load and the store alike.
-  // (the loop's last barrier already guarantees every wave is done reading operand tiles)
-  constexpr int ERS = 272;                           // 64 fp32 + 16 B pad: conflict-free for both the b128 writes and reads
-  char* my = smem + wave * (32 * ERS);               // 8.5 KB per wave, 32 rows per pass
-  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-  const int ncol = n0 + wn * 64 + rcol;
-  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
-#pragma unroll
-  for (int hh = 0; hh < 4; ++hh) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
-    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
-    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
-    f32x4_t v[8], res[8];
-    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
-    if (RES != 0) {
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
-        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
-    if (ACT == 1) {
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      if (RES != 0) v[rr] += res[rr];
-      if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-      else
-        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // exact fp32 path: 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
 // ------------------------------------------------------------------------------------------------
 #define FBM 64
@@ -1037,7 +652,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {
-  if (v < 0 || v > 5) return (int)hipErrorInvalidValue;
+  if (v != 0 && v != 3 && v != 5) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
@@ -1071,46 +686,25 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
   return 0;
 }
 
-int g_gemm_variant = 5;          // 0: 128x128 2-stage, 1: 256x128 3-stage (M % 256 == 0), 2: persistent 128x128, 3: 256x256 2-stage, 4: 256x256 A-in-registers,
-                                 // 5: 256x256 four phases per K-tile, counted vmcnt, staggered wave groups (M, N % 256 == 0, K % 128 == 0; else 3)
-int g_gemm_persist_blocks = 512; // persistent grid: 2 workgroups x 256 CUs
+int g_gemm_variant = 5;          // 0: 128x128 2-stage (any M, N multiple of 128); 3: 256x256 2-stage; 5: 256x256 four phases per K-tile, counted
+                                 // vmcnt, staggered wave groups (M, N % 256 == 0, K % 128 == 0; else 3, else 0)
 
 template <typename T16, bool OF, int RS, int AC>
-static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr,
-                       void* C, int ldc, int M, int N, int K, hipStream_t s) {
-  if (g_gemm_variant == 5 && M % BM4 == 0 && N % BN4 == 0 && K % (2 * BK) == 0) {
+static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr, void* C, int ldc,
+                       int M, int N, int K, hipStream_t s) {
+  constexpr int lds = 2 * 2 * BM4 * BK * 2;              // 128 KB: both 256x256 kernels
+  const bool sq = M % BM4 == 0 && N % BN4 == 0;
+  if (g_gemm_variant == 5 && sq && K % (2 * BK) == 0) {
     auto kern = gemm_16_nt_256p8<T16, OF, RS, AC>;
-    constexpr int lds = 2 * 2 * BM4 * BK * 2;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
     (void)done;
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
                        g_tile_order);
-  } else if (g_gemm_variant == 4 && M % BM4 == 0 && N % BN4 == 0) {
-    auto kern = gemm_16_nt_256ar<T16, OF, RS, AC>;
-    constexpr int lds = 2 * 2 * BM4 * BK * 2;
-    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
-    (void)done;
-    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order);
-  } else if (g_gemm_variant >= 3 && M % BM4 == 0 && N % BN4 == 0) {
+  } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
-    constexpr int lds = 2 * 2 * BM4 * BK * 2;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
     (void)done;
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order);
-  } else if (g_gemm_variant == 2) {
-    const int ntiles = (M / BM) * (N / BN);
-    int grid = g_gemm_persist_blocks < ntiles ? g_gemm_persist_blocks : ((ntiles + 7) / 8) * 8;
-    hipLaunchKernelGGL((gemm_16_nt_128p<T16, OF, RS, AC>), dim3(grid), dim3(256), 0, s, a, lda, w, ldw, bias, residual, ldr, C, ldc,
-                       M, N, K, g_tile_order);
-  } else if (big) {
-    static bool attr_set = false;
-    auto kern = gemm_16_nt_256<T16, OF, RS, AC>;
-    constexpr int lds = 3 * (BM2 + BN) * BK * 2;
-    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
-    (void)done; (void)attr_set;
-    hipLaunchKernelGGL(kern, dim3((M / BM2) * (N / BN)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
                        g_tile_order);
   } else {
     hipLaunchKernelGGL((gemm_16_nt_128<T16, OF, RS, AC>), dim3((M / BM) * (N / BN)), dim3(256), 0, s, a, lda, w, ldw, bias, residual,
@@ -1121,10 +715,9 @@ static void launch_one(bool big, const T16* a, int lda, const T16* w, int ldw, c
 template <typename T16>
 static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, int res,
                          void* C, int ldc, bool of, int M, int N, int K, int act, hipStream_t s) {
-  const bool big = g_gemm_variant == 1 && (M % BM2 == 0);
   const T16* a = (const T16*)A;
   const T16* w = (const T16*)W;
-#define LAUNCH(OF, RS, AC) launch_one<T16, OF, RS, AC>(big, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, s)
+#define LAUNCH(OF, RS, AC) launch_one<T16, OF, RS, AC>(a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, s)
   if (act == RUART_ACT_GELU) {
     if (res != 0) return (int)hipErrorInvalidValue;
     if (of) LAUNCH(true, 0, 1); else LAUNCH(false, 0, 1);

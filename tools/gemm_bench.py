@@ -15,7 +15,7 @@ ap.add_argument("--rows", type=int, default=42880)
 ap.add_argument("--dtype", default="fp16")
 ap.add_argument("--orders", default="0,4,8,16")
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--variants", default="0,3")
+ap.add_argument("--variants", default="3,5")
 a = ap.parse_args()
 lib = hip.load()
 d = torch.device("cuda:0")

@@ -17,7 +17,7 @@ for dt in (hip.DT_F16, hip.DT_BF16):
         if res: ref = ref + R.double()
         Ad, Wd, bd = A.to(d), W.to(d), bias.to(d); Rd = R.to(d) if res else None
         outs = {}
-        for v in (0, 1, 2, 3, 4, 5):
+        for v in (0, 3, 5):
             lib.ruart_gemm_set_variant(v)
             C = torch.full((M, N), float("nan"), dtype=torch.float32 if res else td, device=d)
             rc = lib.ruart_gemm_16_nt(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), hip.ptr(Rd), N, dt, hip.ptr(C), N, hip.DT_F32 if res else dt, M, N, K, act, dt, hip.stream_ptr())
