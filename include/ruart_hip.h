@@ -176,6 +176,13 @@ int ruart_lstm_cell_fwd(const float* pre, const float* h_prev, const float* c_pr
 int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* acts, const float* c_prev, const float* c_out,
                         float* grad_pre, float* grad_h_prev, float* grad_c_prev, int n_active, int n_rows, int h, void* stream);
 
+/* Weight gradient of an embedding lookup (Models/SDNet.py:439-493, nn.Embedding tables) from a sort of the ids prepared on the
+ * host: order[n] = lookup positions grouped by table row, seg_start[n_seg + 1] = slices of order[], seg_row[n_seg] = the table
+ * row of each slice.  grad_out (n, D) fp32; grad_weight (rows, D) must be zero-filled by the caller; rows are summed in the
+ * order given (deterministic).  Replaces the device-side sort torch runs in every backward. */
+int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg, int D,
+                               float* grad_weight, void* stream);
+
 /* NaN contract of the reference (assert torch.sum(torch.isnan(x)) == 0, Layers.py:169,290,430,462,467): after this
  * call every SDNet kernel ORs 1 into *flag (a device int) when it writes a NaN; the Python layer checks and clears it
  * once per step instead of one device->host sync per op.  Pass NULL to disable. */

@@ -133,6 +133,7 @@ class ItemIndex:
         mask[np.arange(max_num)[None, :] < num_cnt[:, None]] = 1
         self.mask = mask
         self.dev = None
+        self.emb_sort = {}
 
     _FIELDS = ("item_of_word", "sample_of_word", "tok_in_sample", "step_rows", "sorted_sample", "sorted_slot", "flat_word")
 
@@ -141,6 +142,22 @@ class ItemIndex:
 
     def bind(self, tensors):
         self.dev = dict(zip(self._FIELDS, tensors))
+
+
+def _sort_ids(ids, padding_idx=None):
+    """(order, seg_start, seg_row) int32 of an id vector: positions grouped by id (stable), the group boundaries and the id of
+    each group; the padding row (its gradient is defined as zero) is left out."""
+    ids = np.asarray(ids, dtype=np.int64)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    if padding_idx is not None:
+        keep = sid != padding_idx
+        order, sid = order[keep], sid[keep]
+    if len(sid) == 0:
+        return np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
+    first = np.concatenate([[True], sid[1:] != sid[:-1]])
+    starts = np.flatnonzero(first)
+    return order.astype(np.int32), np.concatenate([starts, [len(sid)]]).astype(np.int32), sid[starts].astype(np.int32)
 
 
 class BatchIndex:
@@ -188,6 +205,17 @@ class BatchIndex:
             self._spans_host = (np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32),
                                 [(len(t[0]), t[3]) for t in spans])
             self.packed.group_index = None             # (N, L) maps were only needed for the spans: keep the pickle small
+        # sort of every embedding lookup's ids (word / POS / entity tables), for ops.embedding's backward
+        self._emb_host = {}
+        q_keys = [k for k in ("glove", "fasttext", "phoc", "pos", "ent") if k in q_list and isinstance(q_list[k], torch.Tensor)]
+        for k in q_keys:
+            self._emb_host[("q", k)] = _sort_ids(_np(q_list[k]).reshape(-1), 1 if k in ("glove", "fasttext", "phoc") else None)
+        for name, items, idx in (("ocr", ocr_list, self.ocr), ("od", od_list, self.od)):
+            for k in ("glove", "fasttext", "phoc", "pos", "ent"):
+                if k in items and isinstance(items[k], torch.Tensor):
+                    self._emb_host[(name, k)] = _sort_ids(_np(items[k]).reshape(-1)[idx.flat_word],
+                                                          1 if k in ("glove", "fasttext", "phoc") else None)
+        self.emb_sort = {}
         if device is not None:
             self.to(device)
 
@@ -204,6 +232,19 @@ class BatchIndex:
         self.od.bind(parts[n:])
         self.ocr_mask = torch.from_numpy(self.ocr.mask).to(self.device, non_blocking=True)
         self.od_mask = torch.from_numpy(self.od.mask).to(self.device, non_blocking=True)
+        if self._emb_host:
+            keys = list(self._emb_host)
+            flat = np.concatenate([np.concatenate(self._emb_host[k]) for k in keys]).astype(np.int32)
+            dev = torch.from_numpy(flat).to(self.device, non_blocking=True)
+            o = 0
+            for k in keys:
+                parts = []
+                for a in self._emb_host[k]:
+                    parts.append(dev[o:o + len(a)])
+                    o += len(a)
+                self.emb_sort[k] = tuple(parts)
+            self.ocr.emb_sort = {k[1]: v for k, v in self.emb_sort.items() if k[0] == "ocr"}
+            self.od.emb_sort = {k[1]: v for k, v in self.emb_sort.items() if k[0] == "od"}
         if self.packed is not None:
             self.packed.bind(self.device)
             cat, shapes = self._spans_host

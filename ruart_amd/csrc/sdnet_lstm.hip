@@ -237,3 +237,52 @@ extern "C" int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, con
   RUART_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding weight gradient from a HOST-prepared sort (Models/SDNet.py:439-493 looks words / POS / entity ids up in
+// nn.Embedding tables; torch's backward sorts the ids on the device every step - ~100 launches and ~1 ms for the step's nine
+// lookups).  The ids of a batch are known when it is collated, so ruart_amd.batch.BatchIndex sorts them there (numpy, in the
+// loader worker): order[] lists the lookup positions grouped by table row, seg_start[s] .. seg_start[s+1] is the slice of
+// order[] that hit row seg_row[s].  One workgroup per distinct row adds its gradient rows in that fixed order (no atomics:
+// deterministic); rows that were never looked up keep the zero the caller filled gw with.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* __restrict__ gy, const int* __restrict__ order,
+                                                                   const int* __restrict__ seg_start, const int* __restrict__ seg_row,
+                                                                   float* __restrict__ gw, int D, int dpad) {
+  __shared__ float red[256];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int beg = seg_start[s], end = seg_start[s + 1];
+  float* dst = gw + (size_t)seg_row[s] * D;
+  const int G = 256 / dpad;                     // occurrence groups working side by side on narrow tables (dpad = 8..256)
+  const int g = tid / dpad, dl = tid % dpad;
+  for (int d0 = 0; d0 < D; d0 += dpad) {
+    const int d = d0 + dl;
+    float acc = 0.f;
+    if (d < D)
+      for (int i = beg + g; i < end; i += G) acc += gy[(size_t)order[i] * D + d];
+    if (G == 1) {
+      if (d < D) dst[d] = acc;
+      continue;
+    }
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    if (g == 0 && d < D) {
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += red[q * dpad + dl];          // fixed order
+      dst[d] = t;
+    }
+  }
+}
+
+extern "C" int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg,
+                                          int D, float* grad_weight, void* stream) {
+  if (n_seg < 0 || D <= 0 || D > 4096) return (int)hipErrorInvalidValue;
+  if (n_seg == 0) return 0;
+  int dpad = 8;
+  while (dpad < D && dpad < 256) dpad <<= 1;
+  hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, grad_out, order, seg_start, seg_row,
+                     grad_weight, D, dpad);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}

@@ -326,3 +326,34 @@ class _LstmCell(torch.autograd.Function):
 def lstm_cell(pre, h_prev, c_prev, n_active):
     """pre (n_active, 4h), h_prev / c_prev (N, h) -> (h, c) of all N rows; rows >= n_active pass through."""
     return _LstmCell.apply(pre.contiguous(), h_prev.contiguous(), c_prev.contiguous(), int(n_active))
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _Embedding(torch.autograd.Function):
+    """weight[ids] whose backward uses a host-prepared sort of the ids (ruart_embedding_bwd_sorted) instead of sorting on the
+    device: ``sort`` = (order, seg_start, seg_row) int32 device tensors from batch.BatchIndex (padding_idx already left out)."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, order, seg_start, seg_row):
+        ctx.save_for_backward(order, seg_start, seg_row)
+        ctx.wshape = weight.shape
+        return weight.index_select(0, ids.reshape(-1)).view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        order, seg_start, seg_row = ctx.saved_tensors
+        V, D = ctx.wshape
+        gw = torch.zeros(V, D, dtype=torch.float32, device=gy.device)
+        gy = gy.reshape(-1, D).contiguous()
+        hip.check(hip.load().ruart_embedding_bwd_sorted(hip.ptr(gy), hip.ptr(order), hip.ptr(seg_start), hip.ptr(seg_row),
+                                                        seg_row.numel(), D, hip.ptr(gw), hip.stream_ptr()), "ruart_embedding_bwd_sorted")
+        return gw, None, None, None, None
+
+
+def embedding(module, ids, sort=None):
+    """``module(ids)`` for an nn.Embedding; with ``sort`` (and a trainable fp32 table on the device) the gradient takes the
+    host-sorted path."""
+    w = module.weight
+    if sort is None or not w.requires_grad or not torch.is_grad_enabled() or not w.is_cuda or w.dtype != torch.float32:
+        return module(ids)
+    return _Embedding.apply(w, ids, *sort)

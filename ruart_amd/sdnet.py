@@ -281,18 +281,20 @@ class SDNet(nn.Module):
         dev = self.device
         parts, raw = [], None
         p_emb = self.opt.get("dropout_emb", 0.0)
+        bi = q_list.get("_ruart_index")
+        srt = bi.emb_sort if bi is not None else {}
         for key in ("phoc", "fasttext", "glove"):
             if key in self.q_embedding:
-                e = getattr(self, self._word_table(key))(q_list[key].to(dev))
+                e = ops.embedding(getattr(self, self._word_table(key)), q_list[key].to(dev), srt.get(("q", key)))
                 if key == self.opt["q_emb_initial"]:
                     raw = e
                 parts.append(dropout(e, p=p_emb, training=self.drop_emb) if "dropout_emb" in self.opt else e)
         if "bert" in self.q_embedding:
             parts.append(dropout(bert_mix, p=p_emb, training=self.drop_emb))
         if "pos" in self.q_embedding:
-            parts.append(self.pos_embedding(q_list["pos"].to(dev)))
+            parts.append(ops.embedding(self.pos_embedding, q_list["pos"].to(dev), srt.get(("q", "pos"))))
         if "ent" in self.q_embedding:
-            parts.append(self.ent_embedding(q_list["ent"].to(dev)))
+            parts.append(ops.embedding(self.ent_embedding, q_list["ent"].to(dev), srt.get(("q", "ent"))))
         return torch.cat(parts, -1), raw
 
     def _embed_items(self, items, idx, bert_mix):
@@ -305,16 +307,16 @@ class SDNet(nn.Module):
         for key in ("phoc", "fasttext", "glove"):
             if key in self.ocr_embedding:
                 ids = items[key].to(dev).reshape(-1)[d["flat_word"]]
-                e = getattr(self, self._word_table(key))(ids)
+                e = ops.embedding(getattr(self, self._word_table(key)), ids, idx.emb_sort.get(key))
                 if key == self.opt["ocr_emb_initial"]:
                     raw = e
                 parts.append(row_dropout(e, d["item_of_word"], idx.N, p_emb, self.drop_emb) if "dropout_emb" in self.opt else e)
         if "bert" in self.ocr_embedding:
             parts.append(row_dropout(bert_mix, d["item_of_word"], idx.N, p_emb, self.drop_emb))
         if "pos" in self.ocr_embedding:
-            parts.append(self.pos_embedding(items["pos"].to(dev).reshape(-1)[d["flat_word"]]))
+            parts.append(ops.embedding(self.pos_embedding, items["pos"].to(dev).reshape(-1)[d["flat_word"]], idx.emb_sort.get("pos")))
         if "ent" in self.ocr_embedding:
-            parts.append(self.ent_embedding(items["ent"].to(dev).reshape(-1)[d["flat_word"]]))
+            parts.append(ops.embedding(self.ent_embedding, items["ent"].to(dev).reshape(-1)[d["flat_word"]], idx.emb_sort.get("ent")))
         return torch.cat(parts, -1), raw
 
     def _prealign(self, raw_words, idx, q_raw, q_mask):

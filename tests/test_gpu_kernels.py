@@ -465,3 +465,34 @@ def test_linear_x3_fused_dropout_mask():
         scale = float(r_.abs().max())
         assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
     assert bool((got[1][mask.unsqueeze(1).expand_as(x) == 0] == 0).all())      # dropped features get exactly zero gradient
+
+
+@pytest.mark.parametrize("V,D,n,pad", [(2000, 300, 17000, 1), (51, 12, 17000, None), (75, 8, 2560, None), (300, 300, 40, 1), (10, 1000, 500, None)])
+def test_embedding_backward_from_host_sort(V, D, n, pad):
+    """ops.embedding: forward = table lookup; backward = ruart_embedding_bwd_sorted driven by the host-side sort of the ids
+    (batch._sort_ids): must equal nn.Embedding's gradient (padding row zero), for wide word tables, narrow POS / entity tables
+    with thousands of hits per row, and rows that are never hit."""
+    from ruart_amd import ops
+    from ruart_amd.batch import _sort_ids
+    g = torch.Generator().manual_seed(V + D + n)
+    emb = torch.nn.Embedding(V, D, padding_idx=pad).cuda()
+    ids = torch.randint(0, V, (n,), generator=g)
+    if pad is not None:
+        ids[::7] = pad
+    sort = tuple(torch.from_numpy(a).cuda() for a in _sort_ids(ids.numpy(), pad))
+    gy = torch.randn(n, D, generator=g).cuda()
+    out = ops.embedding(emb, ids.cuda(), sort)
+    out.backward(gy)
+    got = emb.weight.grad.clone()
+    emb.weight.grad = None
+    ref_out = emb(ids.cuda())
+    ref_out.backward(gy)
+    assert torch.equal(out, ref_out)
+    ref = emb.weight.grad
+    assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    if pad is not None:
+        assert float(got[pad].abs().max()) == 0.0
+    out2 = ops.embedding(emb, ids.cuda(), sort)                      # deterministic: same sum order every time
+    emb.weight.grad = None
+    out2.backward(gy)
+    assert torch.equal(emb.weight.grad, got)
