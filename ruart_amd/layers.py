@@ -329,13 +329,29 @@ class DeepAttention(nn.Module):
         self.rnn, self.output_size = RNN_from_opt(rnn_input_size, opt["highlvl_hidden_size"], num_layers=1)
         self.opt = opt
 
-    def forward(self, x1_word, x1_abstr, x2_word, x2_abstr, x1_mask, x2_mask, return_bef_rnn=False, return_score=False):
+    def forward(self, x1_word, x1_abstr, x2_word, x2_abstr, x1_mask, x2_mask, return_bef_rnn=False, return_score=False, helper=None):
+        """``helper``: an otherwise idle stream; the attention levels read the same two inputs and do not depend on each other
+        (Layers.py:508-517 only concatenates their outputs), so one of them can run there beside the others."""
         if return_score:
             raise NotImplementedError("return_score is not used by SDNet.forward")
         x1_att = torch.cat(x1_word + x1_abstr, 2)
         x2_att = torch.cat(x2_word + x2_abstr[:-1], 2)
-        x1 = torch.cat(x1_abstr, 2)
+        outs = [None] * len(x2_abstr)
+        side = 1 if (helper is not None and len(x2_abstr) >= 2 and x1_att.is_cuda) else -1
+        if side >= 0:
+            cur = torch.cuda.current_stream(x1_att.device)
+            helper.wait_stream(cur)
+            with torch.cuda.stream(helper):
+                outs[side] = self.int_attn_list[side](x1_att, x2_att, x2_mask, x3=x2_abstr[side])
         for i, x2_i in enumerate(x2_abstr):
-            x1 = torch.cat((x1, self.int_attn_list[i](x1_att, x2_att, x2_mask, x3=x2_i)), 2)
+            if i != side:
+                outs[i] = self.int_attn_list[i](x1_att, x2_att, x2_mask, x3=x2_i)
+        if side >= 0:
+            cur.wait_stream(helper)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (x1_att, x2_att, x2_abstr[side]):
+                    t.record_stream(helper)
+                outs[side].record_stream(cur)
+        x1 = torch.cat(list(x1_abstr) + outs, 2)
         x1_hiddens = self.rnn(x1, x1_mask)
         return (x1_hiddens, x1) if return_bef_rnn else x1_hiddens

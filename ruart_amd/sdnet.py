@@ -109,21 +109,23 @@ class _Trunk(nn.Module):
                 q_merged = self.ques_merger.merge(q_final, q_mask)
             q_long = [q_raw]
 
-            def context_branch(x, mask):
+            def context_branch(x, mask, helper=None):
                 """context_rnn, deep_attn, self-attention, high-level rnn for OCR tokens or objects"""
                 _, rnn_layers = self.context_rnn(x, mask, return_list=True, LN=True)
                 if ev_q_layers is not None:
                     torch.cuda.current_stream(dev).wait_event(ev_q_layers)
                     for t in q_rnn_layers:
                         _record(t, torch.cuda.current_stream(dev))
-                h, pre = self.deep_attn([x], rnn_layers, q_long, q_rnn_layers, mask, q_mask, return_bef_rnn=True)
+                h, pre = self.deep_attn([x], rnn_layers, q_long, q_rnn_layers, mask, q_mask, return_bef_rnn=True, helper=helper)
                 sa_in = torch.cat([h, pre, x], 2)
                 sa = self.highlvl_self_att(sa_in, sa_in, mask, x3=h)
                 return self.high_lvl_context_rnn(torch.cat([h, sa], 2), mask, LN=True)
 
             with torch.cuda.stream(s_od):                                       # ---- object branch
                 od_hl = context_branch(x_od, od_mask)
-            ocr_hl = context_branch(x_ocr, ocr_mask)                            # ---- OCR branch on the main stream
+            # ---- OCR branch (the longest chain) on the main stream; one of its three independent deep-attention levels borrows
+            #      the question stream, which is idle by then
+            ocr_hl = context_branch(x_ocr, ocr_mask, helper=s_q if use_streams else None)
             _join(main, (s_od, s_q), [od_hl, q_merged])
 
             if "position_dim" in opt:
@@ -360,22 +362,20 @@ class SDNet(nn.Module):
         self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
         lw = self._layer_weights()
         H = self.Bert.weights.hidden
-        mixes = []
-        for (s, l, dst, rows) in bi.spans:
-            mixes.append(_PoolMix.apply(lw, layers, s, l, dst, rows, self.Bert.weights.dtype))
         Bq, Q = q_list[opt["q_emb_initial"]].shape
-        q_bert = mixes[0].view(Bq, Q, H)
         q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev).to(torch.uint8)    # once: the attention kernels take uint8
         ocr_mask, od_mask = bi.ocr_mask, bi.od_mask
 
-        # ---- front: variable-size part (real words of this batch): embeddings, pre-align, multi2one -----------
-        # The OCR and object groups are independent: objects on a side stream, OCR on the main one.
+        # ---- front: variable-size part (real words of this batch): BERT pooling, embeddings, pre-align, multi2one -------
+        # Three independent groups on three streams (their backward runs there too): question on s_q, objects on s_od, OCR
+        # tokens - the heaviest - on the main stream.  The item groups need the question's raw word vectors for pre-align.
         main = torch.cuda.current_stream(dev)
         use_streams = bool(opt.get("ruart_streams", True))
         s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
-        q_input, q_raw = self._embed_question(q_list, q_bert)
-        if "PRE_ALIGN_befor_rnn" in opt:
-            q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
+
+        def pooled(g):
+            s_, l_, dst, rows = bi.spans[g]
+            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, self.Bert.weights.dtype)
 
         def front(items, idx, mix):
             words, raw = self._embed_items(items, idx, mix)
@@ -383,11 +383,24 @@ class SDNet(nn.Module):
                 words = torch.cat([words, self._prealign(raw, idx, q_raw, q_mask)], -1)
             return self._multi2one_last(words, idx)                             # (B, max_num, 300)
 
-        _fork(main, (s_od,), [q_raw, q_mask, mixes[2]])
+        _fork(main, (s_q, s_od), [lw, layers, q_mask])
+        with torch.cuda.stream(s_q):
+            q_input, q_raw = self._embed_question(q_list, pooled(0).view(Bq, Q, H))
+            ev_q = s_q.record_event() if use_streams else None
+        if "PRE_ALIGN_befor_rnn" in opt:
+            q_list[opt["q_emb_initial"] + "_emb"] = q_raw                      # the reference's side effect (SDNet.py:449-459)
         with torch.cuda.stream(s_od):
-            x_od = front(od_list, bi.od, mixes[2])
-        x_ocr = front(ocr_list, bi.ocr, mixes[1])
-        _join(main, (s_od,), [x_od])
+            mix_od = pooled(2)
+            if ev_q is not None:
+                s_od.wait_event(ev_q)
+                _record(q_raw, s_od)
+            x_od = front(od_list, bi.od, mix_od)
+        mix_ocr = pooled(1)
+        if ev_q is not None:
+            main.wait_event(ev_q)
+            _record(q_raw, main)
+        x_ocr = front(ocr_list, bi.ocr, mix_ocr)
+        _join(main, (s_od, s_q), [x_od, q_input, q_raw])
 
         # ---- trunk: fixed-shape part (B, L, D) - eager, or one hipGraph replay per direction ------------------
         if "position_dim" in opt:
