@@ -50,10 +50,23 @@ __device__ __forceinline__ Act no_act() { return Act{0, nullptr, 0}; }
 // stage rows [r0, r0+nr) x cols [c0, c0+CH) of a row-major (rows x cols, ld) matrix into dst[nr_pad][ldd], zero-filled
 __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols,
                                       Act act = Act{0, nullptr, 0}) {
-  for (int e = threadIdx.x; e < nr_pad * CH; e += blockDim.x) {
-    const int r = e / CH, c = e % CH;
-    const int gr = r0 + r, gc = c0 + c;
-    dst[r * ldd + c] = (gr < rows && gc < cols) ? act(src[(size_t)gr * ld + gc], gc) : 0.f;
+  // sixteen independent loads in flight per thread before the first LDS store (the loop is latency-bound otherwise: every
+  // iteration would wait ~0.5 us for its own L2 round trip)
+  const int total = nr_pad * CH;
+  for (int e0 = threadIdx.x; e0 < total; e0 += 16 * blockDim.x) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = e0 + u * blockDim.x;
+      const int r = e / CH, c = e % CH;
+      const int gr = r0 + r, gc = c0 + c;
+      v[u] = (e < total && gr < rows && gc < cols) ? act(src[(size_t)gr * ld + gc], gc) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = e0 + u * blockDim.x;
+      if (e < total) dst[(e / CH) * ldd + (e % CH)] = v[u];
+    }
   }
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
