@@ -71,10 +71,18 @@ __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const flo
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
 __device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols) {
-  for (int e = threadIdx.x; e < 16 * CH; e += blockDim.x) {
+  float v[4];                                  // 16 * CH = 1024 elements, 256 threads: all four loads in flight together
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = threadIdx.x + u * 256;
     const int c = e & 15, r = e >> 4;          // c: 16 source columns (fast), r: 64 source rows
     const int gr = r0 + r, gc = c0 + c;
-    dst[c * ldd + r] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+    v[u] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = threadIdx.x + u * 256;
+    dst[(e & 15) * ldd + (e >> 4)] = v[u];
   }
 }
 
