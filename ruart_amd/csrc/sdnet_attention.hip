@@ -395,10 +395,135 @@ static size_t attn_lds_bytes(int L2) {
   return sizeof(float) * (size_t)(16 * LDA_ + 16 * ldS + L2p * LDB_);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-query form (L1 == 1, no activation): LinearSelfAttn.merge and the no-answer score (Layers.py:310-322, 421-432) attend with
+// ONE query row per batch element.  The tiled kernels above would run a 16-row MFMA tile for it and walk the key / value
+// panels through LDS with two barriers per 64 columns (~100 us for 64 x 100 x 500); here one workgroup per batch element does
+// the dot products with wave reductions and the context with coalesced row reads (~10 us).  Same arithmetic order per output
+// on every run (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                        float* __restrict__ out, float* __restrict__ probs, int L2, int h, int D3,
+                                                        int* __restrict__ nan_flag) {
+  __shared__ float p_s[ATTN_MAX_L2];
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ab = a + (size_t)b * h;
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  for (int j0 = wave * 4; j0 < L2; j0 += 16) {         // a wave takes 4 keys at a time: 4 independent coalesced dot products
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane; d < h; d += 64) {
+      const float av = ab[d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < L2) s[u] = fmaf(av, kb[(size_t)(j0 + u) * h + d], s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = wave_sum(s[u]);
+      if (lane == 0 && j0 + u < L2) p_s[j0 + u] = mask[(size_t)b * L2 + j0 + u] ? t : -INFINITY;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < L2; j += 256) mx = fmaxf(mx, p_s[j]);
+  mx = block_max<4>(mx, red);
+  float sum = 0.f;
+  for (int j = tid; j < L2; j += 256) {
+    const float e = expf(p_s[j] - mx);                  // all keys masked => NaN, as the reference
+    p_s[j] = e;
+    sum += e;
+  }
+  sum = block_sum<4>(sum, red);
+  __syncthreads();
+  const float inv = 1.0f / sum;
+  bool bad = false;
+  for (int j = tid; j < L2; j += 256) {
+    const float p = p_s[j] * inv;
+    p_s[j] = p;
+    bad |= !(p == p);
+    if (probs) probs[(size_t)b * L2 + j] = p;
+  }
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+  __syncthreads();
+  for (int d = tid; d < D3; d += 256) {                 // context: rows of v read coalesced, keys in order, 8 loads in flight
+    float o = 0.f;
+    int j = 0;
+    for (; j + 8 <= L2; j += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = vb[(size_t)(j + u) * D3 + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o = fmaf(p_s[j + u], t[u], o);
+    }
+    for (; j < L2; ++j) o = fmaf(p_s[j], vb[(size_t)j * D3 + d], o);
+    out[(size_t)b * D3 + d] = o;
+  }
+}
+
+// backward of the single-query form: grad_v[j] = p_j gO, dp_j = gO . v_j, ds = p (dp - sum p dp), grad_a = sum_j ds_j k_j, grad_k[j] = ds_j a
+__global__ __launch_bounds__(256) void attn1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const float* __restrict__ probs,
+                                                        const float* __restrict__ gout, float* __restrict__ grad_a,
+                                                        float* __restrict__ grad_k, float* __restrict__ grad_v, int L2, int h, int D3) {
+  __shared__ float ds_s[ATTN_MAX_L2];
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ab = a + (size_t)b * h;
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  const float* gb = gout + (size_t)b * D3;
+  const float* pb = probs + (size_t)b * L2;
+  for (int j0 = wave * 4; j0 < L2; j0 += 16) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane; d < D3; d += 64) {
+      const float gv = gb[d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < L2) s[u] = fmaf(gv, vb[(size_t)(j0 + u) * D3 + d], s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = wave_sum(s[u]);
+      if (lane == 0 && j0 + u < L2) ds_s[j0 + u] = t;   // dp_j
+    }
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int j = tid; j < L2; j += 256) dot += ds_s[j] * pb[j];
+  dot = block_sum<4>(dot, red);
+  __syncthreads();
+  for (int j = tid; j < L2; j += 256) ds_s[j] = pb[j] * (ds_s[j] - dot);
+  __syncthreads();
+  for (int d = tid; d < h; d += 256) {
+    float g = 0.f;
+    int j = 0;
+    for (; j + 8 <= L2; j += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = kb[(size_t)(j + u) * h + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g = fmaf(ds_s[j + u], t[u], g);
+    }
+    for (; j < L2; ++j) g = fmaf(ds_s[j], kb[(size_t)j * h + d], g);
+    grad_a[(size_t)b * h + d] = g;
+  }
+  for (int e = tid; e < L2 * h; e += 256) grad_k[(size_t)b * L2 * h + e] = ds_s[e / h] * ab[e % h];
+  for (int e = tid; e < L2 * D3; e += 256) grad_v[(size_t)b * L2 * D3 + e] = pb[e / D3] * gb[e % D3];
+}
+
 extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
                               int diag_len, int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
+  if (L1 == 1 && !relu && diag_len == 0) {              // single-query fast path
+    hipLaunchKernelGGL(attn1_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, k, v, mask, out, probs, L2, h, D3,
+                       ruart_nan_flag_ptr);
+    RUART_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(ceil_div(L1, 16), B), block(256);
   attn_allow_big_lds();
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
@@ -412,6 +537,12 @@ extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, co
                               float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
+  if (L1 == 1 && !relu && diag_len == 0) {              // single-query fast path (ds_ws unused)
+    hipLaunchKernelGGL(attn1_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, k, v, probs, grad_out, grad_a, grad_k, grad_v,
+                       L2, h, D3);
+    RUART_CHECK_LAUNCH();
+    return 0;
+  }
   const bool act = relu || diag_len;
   const float* dg = diag_len ? diag : nullptr;
   attn_allow_big_lds();

@@ -268,7 +268,8 @@ def test_fused_attention_vs_reference(layers_golden, tag):
 
 
 @pytest.mark.parametrize("B,L1,L2,h,D3", [(1, 1, 1, 1, 1), (2, 205, 40, 300, 300), (3, 100, 100, 250, 250), (2, 33, 17, 8, 250),
-                                          (2, 40, 256, 37, 5), (2, 300, 300, 250, 250), (1, 20, 384, 16, 8)])
+                                          (2, 40, 256, 37, 5), (2, 300, 300, 250, 250), (1, 20, 384, 16, 8),
+                                          (64, 1, 100, 500, 500), (3, 1, 40, 250, 250), (2, 1, 384, 7, 3)])     # single-query fast path
 def test_fused_attention_shapes(B, L1, L2, h, D3):
     from ruart_amd import ops
     d = dev()
