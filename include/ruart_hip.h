@@ -183,6 +183,21 @@ int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* a
 int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg, int D,
                                float* grad_weight, void* stream);
 
+/* Optimizer step (Models/SDNetTrainer.py:366-367: clip_grad_norm_(params, grad_clipping) then Adamax.step()) over all trainable
+ * tensors in three launches.  `grads` / `params` / `exp_avg` / `exp_inf` are DEVICE arrays of device pointers (one per tensor);
+ * the work list is cut into chunks of <= 8192 elements: chunk c covers elements [c_start[c], c_start[c] + c_count[c]) of tensor
+ * c_tensor[c] (c_start multiples of 4).
+ *   ruart_grad_norm_clip: partial (n_chunks floats, scratch); norm_coef[0] = total 2-norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6)).
+ *   ruart_adamax_step:    g' = g * norm_coef[1] (norm_coef NULL: no clipping);  m += (1 - beta1)(g' - m);  u = max(beta2 u, |g'| + eps);
+ *                         p -= clr[t] * m / u  with clr[t] = lr / (1 - beta1^step_t), one DEVICE float per tensor (torch.optim.Adamax
+ *                         counts the steps of every parameter separately).
+ * The update's chunk list may leave out elements (embedding rows the trainer re-pins every step): they are not touched. */
+int ruart_grad_norm_clip(const float* const* grads, const int* c_tensor, const int* c_start, const int* c_count, int n_chunks,
+                         float max_norm, float* partial, float* norm_coef, void* stream);
+int ruart_adamax_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_inf, const int* c_tensor,
+                      const int* c_start, const int* c_count, int n_chunks, const float* norm_coef, const float* clr, float beta1,
+                      float beta2, float eps, void* stream);
+
 /* NaN contract of the reference (assert torch.sum(torch.isnan(x)) == 0, Layers.py:169,290,430,462,467): after this
  * call every SDNet kernel ORs 1 into *flag (a device int) when it writes a NaN; the Python layer checks and clears it
  * once per step instead of one device->host sync per op.  Pass NULL to disable. */

@@ -78,7 +78,16 @@ class SDNetTrainer(BaseTrainer):
         if o == "ADAM":
             self.optimizer = optim.Adamax(params, weight_decay=0.5, lr=1e-3)
         elif o == "#":
-            self.optimizer = optim.Adamax(params, lr=self.opt.get("lr", 2e-3))
+            if self.device.type == "cuda" and self.opt.get("ruart_fused_optimizer", True):
+                from .optim import FusedAdamax
+                pinned = {}
+                if "TUNE_PARTIAL" in self.opt:          # rows >= tune_partial are re-pinned after every step: never updated
+                    for flag, name in (("FastText", "fast_embed"), ("GLOVE", "glove_embed")):
+                        if flag in self.opt and getattr(self.network, name).weight.requires_grad:
+                            pinned[getattr(self.network, name).weight] = self.opt["tune_partial"]
+                self.optimizer = FusedAdamax(params, lr=self.opt.get("lr", 2e-3), pinned=pinned)
+            else:
+                self.optimizer = optim.Adamax(params, lr=self.opt.get("lr", 2e-3))
         elif o == "ADAM2":
             self.optimizer = optim.Adam(params, lr=self.opt.get("lr", 1e-3))
         elif o == "SGD":
@@ -147,8 +156,11 @@ class SDNetTrainer(BaseTrainer):
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.average_gradients()
-        torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.opt["grad_clipping"])
-        self.optimizer.step()
+        if hasattr(self.optimizer, "clip_and_step"):       # fused: global-norm clip + Adamax in three launches
+            self.optimizer.clip_and_step(self.opt["grad_clipping"])
+        else:
+            torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.opt["grad_clipping"])
+            self.optimizer.step()
         self.updates += 1
         if "TUNE_PARTIAL" in self.opt:
             tp = self.opt["tune_partial"]

@@ -163,6 +163,35 @@ def test_host_index_from_collate_gives_the_same_forward(golden):
     assert torch.equal(s1, s2)
 
 
+def test_fused_adamax_matches_torch():
+    """FusedAdamax.clip_and_step == clip_grad_norm_ + torch.optim.Adamax.step over several steps (same clip coefficient, same
+    update to fp32 rounding), including a parameter without gradient and an embedding table whose re-pinned rows are skipped."""
+    from ruart_amd.optim import FusedAdamax
+    g = torch.Generator().manual_seed(0)
+    shapes = [(20000, 300), (1000, 1250), (1000,), (7, 3, 5), (8193,), (250, 1800)]
+    ref = [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.1).cuda()) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    fixed = ref[0].detach()[1000:].clone()
+    o_ref = torch.optim.Adamax(ref, lr=2e-3)
+    o_mine = FusedAdamax(mine, lr=2e-3, pinned={mine[0]: 1000})
+    for step in range(5):
+        for k, (a, b) in enumerate(zip(ref, mine)):
+            if k == 3 and step % 2 == 0:
+                a.grad = b.grad = None
+                continue
+            gr = (torch.randn(a.shape, generator=g) * (5.0 if step == 1 else 0.01)).cuda()     # step 1 is clipped hard
+            a.grad, b.grad = gr.clone(), gr.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        o_ref.step()
+        o_mine.clip_and_step(10.0)
+        for t in (ref[0], mine[0]):
+            t.data[1000:] = fixed                                             # the trainer's re-pin
+        assert abs(float(o_mine.norm_coef[0]) - float(norm)) <= 1e-4 * float(norm)
+        for a, b in zip(ref, mine):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), (step, a.shape)
+    assert torch.equal(mine[0].detach()[1000:], fixed)
+
+
 def test_variational_dropout_contract():
     """Layers.py:23-30: one mask per (row, feature) shared over time, scaled by 1/(1-p)."""
     import ruart_amd.layers as L
