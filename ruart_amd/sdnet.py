@@ -328,7 +328,10 @@ class SDNet(nn.Module):
         x1 = raw_words.new_zeros(idx.B, max(idx.Tmax, 1), raw_words.size(1))
         x1 = x1.index_put((d["sample_of_word"], d["tok_in_sample"]), raw_words)
         att = self.pre_align(x1, q_raw, q_mask)
-        return att[d["sample_of_word"], d["tok_in_sample"]]
+        # gather by a flat row index (every row at most once): index_select's backward is a plain index_add, whereas advanced
+        # indexing with two index tensors sorts the indices on the device in every backward
+        flat = d["sample_of_word"] * att.shape[1] + d["tok_in_sample"]
+        return att.reshape(-1, att.shape[2]).index_select(0, flat)
 
     def _multi2one_last(self, x_words, idx):
         """``multi2one`` (uni-directional LSTM, SDNet.py:137, 269-271) over real words only, returning the state at
@@ -339,7 +342,7 @@ class SDNet(nn.Module):
             x_words = row_dropout(x_words, d["item_of_word"], idx.N, L.dropout_p, self.training)
         xproj = ops.linear(x_words, rnn.weight_ih_l0, rnn.bias_ih_l0 + rnn.bias_hh_l0)
         Hh = rnn.weight_hh_l0.shape[1]
-        steps = torch.split(xproj[d["step_rows"]], idx.n_active)
+        steps = torch.split(xproj.index_select(0, d["step_rows"]), idx.n_active)      # unique rows: no sort in backward
         h0 = x_words.new_zeros(idx.N, Hh)
         h, _ = L.lstm_cell_steps(steps, rnn.weight_hh_l0, idx.n_active, h0, h0)
         out = x_words.new_zeros(idx.B, idx.max_num, Hh)
