@@ -46,11 +46,30 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(const float* __restrict__
       // four independent partial sums: the 128-long dot product is the step's longest dependent chain (one wave per SIMD pair
       // cannot hide a 4-cycle FMA latency 128 times), so it is cut to 32 deep; fixed combination order keeps it deterministic
       float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+      // software-pipelined by hand: the next four 16-byte LDS reads are issued before the 16 FMAs of the current four
+      f32x4_t ha[4], hb[4];
 #pragma unroll
-      for (int j = 0; j < HP; j += 4) {
-        const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(h_s + j);
-        p0 = fmaf(w[j], hv[0], p0); p1 = fmaf(w[j + 1], hv[1], p1);
-        p2 = fmaf(w[j + 2], hv[2], p2); p3 = fmaf(w[j + 3], hv[3], p3);
+      for (int u = 0; u < 4; ++u) ha[u] = *reinterpret_cast<const f32x4_t*>(h_s + 4 * u);
+#pragma unroll
+      for (int jb = 0; jb < HP; jb += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hb[u] = *reinterpret_cast<const f32x4_t*>(h_s + jb + 16 + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + 4 * u;
+          p0 = fmaf(w[j], ha[u][0], p0); p1 = fmaf(w[j + 1], ha[u][1], p1);
+          p2 = fmaf(w[j + 2], ha[u][2], p2); p3 = fmaf(w[j + 3], ha[u][3], p3);
+        }
+        if (jb + 32 < HP) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ha[u] = *reinterpret_cast<const f32x4_t*>(h_s + jb + 32 + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + 16 + 4 * u;
+          p0 = fmaf(w[j], hb[u][0], p0); p1 = fmaf(w[j + 1], hb[u][1], p1);
+          p2 = fmaf(w[j + 2], hb[u][2], p2); p3 = fmaf(w[j + 3], hb[u][3], p3);
+        }
       }
       pre += (p0 + p1) + (p2 + p3);
     }
