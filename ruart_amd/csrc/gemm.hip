@@ -334,7 +334,17 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order
+#ifdef RUART_P8_STAMPS
+                                                           , unsigned long long* __restrict__ stamps
+#endif
+) {
+#ifdef RUART_P8_STAMPS
+#define P8_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define P8_STAMP(i)
+#endif
+  P8_STAMP(0);
   constexpr int kHalf = 128 * BK * 2;            // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   stage_w(1, 1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile 0 landed (this wave's share)
   RUART_BAR();
+  P8_STAMP(1);
   if (wave >= 4 && !(ab & 4)) RUART_BAR();   // stagger: waves 4-7 run one barrier behind
   int t = 0;
   for (; t + 2 < nt; t += 2) {
@@ -496,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   tile(I1{}, Ff{}, Ff{}, t + 1);
   if (wave < 4 && !(ab & 4)) RUART_BAR();    // waves 0-3 pair the lagging group's last barrier
   RUART_BAR();                                                  // every wave is done reading operand tiles
+  P8_STAMP(2);
 
   constexpr int ERS = 272;
   char* my = smem + wave * (32 * ERS);
@@ -536,6 +548,10 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
         store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
     }
   }
+#ifdef RUART_P8_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  P8_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -642,6 +658,10 @@ std::vector<ProfRec> g_prof_pool;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 }  // namespace
+#ifdef RUART_P8_STAMPS
+unsigned long long* g_p8_stamps = nullptr;   // diagnostic build only: 4 x s_memrealtime per workgroup
+extern "C" int ruart_gemm_set_stamps(unsigned long long* p) { g_p8_stamps = p; return 0; }
+#endif
 int g_tile_order = 8;            // GROUP_M of the tile walk (0 = plain row-major); tuning knob, see ruart_gemm_set_tile_order
 int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
 
@@ -698,8 +718,13 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     auto kern = gemm_16_nt_256p8<T16, OF, RS, AC>;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
     (void)done;
+#ifdef RUART_P8_STAMPS
+    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       g_tile_order, g_p8_stamps);
+#else
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
                        g_tile_order);
+#endif
   } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
