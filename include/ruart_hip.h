@@ -74,7 +74,7 @@ int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const floa
  * scaled by 1/sqrt(64).  Two kinds of query blocks:
  *   short windows (n_blocks): block b covers tokens [blk_q0[b], blk_q1[b]) (<= 64, whole short sequences) and stages keys
  *     [blk_k0[b], blk_k1[b]); token t attends to keys [tok_lo[t], tok_hi[t]) (its own sequence) - VALU kernel, any dtype;
- *   long blocks (n_long_blocks): 64 consecutive queries of ONE sequence, keys [lblk_k0, lblk_k1) = that whole sequence -
+ *   long blocks (n_long_blocks): up to 128 consecutive queries of ONE sequence, keys [lblk_k0, lblk_k1) = that whole sequence -
  *     MFMA flash-attention kernel, 16-bit dtypes only (in fp32 mode the host plans long sequences as short-window blocks).
  * key_bias (may be NULL) is added to every score of key j (the reference's -10000 for kept-but-masked positions). */
 int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype, int H, int n_heads, int n_blocks,
@@ -118,7 +118,7 @@ typedef struct {
   int n_blocks;
   const int *blk_q0, *blk_q1, *blk_k0, *blk_k1, *tok_lo, *tok_hi;
   const float* key_bias; /* NULL when every kept token is attendable */
-  int n_long_blocks;     /* 64-query blocks of sequences longer than 64 tokens (MFMA kernel); 0 in fp32 mode */
+  int n_long_blocks;     /* <=128-query blocks of sequences longer than 64 tokens (MFMA kernel); 0 in fp32 mode */
   const int *lblk_q0, *lblk_q1, *lblk_k0, *lblk_k1;
 } ruart_bert_batch;
 

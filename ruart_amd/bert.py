@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import hip
 
+LONG_BLOCK = 128       # queries per block of the long-sequence attention kernel (ruart_bert_attention)
 ROW_PAD = 256          # GEMM row granularity (ruart_gemm_16_nt: M % 128 == 0; the 256-row tile variant needs 256)
 
 
@@ -195,18 +196,18 @@ class PackedTokens:
 
     @staticmethod
     def _plan_blocks(lens, cu, mfma_long=True):
-        """Query blocks of <= 64 tokens.  Short sequences are packed whole into windows (VALU kernel, each lane walks its own
-        sequence's keys).  A sequence longer than 64 is split into 64-query chunks that each see the whole sequence as keys:
-        these go to the MFMA flash kernel (``mfma_long``) or, in fp32 mode, to the same VALU kernel.
+        """Query blocks.  Short sequences are packed whole into windows of <= 64 tokens (block-diagonal mask inside the window).
+        A sequence longer than 64 is split into chunks that each see the whole sequence as keys: 128-query chunks for the MFMA
+        long-sequence kernel (``mfma_long``), or 64-query chunks appended to the short list in fp32 mode (VALU kernel).
         Returns two int arrays (4, n): q0, q1, k0, k1."""
         S = len(lens)
         short, long_ = [], []
         s = 0
         while s < S:
             if lens[s] > 64:
-                tgt = long_ if mfma_long else short
-                for q0 in range(int(cu[s]), int(cu[s + 1]), 64):
-                    tgt.append((q0, min(q0 + 64, int(cu[s + 1])), int(cu[s]), int(cu[s + 1])))
+                tgt, step = (long_, LONG_BLOCK) if mfma_long else (short, 64)
+                for q0 in range(int(cu[s]), int(cu[s + 1]), step):
+                    tgt.append((q0, min(q0 + step, int(cu[s + 1])), int(cu[s]), int(cu[s + 1])))
                 s += 1
                 continue
             e = int(np.searchsorted(cu, cu[s] + 64, side="right")) - 1      # last boundary within 64 tokens

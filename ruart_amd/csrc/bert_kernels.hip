@@ -194,30 +194,89 @@ __global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------------------------
-// MFMA flash attention (16-bit modes): 64-query blocks of one long sequence (the (B, 512) north-star shape) AND windows of
-// several whole short sequences (one key tile, block-diagonal mask from tok_lo/tok_hi).
+// MFMA flash attention (16-bit modes).  Two kernels with one inner step:
+//   attn_flash_kernel       windows of several whole short sequences (<= 64 tokens per block, one key tile, block-diagonal mask:
+//                           a key belongs to a query's sequence iff their tok_lo agree; the keys' tok_lo ride along in LDS)
+//   attn_flash_long_kernel  blocks of up to 128 queries of one long sequence (the (B, 512) north-star shape): every wave owns two
+//                           16-query column blocks, so each K and V^T fragment fetched from LDS feeds two MFMAs; K/V tiles are
+//                           double-buffered (the next tile's global loads are in flight under this tile's MFMAs, one barrier per
+//                           tile); no per-lane range tests - the ragged last tile is masked through the staged key bias (-1e30)
 // Everything is laid out "query on lane&15":
 //   S^T (keys x queries) = K . Q^T      A = K rows from LDS (ds_read_b128), B = Q fragments held in registers
-//   online softmax per query column: 16 scores per lane + two cross-lane-group shuffles
+//   online softmax per query column: 16 scores per lane + two cross-lane-group shuffles; exp2 with log2(e) folded into one FMA
 //   O^T (d x queries)   += V^T . P^T    B = the S^T accumulators themselves (converted to 16-bit, no data movement:
 //                                       an accumulator tile is a valid B operand with a permuted k order, cdna guide
 //                                       section 3), A = V^T fetched with ds_read_b64_tr_b16 (hardware transpose, T10)
 //                                       in the SAME permuted key order: element j of lane group g = key 16(j>>2)+4g+(j&3).
 // K/V tiles of 64 keys are staged through registers into LDS rows of 128+16 bytes (conflict-light for both the row
 // reads and the transposed reads); rows past the sequence end are zero-filled so masked probabilities never meet NaNs.
+// __launch_bounds__(256, 2) keeps the accumulators in architectural VGPRs (the softmax reads them with VALU instructions).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tr16x4_t;
 typedef __attribute__((address_space(3))) tr16x4_t* tr_ptr_t;
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4_t;
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {       // no NaN-quieting copies: inputs are never NaN here
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// One online-softmax step of a 16-query column block over a 64-key tile: sacc (scores, masked entries = -1e30) -> probabilities
+// as the two 16-bit B fragments of the P.V product; running max m, sum l and the output accumulators are updated.
+template <typename T16>
+__device__ __forceinline__ void flash_softmax_step(f32x4_t (&sacc)[4], float& m, float& l, f32x4_t (&o)[4],
+                                                   typename Vec8<T16>::type (&pf)[2]) {
+  constexpr float kLog2e = 1.4426950408889634f;
+  float mx = max3f(sacc[0][0], sacc[0][1], sacc[0][2]);
+  mx = max3f(mx, sacc[0][3], sacc[1][0]);
+  mx = max3f(mx, sacc[1][1], sacc[1][2]);
+  mx = max3f(mx, sacc[1][3], sacc[2][0]);
+  mx = max3f(mx, sacc[2][1], sacc[2][2]);
+  mx = max3f(mx, sacc[2][3], sacc[3][0]);
+  mx = max3f(mx, sacc[3][1], sacc[3][2]);
+  mx = max3f(mx, sacc[3][3], m);
+  mx = max3f(mx, __shfl_xor(mx, 16, 64), m);
+  const float mn = max3f(mx, __shfl_xor(mx, 32, 64), m);
+  const float mn2 = mn * kLog2e;
+  float rs = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[it][r], kLog2e, -mn2));
+      sacc[it][r] = p;
+      rs += p;
+    }
+  rs += __shfl_xor(rs, 16, 64);
+  rs += __shfl_xor(rs, 32, 64);
+  if (__any(mn > m)) {                                   // the running maximum rarely moves after the first tiles
+    const float scl = __builtin_amdgcn_exp2f(m * kLog2e - mn2);
+    l *= scl;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= scl;
+    m = mn;
+  }
+  l += rs;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pf[s2][j] = (T16)sacc[2 * s2][j];
+      pf[s2][4 + j] = (T16)sacc[2 * s2 + 1][j];
+    }
+}
 
 template <typename T16>
-__global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
-                                                         const int* __restrict__ bq0, const int* __restrict__ bq1,
-                                                         const int* __restrict__ bk0, const int* __restrict__ bk1,
-                                                         const int* __restrict__ tok_lo, const int* __restrict__ tok_hi,
-                                                         const float* __restrict__ key_bias) {
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
+                                                            const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                            const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                            const int* __restrict__ tok_lo, const float* __restrict__ key_bias) {
   constexpr int RS = 144;
   __shared__ __attribute__((aligned(16))) char Ks[64 * RS];
   __shared__ __attribute__((aligned(16))) char Vs[64 * RS];
+  __shared__ __attribute__((aligned(16))) float Bs[64];
+  __shared__ __attribute__((aligned(16))) int Ls[64];
   typedef typename Vec8<T16>::type frag_t;
   const int b = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,9 +284,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
   const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
   const int tq = q0 + wave * 16 + fr;
   const bool qvalid = tq < q1;
-  // this lane's query attends to keys [lo, hi): its own sequence.  A block is either 64 queries of one long sequence
-  // (lo, hi = the whole sequence) or a window of several whole short sequences (block-diagonal mask).
-  const int lo = qvalid ? tok_lo[tq] : 0, hi = qvalid ? tok_hi[tq] : 0;
+  // a query attends to the keys of its own sequence = the keys whose first-token index equals its own; lanes past the block's
+  // last query shadow query q0 (real scores, nothing stored)
+  const int lo = tok_lo[qvalid ? tq : q0];
 
   frag_t qf[2];
   {
@@ -259,6 +318,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
       *reinterpret_cast<uint4*>(Ks + srow * RS + sc0 * 16 + 16) = kv[1];
       *reinterpret_cast<uint4*>(Vs + srow * RS + sc0 * 16) = vv[0];
       *reinterpret_cast<uint4*>(Vs + srow * RS + sc0 * 16 + 16) = vv[1];
+      if (tid < 64) {
+        const bool in = tid < tn;
+        Ls[tid] = in ? tok_lo[kt + tid] : -1;
+        Bs[tid] = (in && key_bias) ? key_bias[kt + tid] : 0.f;
+      }
     }
     __syncthreads();
 
@@ -273,61 +337,27 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
       }
     }
     // sacc[it][r] = score(key kt + it*16 + g*4 + r, query fr)
-    float mx = -1e30f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < 4; ++it) {
+      const i32x4_t lk = *reinterpret_cast<const i32x4_t*>(&Ls[it * 16 + g * 4]);
+      if (key_bias) sacc[it] += *reinterpret_cast<const f32x4_t*>(&Bs[it * 16 + g * 4]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt + it * 16 + g * 4 + r;
-        const bool ok = j >= lo && j < hi;
-        float v = sacc[it][r];
-        if (key_bias && ok) v += key_bias[j];
-        v = ok ? v : -1e30f;
-        sacc[it][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float scl = __expf(m - mn);
-    float rs = 0.f;
+      for (int r = 0; r < 4; ++r) sacc[it][r] = lk[r] == lo ? sacc[it][r] : -1e30f;
+    }
+    frag_t pf[2];
+    flash_softmax_step<T16>(sacc, m, l, o, pf);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt + it * 16 + g * 4 + r;
-        const float p = (j >= lo && j < hi) ? __expf(sacc[it][r] - mn) : 0.f;
-        sacc[it][r] = p;
-        rs += p;
-      }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * scl + rs;
-    m = mn;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] *= scl;
-
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      frag_t pf;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pf[j] = (T16)sacc[2 * s2][j];
-        pf[4 + j] = (T16)sacc[2 * s2 + 1][j];
-      }
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // transposed fetch of V: block rows (keys) 32*s2 + 4g .. +3 and +16, columns dt*16 .. +15; lane 4q+p of the 16-lane
         // group supplies row q, columns 4p..4p+3 and receives column (lane&15), rows 0..3
         const char* base = Vs + (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
-        const tr16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)base);
-        const tr16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(base + 16 * RS));
         union { struct { tr16x4_t a, b; } s; frag_t f; } u;
-        u.s.a = lo;
-        u.s.b = hi;
-        o[dt] = mfma_16x16x32(u.f, pf, o[dt]);
+        u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)base);
+        u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(base + 16 * RS));
+        o[dt] = mfma_16x16x32(u.f, pf[s2], o[dt]);
       }
-    }
   }
   if (qvalid) {
     const float inv = 1.0f / l;
@@ -335,6 +365,114 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const T16* __restrict__
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(op + dt * 16, o[dt] * inv);
   }
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
+                                                                 const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                                 const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                                 const float* __restrict__ key_bias) {
+  constexpr int RS = 144;
+  __shared__ __attribute__((aligned(16))) char Ks[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vs[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][64];
+  typedef typename Vec8<T16>::type frag_t;
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
+  int tq[2];
+  frag_t qf[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    tq[qb] = q0 + wave * 32 + qb * 16 + fr;
+    const T16* qp = qkv + (size_t)(tq[qb] < q1 ? tq[qb] : q0) * ld + h * 64 + g * 8;
+    qf[qb][0] = *reinterpret_cast<const frag_t*>(qp);
+    qf[qb][1] = *reinterpret_cast<const frag_t*>(qp + 32);
+  }
+  float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+  f32x4_t o[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 2, sc0 = (tid & 3) * 2;       // staging: row 0..63, two 16-byte chunks of K and of V
+  uint4 kv[2], vv[2];
+  float bv = 0.f;
+  auto gload = [&](int kt) {
+    if (kt + srow < k1) {
+      const T16* kp = qkv + (size_t)(kt + srow) * ld + H + h * 64 + sc0 * 8;
+      kv[0] = *reinterpret_cast<const uint4*>(kp);
+      kv[1] = *reinterpret_cast<const uint4*>(kp + 8);
+      vv[0] = *reinterpret_cast<const uint4*>(kp + H);
+      vv[1] = *reinterpret_cast<const uint4*>(kp + H + 8);
+    } else {
+      kv[0] = kv[1] = vv[0] = vv[1] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 64) bv = (kt + tid < k1) ? (key_bias ? key_bias[kt + tid] : 0.f) : -1e30f;
+  };
+  auto lstore = [&](int d) {
+    *reinterpret_cast<uint4*>(Ks[d] + srow * RS + sc0 * 16) = kv[0];
+    *reinterpret_cast<uint4*>(Ks[d] + srow * RS + sc0 * 16 + 16) = kv[1];
+    *reinterpret_cast<uint4*>(Vs[d] + srow * RS + sc0 * 16) = vv[0];
+    *reinterpret_cast<uint4*>(Vs[d] + srow * RS + sc0 * 16 + 16) = vv[1];
+    if (tid < 64) Bs[d][tid] = bv;
+  };
+  gload(k0);
+  lstore(0);
+  __syncthreads();
+  int d = 0;
+  for (int kt = k0; kt < k1; kt += 64, d ^= 1) {
+    const bool more = kt + 64 < k1;
+    if (more) gload(kt + 64);
+    const bool biased = key_bias != nullptr || kt + 64 > k1;       // uniform: otherwise the staged bias is all zero
+    f32x4_t sacc[2][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      sacc[0][it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sacc[1][it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks[d] + (it * 16 + fr) * RS + (ks * 32 + g * 8) * 2);
+        sacc[0][it] = mfma_16x16x32(kf, qf[0][ks], sacc[0][it]);
+        sacc[1][it] = mfma_16x16x32(kf, qf[1][ks], sacc[1][it]);
+      }
+    }
+    // sacc[qb][it][r] = score(key kt + it*16 + g*4 + r, query block qb column fr)
+    if (biased) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(&Bs[d][it * 16 + g * 4]);
+        sacc[0][it] += bb;
+        sacc[1][it] += bb;
+      }
+    }
+    frag_t pf[2][2];
+    flash_softmax_step<T16>(sacc[0], m[0], l[0], o[0], pf[0]);
+    flash_softmax_step<T16>(sacc[1], m[1], l[1], o[1], pf[1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char* base = Vs[d] + (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
+        union { struct { tr16x4_t a, b; } s; frag_t f; } u;
+        u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)base);
+        u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(base + 16 * RS));
+        o[0][dt] = mfma_16x16x32(u.f, pf[0][s2], o[0][dt]);
+        o[1][dt] = mfma_16x16x32(u.f, pf[1][s2], o[1][dt]);
+      }
+    if (more) lstore(d ^ 1);     // that buffer's last readers passed the barrier that ended the previous iteration
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+    if (tq[qb] < q1) {
+      const float inv = 1.0f / l[qb];
+      T16* op = ctx + (size_t)tq[qb] * ldc + h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(op + dt * 16, o[qb][dt] * inv);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,16 +621,22 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
     }
     return 0;
   }
-  // 16-bit: the MFMA kernel serves both block kinds (short windows are a one-tile call with a block-diagonal mask)
-  for (int kind = 0; kind < 2; ++kind) {
-    const int nb = kind ? n_long_blocks : n_blocks;
-    if (nb <= 0) continue;
-    const int *a0 = kind ? lblk_q0 : blk_q0, *a1 = kind ? lblk_q1 : blk_q1, *a2 = kind ? lblk_k0 : blk_k0, *a3 = kind ? lblk_k1 : blk_k1;
-    const dim3 grid(nb, n_heads), block(256);
+  // 16-bit: MFMA kernels.  Short windows are a one-tile call with a block-diagonal mask; long sequences come as blocks of up to
+  // 128 queries that see the whole sequence.
+  if (n_blocks > 0) {
+    const dim3 grid(n_blocks, n_heads), block(256);
     if (dtype == RUART_DT_BF16)
-      hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, a0, a1, a2, a3, tok_lo, tok_hi, key_bias);
+      hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
     else
-      hipLaunchKernelGGL(attn_flash_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, a0, a1, a2, a3, tok_lo, tok_hi, key_bias);
+      hipLaunchKernelGGL(attn_flash_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
+    RUART_CHECK_LAUNCH();
+  }
+  if (n_long_blocks > 0) {
+    const dim3 grid(n_long_blocks, n_heads), block(256);
+    if (dtype == RUART_DT_BF16)
+      hipLaunchKernelGGL(attn_flash_long_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+    else
+      hipLaunchKernelGGL(attn_flash_long_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
     RUART_CHECK_LAUNCH();
   }
   return 0;
