@@ -154,19 +154,19 @@ def test_packed_token_plan_on_cpu():
     for i, l in enumerate(lens):
         ids[i, :l] = g.integers(1, 99, size=l)
     p = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu")
-    # short windows (VALU kernel) and 64-query blocks of long sequences (MFMA kernel) together tile the stream
+    # short windows (<= 64 tokens) and <= 128-query blocks of long sequences (long-sequence kernel) together tile the stream
     q0, q1, k0, k1 = [np.concatenate([a.numpy(), b.numpy()]) for a, b in zip(p.blk, p.lblk)]
-    assert p.n_long_blocks == 2 + 4 and p.n_blocks + p.n_long_blocks == len(q0)      # 65 -> 2 blocks, 200 -> 4 blocks
+    assert p.n_long_blocks == 1 + 2 and p.n_blocks + p.n_long_blocks == len(q0)      # 65 -> 1 block, 200 -> 2 blocks
     for b in range(p.n_long_blocks):                                                   # a long block sees exactly one sequence
         lq0, lk0, lk1 = p.lblk[0][b].item(), p.lblk[2][b].item(), p.lblk[3][b].item()
         assert p.tok_lo[lq0].item() == lk0 and p.tok_hi[lq0].item() == lk1
     p_valu = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu", mfma_long=False)
-    assert p_valu.n_long_blocks == 0 and p_valu.n_blocks == len(q0)
+    assert p_valu.n_long_blocks == 0 and p_valu.n_blocks == p.n_blocks + 2 + 4       # fp32 mode: 64-query chunks, VALU kernel
     assert p.T == sum(lens) and p.Tp % 128 == 0 and p.Tp >= p.T
     covered = np.zeros(p.T, dtype=int)
     lo, hi = p.tok_lo.numpy(), p.tok_hi.numpy()
     for b in range(len(q0)):
-        assert 0 < q1[b] - q0[b] <= 64
+        assert 0 < q1[b] - q0[b] <= (64 if b < p.n_blocks else 128)
         covered[q0[b]:q1[b]] += 1
         assert k0[b] <= lo[q0[b]:q1[b]].min() and k1[b] >= hi[q0[b]:q1[b]].max()     # keys of every query are staged
     assert (covered == 1).all()
