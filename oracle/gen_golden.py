@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | host
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | host | dataset
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -17,6 +17,7 @@ Reference entry points exercised (file:line in /root/reference):
     Models/Layers.py:124-180,182-295,320-341,352-468,471-534
     Models/SDNet.py:253-437           SDNet.forward
     Models/SDNetTrainer.py:510-518    instance_bce_with_logits
+    Utils/VQA_Dataset.py:13-437       VQA_Dataset (+ Models/Bert/tokenization.py BertTokenizer), dataset_*.json[.gz] fixtures
 """
 import os
 import sys
@@ -375,8 +376,110 @@ def gen_host():
     save("host", **arrays)
 
 
+# ----------------------------------------------------------------------------------
+DATASET_VOCAB = (["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("abcdefghijklmnopqrstuvwxyz0123456789") +
+                 ["##" + c for c in "abcdefghijklmnopqrstuvwxyz0123456789"] +
+                 ["the", "what", "is", "sign", "stop", "##ing", "##s", "un", "##aff", "##able", "coca", "cola", "shop", "caf", "##e",
+                  "cafe", "exit", "##it", "ex", "north", "##th", "bus", "2", "##nd", "street", "park", "##ed", "!", "?", ".", ",", "-",
+                  "'", "$", "\u4e2d", "\u56fd", "naive", "brand", "name", "yes", "no", "write", "written", "on", "##on"])
+
+
+def synthetic_records(seed):
+    """Preprocessed records in the layout CoQAPreprocess writes (annotated_question / detector lists / scores), with the text
+    cases the tokenizer has to get right: capitals, accents, punctuation runs, CJK, control characters, an unknown word, a word
+    of more than 100 characters, empty word lists, repeated strings, more candidates than max_ocr_num."""
+    g = np.random.default_rng(seed)
+    texts = ["STOP", "Stopping", "unaffable", "Coca-Cola", "caf\u00e9", "Caf\u00c9!", "exit", "north", "2nd", "bus stop", "park.ed",
+             "\u4e2d\u56fd shop", "na\u00efve", "x" * 101, "zz\u0000top", "tab\tsplit", "\u00a0wide\u3000space", "$5,00", "what's", "???",
+             "q\u0301", "brand-name", "WRITTEN", "the", "\ufffdsign", "s\u200bt"]
+
+    def words_of(text):
+        return text.replace("-", " - ").split() or [text]
+
+    def annotated(text):
+        w = words_of(text)
+        return {"word": w, "wordid": g.integers(5, 900, size=len(w)).tolist(), "pos_id": g.integers(0, 51, size=len(w)).tolist(),
+                "ent_id": g.integers(0, 75, size=len(w)).tolist()}
+
+    def ocr_item(text, i, empty=False):
+        a = annotated(text)
+        if empty:
+            a = {"word": [], "wordid": [], "pos_id": [], "ent_id": []}
+        return {"word": a, "original": text, "pos": g.random(8).round(4).tolist(), "ANLS": float(np.round(g.random() ** 2, 3)),
+                "ACC": float(g.integers(0, 4)) / 10.0, "cnt": int(g.integers(0, 9)), "idx": int(i)}
+
+    def od_item(text):
+        return {"object": annotated(text), "original": text.upper(), "pos": g.random(8).round(4).tolist()}
+
+    recs = []
+    for qi in range(7):
+        n_ocr = [3, 12, 0, 140, 6, 9, 1][qi]
+        picks = g.integers(0, len(texts), size=n_ocr)
+        ocr = [ocr_item(texts[j], i, empty=(i % 11 == 5)) for i, j in enumerate(picks)]
+        gram = [ocr_item(texts[j] + " " + texts[(j + 1) % len(texts)], i) for i, j in enumerate(picks[:5])]
+        es = [ocr_item(texts[j], i) for i, j in enumerate(g.integers(0, len(texts), size=[0, 4, 15, 15, 2, 12, 0][qi]))]
+        od_texts = ["STOP", "exit", "north", "bus stop", "the", "2nd", "Caf\u00c9!", "WRITTEN", "\u4e2d\u56fd"]   # <= 8 pieces: the reference's
+        od = [od_item(od_texts[j]) for j in g.integers(0, len(od_texts), size=[2, 0, 5, 45, 1, 3, 2][qi])]    # collate rejects longer ones
+        q_text = ["What is written on the sign?", "what brand-name is the caf\u00e9", "", "Is the bus parked on 2nd street ?",
+                  "what's the exit", "WHAT IS THE \u4e2d\u56fd SHOP", "the?"][qi]
+        answers = [["stop"], ["coca cola", "Coca-Cola"], ["x"], ["yes"], [], ["answering does not require reading text in the image"],
+                   ["exit", "north exit"]][qi]
+        recs.append({"question_id": 1000 + qi, "question": q_text, "filename": "img/%d.jpg" % qi, "orign_answers": answers,
+                     "annotated_question": annotated(q_text) if q_text else {"word": [], "wordid": [], "pos_id": [], "ent_id": []},
+                     "ocr_PMTD_ASTER": ocr, "ocr_PMTD_ASTER_gram2": gram, "ES_ocr": es, "OD_bottom-up": od})
+    return recs
+
+
+def gen_dataset():
+    """Utils/VQA_Dataset.py VQA_Dataset.__getitem__ over synthetic preprocessed records, several label / list configurations,
+    followed by the reference's collate.  Inputs and expected outputs are stored as JSON (lists of ints / floats / strings)."""
+    import copy
+    import json
+    import tempfile
+    from Utils.VQA_Dataset import VQA_Dataset, VQA_collate
+    tmp = tempfile.mkdtemp()
+    vocab_path = os.path.join(tmp, "vocab.txt")
+    with open(vocab_path, "w", encoding="utf-8") as f:
+        f.write("\n".join(DATASET_VOCAB) + "\n")
+    recs = synthetic_records(5)
+    variants = {
+        "base": {},
+        "dedup_one": {"remove_same": True, "lable_way": "lable_one_offical"},
+        "yesno_relevance": {"label_yesno": True, "ES_sort_way": "relevance", "lable_way": "lable_one"},
+        "acc_all_no_es": {"score_name": "ACC", "lable_way": "lable_all", "_drop": ["ES_ocr", "label_no_answer"]},
+        "test_mode": {"_mode": "test"},
+    }
+    expected = {}
+    for name, ov in variants.items():
+        opt = default_opt(datadir="", BERT_tokenizer_file=vocab_path)
+        ov = dict(ov)
+        mode = ov.pop("_mode", "train")
+        for k in ov.pop("_drop", []):
+            opt.pop(k, None)
+        opt.update(ov)
+        ds = VQA_Dataset(copy.deepcopy(recs), opt, mode=mode)
+        samples = [ds[i] for i in range(len(ds))]
+        out = []
+        for smp in samples:
+            out.append({"q": smp["q"], "ocr": smp["ocr"], "od": smp["od"], "gt": smp["gt"].tolist(), "extra_info": smp["extra_info"]})
+        q, ocr, od, gt, extra = VQA_collate(opt).VQA_collate_fun(samples[:4])
+        coll = {"gt": gt.tolist()}
+        for nm, d in (("q", q), ("ocr", ocr), ("od", od)):
+            for k, v in d.items():
+                coll["%s:%s" % (nm, k)] = v.tolist() if isinstance(v, torch.Tensor) else v
+        expected[name] = {"n": len(ds), "samples": out, "collated": coll}
+        print(name, "samples", len(ds), "ocr counts", [len(s["ocr"]) for s in out])
+    with open(os.path.join(OUT, "dataset_input.json"), "w", encoding="utf-8") as f:
+        json.dump({"vocab": DATASET_VOCAB, "records": recs, "variants": variants}, f, ensure_ascii=True)
+    import gzip
+    with gzip.open(os.path.join(OUT, "dataset_expected.json.gz"), "wt", encoding="utf-8") as f:
+        json.dump(expected, f, ensure_ascii=True)
+    for fn in ("dataset_input.json", "dataset_expected.json.gz"):
+        print("wrote", fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "host"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "host", "dataset"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
@@ -385,3 +488,5 @@ if __name__ == "__main__":
         gen_e2e()
     if "host" in which:
         gen_host()
+    if "dataset" in which:
+        gen_dataset()

@@ -27,6 +27,12 @@ from .batch import BatchIndex
 from .bert import Bert, _PoolMix, bert_encode
 from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RNN_from_opt, dropout, row_dropout
 
+# The forward runs its question / object / OCR branches on three streams and several modules (deep attention, the high-level
+# RNNs) serve two branches, so a parameter's gradient contributions legitimately arrive from streams other than the one its
+# accumulation node was created on; autograd orders them with events.  That is the design, not a leaked graph: silence the hint.
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 _UNSUPPORTED = ("img_feature", "fixed_answers", "ModelParallel", "PRE_ALIGN_after_rnn", "label_yesno", "no_Context_Self_Attention",
                 "no_DeepAttention")
 

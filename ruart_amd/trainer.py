@@ -9,9 +9,12 @@ optimizer selection by ``opt['optimizer']`` (:307-317), global-norm clipping (:3
 
 New: ``world_size > 1`` => one process per GPU, gradients averaged with RCCL (dp.GradSync) before clipping; every rank
 holds identical parameters, so the step is "N independent B-sample reference steps with averaged gradients"
-(SURVEY.md section 8e).  Offline preprocessing, msgpack readers and the spaCy/fastText tooling are out of scope: ``train``
-takes any iterable of collated batches.
+(SURVEY.md section 8e).  ``train()`` / ``predict_for_test()`` without arguments follow the reference end to end - vocabulary and
+word vectors from ``train_meta.msgpack``, records from ``{train,val,test}-preprocessed.msgpack`` through ``dataset.VQA_Dataset``,
+run folder, best-model checkpoints, ``submission.json`` - and ``train`` also takes any iterable of collated batches.  The offline
+preprocessing itself (spaCy / fastText / detector outputs -> msgpack) stays out of scope.
 """
+import json
 import logging
 import os
 import random
@@ -22,7 +25,8 @@ import torch.nn as nn
 import torch.optim as optim
 
 from . import layers as L
-from .batch import to_device
+from .batch import VQA_collate, to_device
+from .sampler import VQA_Sampler
 from .sdnet import SDNet
 
 log = logging.getLogger(__name__)
@@ -42,11 +46,36 @@ class AverageMeter:
 
 
 class BaseTrainer:
+    """Models/BaseTrainer.py:6-69: option plumbing, the feature folder, the run folder."""
+
     def __init__(self, opt):
         self.opt = opt
         self.isTrain = False
         self.use_cuda = opt.get("cuda") is True
         self.saveFolder = opt.get("saveFolder", ".")
+        self.opt.setdefault("logFile", "log.txt")
+        if "source_dir" in opt and "datadir" in opt:     # :20-21; a caller-provided FEATURE_FOLDER stands otherwise
+            opt["FEATURE_FOLDER"] = os.path.join(opt["datadir"], "./source/data/" + opt["source_dir"] + "/")
+
+    def getSaveFolder(self):
+        """Training: the first free ``<datadir>/conf~/run_<n>``; otherwise the folder the loaded model lives in (:49-62)."""
+        if self.isTrain:
+            runid = 1
+            while os.path.exists(os.path.join(self.opt["datadir"], "conf~", "run_" + str(runid))):
+                runid += 1
+            self.saveFolder = os.path.join(self.opt["datadir"], "conf~", "run_" + str(runid))
+            os.makedirs(self.saveFolder)
+            log.info("Saving logs, model and evaluation in %s", self.saveFolder)
+        else:
+            self.saveFolder = os.path.join(self.opt["datadir"], "/".join(self.opt["MODEL_PATH"].split("/")[:2]))
+            os.makedirs(self.saveFolder, exist_ok=True)
+
+    def saveConf(self):
+        if "confFile" not in self.opt:
+            return
+        with open(self.opt["confFile"], encoding="utf-8") as f, \
+                open(os.path.join(self.saveFolder, "conf_copy"), "w", encoding="utf-8") as fw:
+            fw.writelines(f)
 
 
 class SDNetTrainer(BaseTrainer):
@@ -63,6 +92,8 @@ class SDNetTrainer(BaseTrainer):
         self.grad_sync = None
         self.fixed_answers_len = 0
         self.updates = 0
+        self.best_ANLS = self.best_ACC = -1
+        self.best_ANLS_batch = self.best_ACC_batch = -1
 
     # -- model / optimizer ------------------------------------------------------------------------------------
     def setup_model(self, vocab_embedding):
@@ -213,23 +244,93 @@ class SDNetTrainer(BaseTrainer):
                 ANLS += a if a >= 0.5 else 0
         return loss, ANLS, ACC, res, save_res
 
-    def evaluate(self, val_loader, batch_i=0, mode="dev"):
+    def _loader(self, data, sampler, workers=0):
+        from torch.utils.data import DataLoader
+        collate = VQA_collate(self.opt, prepare_index=workers > 0).VQA_collate_fun
+        return DataLoader(data, batch_sampler=sampler, collate_fn=collate, num_workers=workers)
+
+    def evaluate(self, val_data, batch_i=0, mode="dev"):
+        """Models/SDNetTrainer.py:127-176.  ``val_data`` is a ``VQA_Dataset`` (batched here in the reference's deterministic
+        order; ``dev`` keeps the best-ANLS / best-ACC checkpoints and ``save_res_last.json``, ``test`` writes
+        ``submission.json`` without the wrap-around padding of the last batch) or any iterable of collated batches (metrics
+        only).  Returns (mean loss, ANLS, ACC, predictions)."""
+        assert mode in ("train", "dev", "test")
+        from torch.utils.data import Dataset
+        is_dataset = isinstance(val_data, Dataset)
+        loader = self._loader(val_data, VQA_Sampler(val_data, self.opt["max_batch_num"], self.batch_size, False)) if is_dataset \
+            else val_data
         loss = ANLS = ACC = n = nb = 0
-        res = []
-        for batch in val_loader:
+        res, save_res = [], []
+        for batch in loader:
             batch = self.ToCUDA(batch)
-            l, a, c, r, _ = self.predict(batch)
+            l, a, c, r, sr = self.predict(batch)
             loss, ANLS, ACC, n, nb = loss + l, ANLS + a, ACC + c, n + len(r), nb + 1
             res.extend(r)
-        return loss / max(nb, 1), ANLS / max(n, 1), ACC / max(n, 1), res
+            save_res.extend(sr)
+        n_items = len(val_data) if is_dataset else n
+        loss, ANLS, ACC = loss / max(nb, 1), ANLS / max(n_items, 1), ACC / max(n_items, 1)
+        if not is_dataset:
+            return loss, ANLS, ACC, res
+        if mode == "test":
+            end = len(val_data) % self.batch_size
+            if end != 0:
+                res = res[:-(self.batch_size - end)]
+            path = os.path.join(self.saveFolder, "submission.json")
+            with open(path, "w") as wf:
+                json.dump(res, wf, indent=2)
+            log.info("%d test samples are predicted, %d predictions saved in %s", len(val_data), len(res), path)
+            return loss, ANLS, ACC, res
+        if mode == "dev":
+            with open(os.path.join(self.saveFolder, "save_res_last.json"), "w") as wf:
+                json.dump(save_res, wf, indent=2)
+            if ANLS > self.best_ANLS:
+                self.best_ANLS, self.best_ANLS_batch = ANLS, batch_i
+                self.save_for_predict(os.path.join(self.saveFolder, "ANLS_best_model.pt"))
+            if ACC > self.best_ACC:
+                self.best_ACC, self.best_ACC_batch = ACC, batch_i
+                self.save_for_predict(os.path.join(self.saveFolder, "ACC_best_model.pt"))
+        log.info("Dataset: %s Batch: %7d ANLS: %.3f Best ANLS: %.3f Batch: %d ACC: %.3f Best ACC:%.3f Batch:%d", mode, batch_i, ANLS,
+                 self.best_ANLS, self.best_ANLS_batch, ACC, self.best_ACC, self.best_ACC_batch)
+        return loss, ANLS, ACC, res
 
-    def train(self, train_loader, val_loader=None, eval_every=1500, log_every=30):
-        """The outer loop of Models/SDNetTrainer.py:107-123 over any iterable of collated batches."""
+    def _setup_from_meta(self):
+        from .dataset import load_meta
+        self.vocab, self.char_vocab, vocab_embedding = load_meta(self.opt)
+        self.setup_model(vocab_embedding)
+
+    def _records(self, split):
+        from .dataset import load_msgpack
+        return load_msgpack(os.path.join(self.opt["FEATURE_FOLDER"], split + "-preprocessed.msgpack"))["data"]
+
+    def train(self, train_loader=None, val_loader=None, eval_every=1500, log_every=30):
+        """The outer loop of Models/SDNetTrainer.py:50-123.  Without arguments it is the reference's ``train()``: run folder,
+        model from ``train_meta.msgpack`` (+ ``RESUME``), ``VQA_Dataset`` over the train / val msgpack records, the deterministic
+        ``VQA_Sampler`` stream, evaluation every ``eval_every`` batches and once more on both sets at the end.  With a loader it
+        runs over any iterable of collated batches.  Either way the next batch is staged one step ahead so that its frozen-BERT
+        pass overlaps this step's trunk."""
         self.isTrain = True
+        train_data = None
+        batch_st = 0
+        if train_loader is None:
+            from .dataset import VQA_Dataset
+            self.getSaveFolder()
+            self.saveConf()
+            self._setup_from_meta()
+            if "RESUME" in self.opt:
+                self.load_model(os.path.join(self.opt["datadir"], self.opt["MODEL_PATH"]))
+            batch_st = self.opt.get("batch_st", 0)
+            train_data = VQA_Dataset(self._records("train"), self.opt)
+            dist = torch.distributed
+            rank, world = (dist.get_rank(self.process_group), dist.get_world_size(self.process_group)) \
+                if dist.is_available() and dist.is_initialized() else (0, 1)
+            sampler = VQA_Sampler(train_data, self.opt["max_batch_num"], self.batch_size, True, batch_st=batch_st,
+                                  epoch=self.opt.get("epoch"), rank=rank, world_size=world)
+            train_loader = self._loader(train_data, sampler, workers=self.opt.get("num_worker", 0))
+            val_loader = VQA_Dataset(self._records("val"), self.opt)
         it = iter(train_loader)
         nxt = next(it, None)
         nxt = self.ToCUDA(nxt) if nxt is not None else None
-        batch_i = 0
+        batch_i = batch_st
         while nxt is not None:
             batch = nxt
             nxt = next(it, None)
@@ -240,6 +341,22 @@ class SDNetTrainer(BaseTrainer):
             if batch_i % log_every == 0:
                 log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
             batch_i += 1
+        if train_data is not None:                       # :121-122
+            self.evaluate(val_loader, batch_i - 1)
+            self.evaluate(train_data, batch_i - 1, mode="train")
+            log.info("Training over")
+
+    def predict_for_test(self):
+        """Models/SDNetTrainer.py:231-251: load the model named by ``MODEL_PATH``, predict the test records, write
+        ``submission.json`` next to it."""
+        from .dataset import VQA_Dataset
+        assert "RESUME" in self.opt
+        self.isTrain = False
+        self.getSaveFolder()
+        self._setup_from_meta()
+        self.load_model(os.path.join(self.opt["datadir"], self.opt["MODEL_PATH"]))
+        test_data = VQA_Dataset(self._records("test"), self.opt, mode="test")
+        return self.evaluate(test_data, 0, "test")
 
     # -- checkpoints ------------------------------------------------------------------------------------------
     def load_model(self, model_path):

@@ -334,3 +334,56 @@ def test_stress_config_bert_large_and_edge_batches():
     b1 = synth.synthetic_batch(opt, 1, seed=9, n_q=3, n_ocr=12, n_od=1, bert_vocab=1200)
     s1, _ = net(b1[0], b1[1], b1[2])
     assert s1.shape == (1, 301) and torch.isfinite(s1).all()
+
+
+def test_train_and_predict_from_msgpack(golden_dir, tmp_path):
+    """The reference's own entry points, end to end on its on-disk artefacts (Models/SDNetTrainer.py:50-123, 231-251):
+    ``train()`` reads train_meta / train / val msgpack, builds ``VQA_Dataset`` + sampler + collate, trains, keeps the best
+    checkpoints in ``<datadir>/conf~/run_1``; ``predict_for_test()`` resumes from that checkpoint and writes submission.json.
+    BERT comes from a HF-0.x model directory (bert_config.json + pytorch_model.bin) and a vocab.txt, as the shipped conf has it."""
+    import json
+    import msgpack
+    from ruart_amd.trainer import SDNetTrainer
+    with open(os.path.join(golden_dir, "dataset_input.json"), encoding="utf-8") as f:
+        inp = json.load(f)
+    feat = tmp_path / "source" / "data" / "stvqa"
+    feat.mkdir(parents=True)
+    for split in ("train", "val", "test"):
+        with open(feat / (split + "-preprocessed.msgpack"), "wb") as f:
+            msgpack.dump({"data": inp["records"]}, f)
+    g = np.random.default_rng(3)
+    V = 1200
+    with open(feat / "train_meta.msgpack", "wb") as f:
+        msgpack.dump({"vocab": ["w%d" % i for i in range(V)], "char_vocab": list("abc"),
+                      "glove_embedding": g.standard_normal((V, 300)).astype(np.float32).tolist(),
+                      "fast_embedding": g.standard_normal((V, 300)).astype(np.float32).tolist()}, f)
+    (tmp_path / "vocab.txt").write_text("\n".join(inp["vocab"]) + "\n", encoding="utf-8")
+    cfg = synth.bert_config(vocab_size=len(inp["vocab"]), max_position_embeddings=64)      # 12 x 768: the conf's BERT-base
+    (tmp_path / "bert").mkdir()
+    with open(tmp_path / "bert" / "bert_config.json", "w") as f:
+        json.dump(cfg, f)
+    torch.save({k: T(v) for k, v in synth.make_bert_weights(cfg, seed=5, w_std=0.05).items()}, tmp_path / "bert" / "pytorch_model.bin")
+
+    def options(**kw):
+        opt = default_opt(cuda=True, datadir=str(tmp_path), source_dir="stvqa", BERT_tokenizer_file="vocab.txt",
+                          BERT_model_file="bert/", batch_size=4, max_batch_num=5, **kw)
+        for k in ("RESUME", "epoch", "vocab_size"):
+            opt.pop(k, None)
+        return opt
+
+    tr = SDNetTrainer(options(), device="cuda:0")
+    tr.train(eval_every=3)
+    run = tmp_path / "conf~" / "run_1"
+    assert tr.updates == 5 and tr.opt["vocab_size"] == V and np.isfinite(tr.train_loss.avg)
+    assert (run / "ANLS_best_model.pt").exists() and (run / "ACC_best_model.pt").exists()
+    saved = json.load(open(run / "save_res_last.json"))
+    assert len(saved) >= 5 and tr.best_ANLS >= 0                     # 5 val samples (+ the wrap-around of the last batch)
+
+    opt = options(MODEL_PATH="conf~/run_1/ANLS_best_model.pt")
+    opt["RESUME"] = True
+    te = SDNetTrainer(opt, device="cuda:0")
+    te.predict_for_test()
+    sub = json.load(open(run / "submission.json"))
+    assert len(sub) == 6 and all("answer" in r for r in sub)         # 6 test records: padding of the last batch trimmed
+    ck = torch.load(run / "ANLS_best_model.pt", map_location="cpu")["state_dict"]["network"]
+    assert torch.equal(te.network.alphaBERT.detach().cpu(), ck["alphaBERT"])
