@@ -183,6 +183,14 @@ int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* a
 int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg, int D,
                                float* grad_weight, void* stream);
 
+/* PHOC table (Utils/cphoc.c:12-113 `build_phoc`, applied per vocabulary word by Utils/CoQAUtils.py:75-87): row w of `out`
+ * (n_words x 604 fp32, row stride ldo >= 604, ldo % 4 == 0, 16-byte aligned) = the pyramidal histogram of characters of the word
+ * chars[offsets[w] .. offsets[w+1]) - 36 unigrams x 14 regions of levels 2..5, then 50 bigrams x 2 regions of level 2; entries are
+ * 0.0 / 1.0.  Words must already be lower-cased and reduced to [a-z0-9] (Utils/phoc.py:8-10); on any other byte the reference
+ * raises: here `status` (device int, zero it first; may be NULL) receives 1 + the index of one offending word and that character
+ * is skipped.  An empty word gives a zero row. */
+int ruart_phoc_table(const unsigned char* chars, const int* offsets, int n_words, float* out, int ldo, int* status, void* stream);
+
 /* Optimizer step (Models/SDNetTrainer.py:366-367: clip_grad_norm_(params, grad_clipping) then Adamax.step()) over all trainable
  * tensors in three launches.  `grads` / `params` / `exp_avg` / `exp_inf` are DEVICE arrays of device pointers (one per tensor);
  * the work list is cut into chunks of <= 8192 elements: chunk c covers elements [c_start[c], c_start[c] + c_count[c]) of tensor

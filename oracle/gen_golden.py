@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | host | dataset
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | host | dataset | phoc
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -17,6 +17,7 @@ Reference entry points exercised (file:line in /root/reference):
     Models/Layers.py:124-180,182-295,320-341,352-468,471-534
     Models/SDNet.py:253-437           SDNet.forward
     Models/SDNetTrainer.py:510-518    instance_bce_with_logits
+    Utils/phoc.py:8-12 (+ cphoc.so)   build_phoc, phoc.npz
     Utils/VQA_Dataset.py:13-437       VQA_Dataset (+ Models/Bert/tokenization.py BertTokenizer), dataset_*.json[.gz] fixtures
 """
 import os
@@ -320,6 +321,52 @@ def gen_e2e():
     save("sdnet_e2e", **arrays)
 
 
+def gen_e2e_phoc():
+    """SDNet.forward + loss + backward with the PHOC table enabled (a PHOC conf: `PHOC`, `phoc_dim 604`, `phoc` in ocr_embedding;
+    Models/SDNet.py:26-27, 51-55, 73, 441-446): the OCR / object words carry their 604-d pyramidal character histogram next to
+    the fastText vector.  The table is the reference's build_phoc over synth.phoc_vocab_words()."""
+    from Utils.phoc import build_phoc
+    V = 600
+    opt = default_opt(vocab_size=V, PHOC=True, phoc_dim=604, ocr_embedding="fasttext,phoc,pos,ent,bert")
+    bert_cfg = synth.bert_config(vocab_size=2000)
+    seed = 1033
+    from Models.SDNet import SDNet
+    import Models.Layers as L
+    bw = synth.make_bert_weights(bert_cfg, seed=seed)
+    opt = dict(opt)
+    opt["BERT_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    table = np.array([build_phoc(w) for w in synth.phoc_vocab_words(V, seed)], dtype=np.float32)
+    sw["phoc_embed.weight"] = table
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]).clone(), "fast_embedding": T(sw["fast_embed.weight"]).clone(),
+           "phoc_embedding": T(table).clone()}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing), (missing, unexpected)
+    B = 3
+    q, ocr, od, gt, extra = synth.synthetic_batch(opt, B, seed=19, n_q=14, n_ocr=24, n_od=7, bert_vocab=2000, ragged=True)
+    L.set_dropout_prob(0.0)
+    net.train()
+    net.Bert.bert_model.eval()
+    net.drop_emb = False
+    scores, _ = net(q, ocr, od)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
+    loss.backward()
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(19), B=np.array(B), vocab_size=np.array(V), phoc_ones=table.sum(1).astype(np.int32),
+                  scores=scores.detach().numpy(), loss=np.array(loss.item()), ocr_num_cnt=np.array(ocr["num_cnt"]))
+    names, norms = [], []
+    for n_, p in net.named_parameters():
+        if n_.startswith("Bert."):
+            continue
+        names.append(n_)
+        norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+    arrays["grad_names"] = np.array(names)
+    arrays["grad_norms"] = np.array(norms)
+    arrays["grad:multi2one.rnns.0.weight_ih_l0[:8]"] = net.multi2one.rnns[0].weight_ih_l0.grad[:8].numpy().copy()
+    save("sdnet_e2e_phoc", **arrays)
+
+
 # ----------------------------------------------------------------------------------
 def synthetic_samples(opt, n, seed):
     """Per-sample dicts in the layout VQA_Dataset.__getitem__ emits (Utils/VQA_Dataset.py:145-153)."""
@@ -478,15 +525,47 @@ def gen_dataset():
         print("wrote", fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KB")
 
 
+def phoc_words(seed=9, n_random=400):
+    """Words for the PHOC fixture: the SURVEY's two known answers, every length 1..24 of a repeated letter and of mixed text
+    (region boundaries fall differently for every length), all 50 bigrams at the start / middle / end, strings the wrapper has
+    to clean, and seeded random words."""
+    g = np.random.default_rng(seed)
+    alpha = "abcdefghijklmnopqrstuvwxyz0123456789"
+    bigrams = ("th he in er an re es on st nt en at ed nd to or ea ti ar te ng al it as is ha et se ou of le sa ve ro ra ri hi ne me "
+               "de co ta ec si ll so na li la el").split()
+    words = ["the", "Hello-42", "", "a", "  STOP  ", "caf\u00e9", "x" * 70, "0123456789", "!!!", "th", "the the"]
+    words += ["a" * n for n in range(1, 25)] + ["thequickbrownfox0123456789"[:n] for n in range(1, 25)]
+    for b in bigrams:
+        words += [b, b + "xyz", "xy" + b + "z", "wxyz" + b, b + b + b]
+    for _ in range(n_random):
+        n = int(g.integers(1, 40))
+        words.append("".join(alpha[int(k)] for k in g.integers(0, 36, size=n)))
+    return words
+
+
+def gen_phoc():
+    """Utils/phoc.py build_phoc (the prebuilt cphoc.so) over phoc_words(); rows stored bit-packed."""
+    from Utils.phoc import build_phoc
+    words = phoc_words()
+    rows = np.array([build_phoc(w) for w in words], dtype=np.float32)
+    assert rows.shape == (len(words), 604) and set(np.unique(rows)) <= {0.0, 1.0}
+    save("phoc", words=np.array("\n".join(words)), n=np.array(len(words)), bits=np.packbits(rows.astype(np.uint8), axis=1),
+         ones=rows.sum(1).astype(np.int32))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "host", "dataset"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "host", "dataset", "phoc"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
         gen_bert()
     if "e2e" in which:
         gen_e2e()
+    if "e2e_phoc" in which:
+        gen_e2e_phoc()
     if "host" in which:
         gen_host()
     if "dataset" in which:
         gen_dataset()
+    if "phoc" in which:
+        gen_phoc()

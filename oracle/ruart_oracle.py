@@ -220,6 +220,8 @@ def instance_bce_with_logits(scores, labels, d1=True):
 def _embed(P, opt, bert_w, bert_cfg, items, names, word_key):
     """SDNet.py:439-493 for one of q / ocr / od.  Returns (concat embedding, raw word vectors)."""
     parts = []
+    if "phoc" in names:                                  # :441-446, first in the concatenation
+        parts.append(P["phoc_embed.weight"][items["phoc"]])
     table = P["fast_embed.weight"] if word_key == "fasttext" else P["glove_embed.weight"]
     wv = table[items[word_key]]
     parts.append(wv)
@@ -344,3 +346,53 @@ def sdnet_forward(P, opt, bert_w, bert_cfg, q, ocr, od, caps=None):
     score = get_final_scores(P, "get_answer", ocr_final, q_merged, ocr_mask, opt["ES_ocr_len"], mask_flag="mask_score" in opt)   # :428-429
     cap("get_answer", score)
     return score
+
+
+# ------------------------------------------------------------------------------------
+# PHOC word descriptor  (Utils/cphoc.c, Utils/phoc.py)
+# ------------------------------------------------------------------------------------
+_PHOC_UNIGRAMS = "abcdefghijklmnopqrstuvwxyz0123456789"
+_PHOC_BIGRAMS = ("th he in er an re es on st nt en at ed nd to or ea ti ar te ng al it as is ha et se ou of le sa ve ro ra ri hi ne me "
+                 "de co ta ec si ll so na li la el").split()
+
+
+def build_phoc_raw(word):
+    """cphoc.c:12-113.  604 floats: 36 unigrams x the 14 regions of pyramid levels 2..5, then 50 bigrams x the 2 regions of
+    level 2.  A character (bigram) spanning [lo, hi] of the word's unit interval is counted in a region when
+    (min(hi, r1) - max(lo, r0)) / (hi - lo) >= 0.5; every operation is a single-precision one, in the C source's order
+    (:33-34, :57-62, :89-98) - boundary cases depend on it.  Raises on a character outside the unigram list (:45-50)."""
+    import numpy as np
+    f = np.float32
+    out = np.zeros(604, dtype=np.float32)
+    n = len(word)
+
+    def half_inside(lo, hi, region, level):
+        r0, r1 = f(region) / f(level), f(region + 1) / f(level)
+        o0, o1 = max(lo, r0), min(hi, r1)
+        return (o1 - o0) / (hi - lo) >= f(0.5)
+
+    for i, ch in enumerate(word):
+        lo, hi = f(i) / f(n), f(i + 1) / f(n)
+        ci = _PHOC_UNIGRAMS.find(ch)
+        if ci < 0:
+            raise RuntimeError("Error: unigram %s is unknown" % ch)
+        for level in range(2, 6):
+            base = sum(l for l in range(2, 6) if l < level)
+            for region in range(level):
+                if half_inside(lo, hi, region, level):
+                    out[base * 36 + region * 36 + ci] = 1
+    for i in range(n - 1):
+        if word[i:i + 2] not in _PHOC_BIGRAMS:
+            continue
+        bi = _PHOC_BIGRAMS.index(word[i:i + 2])
+        lo, hi = f(i) / f(n), f(i + 2) / f(n)
+        for region in range(2):
+            if half_inside(lo, hi, region, 2):
+                out[36 * 14 + region * 50 + bi] = 1
+    return out
+
+
+def build_phoc(token):
+    """phoc.py:8-12: lower-case, strip, keep [a-z0-9], then the raw descriptor (as a list of floats)."""
+    token = "".join(c for c in token.lower().strip() if c in _PHOC_UNIGRAMS)
+    return build_phoc_raw(token).tolist()

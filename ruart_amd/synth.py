@@ -77,6 +77,7 @@ def sdnet_dims(opt):
         n = 0
         n += opt["glove_dim"] if "glove" in names else 0
         n += opt["fast_dim"] if "fasttext" in names else 0
+        n += int(opt["phoc_dim"]) if "phoc" in names else 0
         n += bert_dim if "bert" in names else 0
         n += opt["pos_dim"] if "pos" in names else 0
         n += opt["ent_dim"] if "ent" in names else 0
@@ -105,6 +106,8 @@ def sdnet_param_shapes(opt):
     s["gammaBERT"] = (1, 1)
     s["fast_embed.weight"] = (V, opt["fast_dim"])
     s["glove_embed.weight"] = (V, opt["glove_dim"])
+    if "PHOC" in opt:
+        s["phoc_embed.weight"] = (V, int(opt["phoc_dim"]))      # values: phoc_vocab_words() through the PHOC builder, not random
 
     def attn(name, din, hid, similarity=False):
         s[name + ".scoring.linear.weight"] = (hid, din)
@@ -208,6 +211,15 @@ def _bertify(g, n_words, bert_vocab, max_bert_len, p2=0.4):
     return ids, offs
 
 
+def phoc_vocab_words(V, seed=1033):
+    """A deterministic spelling for every word id (ids 0..4 = padding / unknown / sentinels get the empty word): the PHOC
+    table of a synthetic vocabulary is built from these, on the reference side with its ``build_phoc``, here with
+    ``ruart_amd.phoc.phoc_table``."""
+    g = np.random.default_rng(seed + 41)
+    alpha = "abcdefghijklmnopqrstuvwxyz0123456789"
+    return ["" if i < 5 else "".join(alpha[int(k)] for k in g.integers(0, 36, size=int(g.integers(1, 13)))) for i in range(V)]
+
+
 def synthetic_batch(opt, B, seed=7, n_q=30, n_ocr=100, n_od=None, bert_vocab=30522,
                     ragged=False, targets=True):
     """One batch in VQA_collate_fun layout.  ``n_ocr`` / ``n_od`` count items *including*
@@ -278,6 +290,8 @@ def synthetic_batch(opt, B, seed=7, n_q=30, n_ocr=100, n_od=None, bert_vocab=305
         d["bert_offsets"] = off
         d["position"] = torch.from_numpy(position)
         d["fasttext_mask"] = ~d["fasttext"].eq(0)
+        if "phoc" in opt["ocr_embedding"].split(","):            # the PHOC table is indexed by the same word ids
+            d["phoc"], d["phoc_mask"] = d["fasttext"].clone(), d["fasttext_mask"].clone()
         d["bert_mask"] = ~d["bert"].eq(0)
         d["num_cnt"] = num_cnt
         d["len_cnt"] = len_cnt

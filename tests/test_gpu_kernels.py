@@ -497,3 +497,27 @@ def test_embedding_backward_from_host_sort(V, D, n, pad):
     emb.weight.grad = None
     out2.backward(gy)
     assert torch.equal(emb.weight.grad, got)
+
+
+def test_phoc_table_matches_reference(golden_dir):
+    """ruart_phoc_table (one launch for the whole word list) bit-exact against the reference's build_phoc rows, against the
+    oracle on fresh random words, and the error contract for bytes outside [a-z0-9]."""
+    from ruart_amd.phoc import PHOC_DIM, build_phoc, normalize, phoc_table
+    z = np.load(os.path.join(golden_dir, "phoc.npz"))
+    words = str(z["words"]).split("\n")
+    ref = np.unpackbits(z["bits"], axis=1)[:, :PHOC_DIM].astype(np.float32)
+    got = phoc_table(words, dev()).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref), [w for w, a, b in zip(words, got, ref) if not np.array_equal(a, b)][:5]
+    g = np.random.default_rng(77)
+    alpha = "abcdefghijklmnopqrstuvwxyz0123456789"
+    fresh = ["".join(alpha[int(k)] for k in g.integers(0, 36, size=int(g.integers(1, 90)))) for _ in range(3000)]
+    got = phoc_table(fresh, dev(), normalized=True).cpu().numpy()
+    for w, row in zip(fresh[:400], got):
+        assert np.array_equal(row, O.build_phoc_raw(w)), w
+    assert set(np.unique(got)) <= {0.0, 1.0}
+    assert build_phoc("Hello-42") == O.build_phoc("Hello-42") and normalize("  Café-7 ") == "caf7"
+    assert phoc_table([], dev()).shape == (0, PHOC_DIM)
+    with pytest.raises(RuntimeError):
+        phoc_table(["ok", "not-ok"], dev(), normalized=True)          # the reference's raw builder raises on '-'
+    with pytest.raises(Exception):
+        phoc_table(["a"], "cpu")

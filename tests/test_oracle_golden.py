@@ -173,3 +173,56 @@ def test_sdnet_end_to_end(golden_dir):
         if "grad:" + name in z.files:
             close(g, z["grad:" + name], 1e-6 + 2e-4 * float(np.abs(z["grad:" + name]).max()), 0, "grad " + name)
     close(P["fast_embed.weight"].grad[:64], z["grad:fast_embed.weight[:64]"], 1e-6, 1e-3, "fast_embed grad rows")
+
+
+def _phoc_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, "phoc.npz"))
+    words = str(z["words"]).split("\n")
+    assert len(words) == int(z["n"])
+    return words, np.unpackbits(z["bits"], axis=1)[:, :604].astype(np.float32), z["ones"]
+
+
+def test_phoc_restatement(golden_dir):
+    """oracle.build_phoc against the reference's build_phoc (prebuilt cphoc.so) on 700+ words, plus the two known answers the
+    survey recorded."""
+    words, rows, ones = _phoc_case(golden_dir)
+    for w, ref in zip(words, rows):
+        got = np.array(O.build_phoc(w), dtype=np.float32)
+        assert got.shape == (604,) and np.array_equal(got, ref), w
+    assert np.flatnonzero(O.build_phoc("the")).tolist() == [19, 40, 43, 91, 115, 148, 199, 259, 292, 343, 403, 472, 504, 555]
+    assert int(sum(O.build_phoc("Hello-42"))) == 30
+    assert ones[words.index("the")] == 14 and ones[words.index("")] == 0
+    with pytest.raises(RuntimeError):
+        O.build_phoc_raw("a-b")
+
+
+def test_sdnet_end_to_end_with_phoc(golden_dir):
+    """A PHOC conf (Models/SDNet.py:26-27, 51-55, 73, 441-446): OCR / object words carry their 604-d descriptor; the table is
+    rebuilt here by the restated builder from the same synthetic spellings."""
+    z = np.load(os.path.join(golden_dir, "sdnet_e2e_phoc.npz"))
+    V = int(z["vocab_size"])
+    opt = default_opt(vocab_size=V, PHOC=True, phoc_dim=604, ocr_embedding="fasttext,phoc,pos,ent,bert")
+    cfg = synth.bert_config(vocab_size=2000)
+    bw = {k: T(v) for k, v in synth.make_bert_weights(cfg, seed=int(z["seed"])).items()}
+    sw = synth.make_sdnet_weights(opt, seed=int(z["seed"]))
+    table = np.array([O.build_phoc(w) for w in synth.phoc_vocab_words(V, int(z["seed"]))], dtype=np.float32)
+    assert np.array_equal(table.sum(1).astype(np.int32), z["phoc_ones"])
+    sw["phoc_embed.weight"] = table
+    P = {k: T(v).requires_grad_(v.shape != (1, 1, 1)) for k, v in sw.items()}
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=14, n_ocr=24, n_od=7, bert_vocab=2000,
+                                              ragged=True)
+    assert ocr["num_cnt"] == z["ocr_num_cnt"].tolist() and torch.equal(ocr["phoc"], ocr["fasttext"])
+    scores = O.sdnet_forward(P, opt, bw, cfg, q, ocr, od)
+    close(scores, z["scores"], 2e-5, 1e-4, "scores")
+    loss = O.instance_bce_with_logits(scores, gt)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    for name, ref_norm in zip(z["grad_names"].tolist(), z["grad_norms"].tolist()):
+        g = P[name].grad
+        if ref_norm < 0:
+            assert g is None or float(g.norm()) == 0.0, name
+            continue
+        got = float(g.double().norm())
+        assert abs(got - ref_norm) <= 2e-4 * max(ref_norm, 1e-3), (name, got, ref_norm)
+    ref = z["grad:multi2one.rnns.0.weight_ih_l0[:8]"]
+    close(P["multi2one.rnns.0.weight_ih_l0"].grad[:8], ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 0, "multi2one grad rows")

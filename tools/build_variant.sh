@@ -8,5 +8,5 @@ mkdir -p build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -I ruart_amd/csrc -Wno-unused-result -Wno-pass-failed "$@" \
   -c ruart_amd/csrc/gemm.hip -o build/gemm_$name.o 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libruart_hip_$name.so build/gemm_$name.o \
-  ruart_amd/csrc/bert_kernels.o ruart_amd/csrc/bert_forward.o ruart_amd/csrc/sdnet_attention.o ruart_amd/csrc/sdnet_lstm.o ruart_amd/csrc/sdnet_gemm.o ruart_amd/csrc/sdnet_optim.o
+  ruart_amd/csrc/bert_kernels.o ruart_amd/csrc/bert_forward.o ruart_amd/csrc/sdnet_attention.o ruart_amd/csrc/sdnet_lstm.o ruart_amd/csrc/sdnet_gemm.o ruart_amd/csrc/sdnet_optim.o ruart_amd/csrc/phoc.o
 echo built build/libruart_hip_$name.so
