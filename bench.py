@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
+    ap.add_argument("--unlock-bert", action="store_true",
+                    help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
     ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
     return ap.parse_args()
 
@@ -75,7 +77,7 @@ def build_trainer(opt, cfg, device, seed=1033):
     tr = SDNetTrainer(opt, device=device)
     tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
     missing, unexpected = tr.network.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
-    assert not missing and not unexpected
+    assert not unexpected and all(k.startswith("Bert.bert_model.") for k in missing), (missing, unexpected)
     del opt["bert_state"]
     return tr, sw
 
@@ -191,6 +193,9 @@ def main():
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
     if a.graph_trunk is not None:
         opt["ruart_graph_trunk"] = bool(a.graph_trunk)
+    if a.unlock_bert:
+        opt.pop("LOCK_BERT")
+        a.no_roofline = True                     # the 16-bit encoder GEMM is not on this path
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
     note("building model")
     tr, _ = build_trainer(opt, cfg, device)
@@ -285,9 +290,13 @@ def main():
         out = {"metric": "VQA samples/sec fwd+bwd (B=64, q=30, ocr=100)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=100)",
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA"}[a.precision], "data": "synthetic",
+               "vs_baseline": None,
+               "dtype": "f32 storage, split-bf16 MFMA" if a.unlock_bert and a.precision != "fp32" else
+                        {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA"}[a.precision],
+               "data": "synthetic",
                "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, 100 OCR items, "
-                                      "36 objects, bert-base 12x768 frozen, SDNet trunk fwd+bwd, Adamax" % a.batch,
+                                      "36 objects, bert-base 12x768 %s, SDNet trunk fwd+bwd, Adamax"
+                                      % (a.batch, "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
                           "parallelism": "dp%d" % world, "mode": a.mode},
                "roofline": roof}

@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | host | dataset | phoc
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -367,6 +367,44 @@ def gen_e2e_phoc():
     save("sdnet_e2e_phoc", **arrays)
 
 
+def gen_e2e_unlocked():
+    """SDNet.forward + loss + backward WITHOUT `LOCK_BERT` (Models/SDNet.py:88-94): the encoder is part of the graph and every one of
+    its parameters gets a gradient.  BERT's own dropout (re-enabled by network.train()) is configured to 0 so
+    the pass is deterministic.  Stored: scores, loss, the gradient norm of every parameter, a few gradient slices."""
+    opt = default_opt(vocab_size=600)
+    opt.pop("LOCK_BERT")
+    bert_cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    seed = 1033
+    net, opt, bw, sw, L = build_reference_sdnet(opt, bert_cfg, seed)
+    assert all(p.requires_grad for p in net.Bert.parameters())
+    B = 2
+    q, ocr, od, gt, extra = synth.synthetic_batch(opt, B, seed=23, n_q=12, n_ocr=16, n_od=6, bert_vocab=2000, ragged=True)
+    L.set_dropout_prob(0.0)
+    net.train()
+    net.drop_emb = False
+    scores, _ = net(q, ocr, od)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
+    loss.backward()
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(23), B=np.array(B), vocab_size=np.array(600),
+                  scores=scores.detach().numpy(), loss=np.array(loss.item()), ocr_num_cnt=np.array(ocr["num_cnt"]))
+    names, norms = [], []
+    for n_, p in net.named_parameters():
+        names.append(n_)
+        norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+    arrays["grad_names"] = np.array(names)
+    arrays["grad_norms"] = np.array(norms)
+    pick = {"Bert.bert_model.encoder.layer.0.attention.self.query.weight": (slice(0, 4), slice(0, 64)),
+            "Bert.bert_model.encoder.layer.11.output.dense.weight": (slice(0, 4), slice(0, 64)),
+            "Bert.bert_model.encoder.layer.5.intermediate.dense.bias": (slice(0, 64),),
+            "Bert.bert_model.embeddings.LayerNorm.gamma": (slice(0, 64),),
+            "Bert.bert_model.embeddings.position_embeddings.weight": (slice(0, 4), slice(0, 64))}
+    prm = dict(net.named_parameters())
+    for k, sl in pick.items():
+        arrays["grad:" + k] = prm[k].grad[sl].numpy().copy()
+    print("bert grads:", sum(1 for n_ in names if n_.startswith("Bert.")), "none:", [n_ for n_, v in zip(names, norms) if v < 0])
+    save("sdnet_e2e_unlocked", **arrays)
+
+
 # ----------------------------------------------------------------------------------
 def synthetic_samples(opt, n, seed):
     """Per-sample dicts in the layout VQA_Dataset.__getitem__ emits (Utils/VQA_Dataset.py:145-153)."""
@@ -554,7 +592,7 @@ def gen_phoc():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "host", "dataset", "phoc"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
@@ -563,6 +601,8 @@ if __name__ == "__main__":
         gen_e2e()
     if "e2e_phoc" in which:
         gen_e2e_phoc()
+    if "e2e_unlocked" in which:
+        gen_e2e_unlocked()
     if "host" in which:
         gen_host()
     if "dataset" in which:

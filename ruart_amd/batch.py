@@ -204,7 +204,9 @@ class BatchIndex:
                 spans.append((s, l, d, rows))
             self._spans_host = (np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32),
                                 [(len(t[0]), t[3]) for t in spans])
-            self.packed.group_index = None             # (N, L) maps were only needed for the spans: keep the pickle small
+            if "LOCK_BERT" in opt:
+                self.packed.group_index = None         # (N, L) maps were only needed for the spans: keep the pickle small
+                                                       # (the trainable encoder pads its attention per group from them)
         # sort of every embedding lookup's ids (word / POS / entity tables), for ops.embedding's backward
         self._emb_host = {}
         q_keys = [k for k in ("glove", "fasttext", "phoc", "pos", "ent") if k in q_list and isinstance(q_list[k], torch.Tensor)]

@@ -158,7 +158,7 @@ class PackedTokens:
         if device is not None:
             self.bind(device)
 
-    _DEVICE_FIELDS = ("buf", "ids", "pos", "tok_lo", "tok_hi", "blk", "lblk", "key_bias", "c_batch", "_layers", "_event", "_set")
+    _DEVICE_FIELDS = ("buf", "ids", "pos", "tok_lo", "tok_hi", "blk", "lblk", "key_bias", "c_batch", "_layers", "_event", "_set", "_train_plan")
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._DEVICE_FIELDS}
@@ -343,9 +343,24 @@ class Bert(nn.Module):
             raise ValueError("BERT checkpoint is %dx%d, conf expects %dx%d" % (cfg["num_hidden_layers"], cfg["hidden_size"],
                                                                               self.bert_layer, self.bert_dim))
         self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "fp16"))
+        self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
+        self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path
         self.pack = not opt.get("bert_no_pack", False)
         self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 0))
         self._init_pipeline()
+
+    def unlock(self):
+        """Confs without LOCK_BERT (Models/SDNet.py:88-94): the encoder's parameters become fp32 ``nn.Parameter``s under the
+        reference's names (``Bert.bert_model.*``) and every pass goes through the autograd-capable path of bert_train.py."""
+        from .bert_train import BertModelTrainable
+        if not self.pack:
+            raise NotImplementedError("the trainable encoder runs on the packed token stream (bert_no_pack is for the frozen path)")
+        state, cfg = self._source
+        self.bert_model = BertModelTrainable(state, cfg, self._device)
+        self._source = None
+
+    def lock(self):
+        self._source = None
 
     # -- encoder pipelining across steps ---------------------------------------------------------------------
     # BERT is frozen, so the encoder pass of batch t+1 depends on nothing step t produces.  ``prefetch`` launches it on a
@@ -364,8 +379,8 @@ class Bert(nn.Module):
         """Encode ``packed`` asynchronously into the buffer set the current step does NOT use; ``layers_for`` returns the
         result.  ``after_stream``: the stream whose already enqueued work (the previous consumers of that set) must finish
         first.  Call it after ``layers_for`` of the current batch."""
-        if getattr(packed, "_layers", None) is not None:
-            return
+        if getattr(packed, "_layers", None) is not None or self.bert_model is not None:
+            return                           # (a trainable encoder changes every step: nothing to run ahead)
         dev = self._device
         if self._pf_stream is None or self._pf_stream.device != dev:
             # an ordinary stream by default; a CU-masked one (ruart_stream_create_cu_masked) only on request - measured on
@@ -390,6 +405,8 @@ class Bert(nn.Module):
 
     def layers_for(self, packed):
         """All-layer encoder output of ``packed``: the prefetched one (the current stream waits for it) or computed now."""
+        if self.bert_model is not None:
+            return self.bert_model(packed, training=self.training)
         layers = getattr(packed, "_layers", None)
         if layers is not None:
             torch.cuda.current_stream(self._device).wait_event(packed._event)
@@ -407,6 +424,8 @@ class Bert(nn.Module):
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
     def encode(self, groups):
         packed = PackedTokens(groups, self._device, pack=self.pack, mfma_long=self.weights.dtype != hip.DT_F32)
+        if self.bert_model is not None:
+            return packed, self.bert_model(packed, training=self.training)
         return packed, bert_encode(self.weights, packed)
 
     def pool_mix(self, packed, layers, group, offsets, word_mask, layer_w, offsets_arr=None):
@@ -415,7 +434,11 @@ class Bert(nn.Module):
         dev = self._device
         desc = torch.from_numpy(np.concatenate([s, n, d])).to(dev)
         W = len(s)
-        out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, self.weights.dtype)
+        if self.bert_model is not None:
+            from .bert_train import pool_mix
+            out = pool_mix(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows)
+        else:
+            out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, self.weights.dtype)
         N, Lw = word_mask.shape
         return out.view(N, Lw, self.weights.hidden)
 

@@ -1,0 +1,151 @@
+"""Trainable BERT encoder for confs without ``LOCK_BERT`` (Models/SDNet.py:88-94: the encoder's parameters then simply join the
+trainer's optimizer, SDNetTrainer.py:305-311).
+
+The frozen path (bert.py) is one C call over 16-bit copies of the weights; this one keeps the parameters in fp32 under the
+reference's own names (``Bert.bert_model.embeddings.word_embeddings.weight``, ``...encoder.layer.3.attention.self.query.weight``,
+``...LayerNorm.gamma``) and builds the autograd graph out of the pieces the trunk already has, on the SAME packed token stream:
+
+  projections   ops.linear  -> ``ruart_gemm_x3`` (fp32 operands, three bf16 MFMA products) for x.W^T, dY.W and dY^T.X
+  attention     per group of sequences, padded to the group's longest REAL length: ops.fused_attention -> ``ruart_attn_fwd/bwd``
+                (the reference's -10000 key bias and a hard mask agree to the last bit in fp32: exp(-10000 + s - max) == 0);
+                plain torch (bmm, softmax, dropout) when attention-probability dropout is active or a sequence exceeds the
+                kernel's 384-key panel
+  LayerNorm / GELU / embeddings / dropout   torch (row-wise, HBM-bound; TF-style LN == F.layer_norm with eps 1e-12)
+
+Dropout follows the reference: ``hidden_dropout_prob`` after the embeddings and after both output projections,
+``attention_probs_dropout_prob`` on the attention probabilities, in training mode only (modeling.py:198, 244-246, 262, 301).
+Every layer's output is returned (modeling.py:326-333), as the linear layer mix needs all of them.
+
+Cost: fp32 storage and 3 MFMA products per GEMM - the accuracy class of the fp32 reference (tests hold parameter gradients to 1e-3
+relative), about a quarter of the frozen path's encoder speed.  16-bit backward kernels are the next step."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _Node(nn.Module):
+    """Name-only container: gives parameters the reference's dotted paths."""
+
+
+def _register(root, dotted, tensor):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Node())
+        m = getattr(m, p)
+    prm = nn.Parameter(tensor)
+    m.register_parameter(parts[-1], prm)
+    return prm
+
+
+class BertModelTrainable(nn.Module):
+    """State-dict compatible stand-in for the reference's ``BertModel`` (modeling.py:524-614) on the packed token stream."""
+
+    def __init__(self, state, cfg, device):
+        super().__init__()
+        self.cfg = dict(cfg)
+        self.hidden = int(cfg["hidden_size"])
+        self.n_layers = int(cfg["num_hidden_layers"])
+        self.n_heads = int(cfg["num_attention_heads"])
+        self.p_hidden = float(cfg.get("hidden_dropout_prob", 0.1))
+        self.p_attn = float(cfg.get("attention_probs_dropout_prob", 0.1))
+        self._p = {}
+        for k, v in state.items():
+            name = k[5:] if k.startswith("bert.") else k
+            if name.startswith("cls."):
+                continue                                   # pre-training heads: not part of BertModel
+            name = name.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+            t = (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).to(torch.float32)
+            self._p[name] = _register(self, name, t.clone().to(device))
+
+    def _ln(self, x, prefix):
+        return F.layer_norm(x, (self.hidden,), self._p[prefix + ".gamma"], self._p[prefix + ".beta"], 1e-12)
+
+    def _attention(self, qkv, plan, training):
+        """qkv (T, 3H) packed -> context (T, H).  ``plan``: per group (token index matrix padded with 0, key mask)."""
+        T = qkv.size(0)
+        nh, hd = self.n_heads, self.hidden // self.n_heads
+        outs = []
+        for idx, mask in plan["groups"]:
+            N, Lg = idx.shape
+            g = qkv.index_select(0, idx.reshape(-1)).view(N, Lg, 3, nh, hd).permute(2, 0, 3, 1, 4)      # (3, N, nh, Lg, hd)
+            q, k, v = (g[i].reshape(N * nh, Lg, hd) for i in range(3))
+            km = mask.view(N, 1, Lg).expand(N, nh, Lg).reshape(N * nh, Lg)
+            if (training and self.p_attn > 0) or Lg > 384:
+                s = torch.bmm(q, k.transpose(1, 2)).masked_fill(~km.bool().unsqueeze(1), float("-inf"))
+                p = F.dropout(torch.softmax(s, dim=-1), self.p_attn, training)
+                ctx = torch.bmm(p, v)
+            else:
+                ctx = ops.fused_attention(q, k, v, km)
+            outs.append(ctx.view(N, nh, Lg, hd).permute(0, 2, 1, 3).reshape(N * Lg, self.hidden))
+        return torch.cat(outs, 0).index_select(0, plan["token_slot"])[:T]
+
+    def forward(self, packed, training=False):
+        """All layer outputs (n_layers, T, H) fp32 for the ``PackedTokens`` stream."""
+        P = self._p
+        plan = attention_plan(packed)
+        T = packed.T
+        ids, pos = packed.ids[:T].long(), packed.pos[:T].long()
+        x = P["embeddings.word_embeddings.weight"][ids] + P["embeddings.position_embeddings.weight"][pos] \
+            + P["embeddings.token_type_embeddings.weight"][0]
+        x = F.dropout(self._ln(x, "embeddings.LayerNorm"), self.p_hidden, training)
+        scale = 1.0 / float(np.sqrt(self.hidden // self.n_heads))
+        layers = []
+        for l in range(self.n_layers):
+            pre = "encoder.layer.%d." % l
+            a = pre + "attention.self."
+            w_qkv = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0)
+            b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0)
+            ctx = self._attention(ops.linear(x, w_qkv, b_qkv), plan, training)
+            o = ops.linear(ctx, P[pre + "attention.output.dense.weight"], P[pre + "attention.output.dense.bias"])
+            x = self._ln(F.dropout(o, self.p_hidden, training) + x, pre + "attention.output.LayerNorm")
+            h = F.gelu(ops.linear(x, P[pre + "intermediate.dense.weight"], P[pre + "intermediate.dense.bias"]))
+            o = ops.linear(h, P[pre + "output.dense.weight"], P[pre + "output.dense.bias"])
+            x = self._ln(F.dropout(o, self.p_hidden, training) + x, pre + "output.LayerNorm")
+            layers.append(x)
+        return torch.stack(layers, 0)
+
+
+def attention_plan(packed):
+    """Device index vectors for the padded-per-group attention, cached on the batch: for every group the (N, Lg) matrix of packed
+    token indices (0 where padded) with its key mask, and for every packed token its slot in the concatenation of the groups'
+    padded outputs."""
+    plan = getattr(packed, "_train_plan", None)
+    if plan is not None:
+        return plan
+    if packed.bias_host is not None:
+        raise NotImplementedError("the trainable encoder expects the packed stream (no padded slots)")
+    dev = packed.ids.device
+    groups, slot, base = [], np.zeros(packed.T, dtype=np.int64), 0
+    for gidx in packed.group_index:
+        real = gidx >= 0
+        cols = np.nonzero(real.any(0))[0]
+        Lg = int(cols.max()) + 1 if len(cols) else 1       # the reference's column positions, cut after the last real one
+        g, m = gidx[:, :Lg], real[:, :Lg]
+        n_idx, j_idx = np.nonzero(m)
+        slot[g[m]] = base + n_idx * Lg + j_idx
+        groups.append((torch.from_numpy(np.where(m, g, 0).astype(np.int64)).to(dev), torch.from_numpy(m.astype(np.uint8)).to(dev)))
+        base += g.shape[0] * Lg
+    plan = {"groups": groups, "token_slot": torch.from_numpy(slot).to(dev)}
+    packed._train_plan = plan
+    return plan
+
+
+def pool_mix(layer_w, layers, span_start, span_len, dst_row, n_rows):
+    """Differentiable form of ``ruart_bert_pool_mix`` (Bert.py:149-165 + SDNet.py:573-581): mix the layers, then average every
+    word's piece span.  Gradients reach both the layer weights and the encoder."""
+    mixed = torch.einsum("l,lth->th", layer_w.to(layers.dtype), layers)
+    W = span_start.numel()
+    out = mixed.new_zeros(n_rows, mixed.size(1))
+    if W == 0:
+        return out
+    ln = span_len.long()
+    word_of_piece = torch.repeat_interleave(torch.arange(W, device=ln.device), ln)
+    first = torch.cumsum(ln, 0) - ln
+    piece = span_start.long()[word_of_piece] + (torch.arange(word_of_piece.numel(), device=ln.device) - first[word_of_piece])
+    rows = mixed.index_select(0, piece) / ln[word_of_piece].unsqueeze(1).to(mixed.dtype)
+    return out.index_add(0, dst_row.long()[word_of_piece], rows)

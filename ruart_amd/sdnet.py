@@ -25,6 +25,7 @@ from . import layers as L
 from . import ops
 from .batch import BatchIndex
 from .bert import Bert, _PoolMix, bert_encode
+from .bert_train import pool_mix as bert_train_pool_mix
 from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RNN_from_opt, dropout, row_dropout
 
 # The forward runs its question / object / OCR branches on three streams and several modules (deep attention, the high-level
@@ -80,6 +81,7 @@ class _Trunk(nn.Module):
             if hasattr(net, name):
                 setattr(self, name, getattr(net, name))
         self._net_streams = net._side_streams       # eager mode shares the SDNet's two side streams (few HW queues)
+        self._net_use_streams = net._use_streams
         self._bank = L.MaskBank()
 
     def _side_streams(self, dev):
@@ -102,7 +104,7 @@ class _Trunk(nn.Module):
             # are small (B=64 rows), so they run on three HIP streams and overlap on the 256 CUs; autograd replays each backward
             # on its forward's stream, so the backward overlaps the same way.
             main = torch.cuda.current_stream(dev)
-            use_streams = bool(opt.get("ruart_streams", True))
+            use_streams = self._net_use_streams()
             s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
             _fork(main, (s_q, s_od), [q_input, q_raw, q_mask, x_od, od_mask])
 
@@ -194,8 +196,10 @@ class SDNet(nn.Module):
 
         if "BERT" in opt:
             self.Bert = Bert(opt, device=opt.get("device", "cuda"))
-            if "LOCK_BERT" not in opt:
-                raise NotImplementedError("fine-tuning BERT (no LOCK_BERT) is a later scope row (SURVEY.md section 8f)")
+            if "LOCK_BERT" in opt:
+                self.Bert.lock()
+            else:
+                self.Bert.unlock()           # trainable fp32 encoder, parameters named as in the reference (bert_train.py)
             bert_dim, bert_layers = (1024, 24) if "BERT_LARGE" in opt else (768, 12)
             if "BERT_LINEAR_COMBINE" not in opt:
                 raise NotImplementedError("the hot path is BERT_LINEAR_COMBINE (all layers mixed)")
@@ -277,6 +281,13 @@ class SDNet(nn.Module):
         nxt, self._next_batch = getattr(self, "_next_batch", None), None
         if nxt is not None:
             self.Bert.prefetch(self.prepare(*nxt).packed)
+
+    def _use_streams(self):
+        """Question / object / OCR branches on three streams - with a frozen encoder.  With a trainable one the encoder's
+        backward (some 200 parameters accumulating on yet another stream) joined the three-stream graph and, on this ROCm
+        stack, steps stopped completing after a few iterations at B = 64 (single-stream: stable); the overlap is worth 1 ms of a
+        300 ms step there, so that mode runs on one stream."""
+        return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or self.Bert.bert_model is None)
 
     def _layer_weights(self):
         """softmax(alpha)_l * gamma - the scalar each BERT layer is mixed with (SDNet.py:574-576)."""
@@ -379,11 +390,13 @@ class SDNet(nn.Module):
         # Three independent groups on three streams (their backward runs there too): question on s_q, objects on s_od, OCR
         # tokens - the heaviest - on the main stream.  The item groups need the question's raw word vectors for pre-align.
         main = torch.cuda.current_stream(dev)
-        use_streams = bool(opt.get("ruart_streams", True))
+        use_streams = self._use_streams()
         s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
 
         def pooled(g):
             s_, l_, dst, rows = bi.spans[g]
+            if self.Bert.bert_model is not None:
+                return bert_train_pool_mix(lw, layers, s_, l_, dst, rows)
             return _PoolMix.apply(lw, layers, s_, l_, dst, rows, self.Bert.weights.dtype)
 
         def front(items, idx, mix):

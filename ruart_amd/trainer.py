@@ -163,7 +163,8 @@ class SDNetTrainer(BaseTrainer):
         concurrently with this step's SDNet trunk; the whole step itself runs on a high-priority stream so the trunk's small
         kernels are dispatched ahead of the encoder's big GEMM workgroups."""
         dev = self.device
-        if dev.type == "cuda":
+        unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
+        if dev.type == "cuda" and not unlocked:          # (a trainable encoder: nothing runs ahead, plain stream)
             if getattr(self, "_step_stream", None) is None:
                 self._step_stream = torch.cuda.Stream(device=dev, priority=-1)
             self._step_stream.wait_stream(torch.cuda.current_stream(dev))

@@ -226,3 +226,36 @@ def test_sdnet_end_to_end_with_phoc(golden_dir):
         assert abs(got - ref_norm) <= 2e-4 * max(ref_norm, 1e-3), (name, got, ref_norm)
     ref = z["grad:multi2one.rnns.0.weight_ih_l0[:8]"]
     close(P["multi2one.rnns.0.weight_ih_l0"].grad[:8], ref, 1e-6 + 2e-4 * float(np.abs(ref).max()), 0, "multi2one grad rows")
+
+
+def test_sdnet_end_to_end_unlocked_bert(golden_dir):
+    """No LOCK_BERT (Models/SDNet.py:88-94): the restated encoder is differentiated too; every BERT parameter's gradient norm
+    (197 tensors + the two never-reached pooler ones) and a few slices against the reference's backward."""
+    z = np.load(os.path.join(golden_dir, "sdnet_e2e_unlocked.npz"))
+    opt = default_opt(vocab_size=int(z["vocab_size"]))
+    cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bw = {k: T(v).requires_grad_(True) for k, v in synth.make_bert_weights(cfg, seed=int(z["seed"])).items()}
+    sw = synth.make_sdnet_weights(opt, seed=int(z["seed"]))
+    P = {k: T(v).requires_grad_(v.shape != (1, 1, 1)) for k, v in sw.items()}
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=12, n_ocr=16, n_od=6, bert_vocab=2000,
+                                              ragged=True)
+    assert ocr["num_cnt"] == z["ocr_num_cnt"].tolist()
+    scores = O.sdnet_forward(P, opt, bw, cfg, q, ocr, od)
+    close(scores, z["scores"], 2e-5, 1e-4, "scores")
+    loss = O.instance_bce_with_logits(scores, gt)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    n_bert = 0
+    for name, ref_norm in zip(z["grad_names"].tolist(), z["grad_norms"].tolist()):
+        g = bw["bert." + name[len("Bert.bert_model."):]].grad if name.startswith("Bert.") else P[name].grad
+        if ref_norm < 0:
+            assert g is None or float(g.norm()) == 0.0, name
+            continue
+        n_bert += name.startswith("Bert.")
+        got = float(g.double().norm())
+        assert abs(got - ref_norm) <= 3e-4 * max(ref_norm, 1e-3), (name, got, ref_norm)
+        if "grad:" + name in z.files:
+            ref = z["grad:" + name]
+            sl = tuple(slice(0, n) for n in ref.shape)
+            close(g[sl], ref, 1e-7 + 3e-4 * float(np.abs(ref).max()), 0, "grad " + name)
+    assert n_bert == 197
