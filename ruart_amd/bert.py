@@ -379,7 +379,7 @@ class Bert(nn.Module):
         """Encode ``packed`` asynchronously into the buffer set the current step does NOT use; ``layers_for`` returns the
         result.  ``after_stream``: the stream whose already enqueued work (the previous consumers of that set) must finish
         first.  Call it after ``layers_for`` of the current batch."""
-        if getattr(packed, "_layers", None) is not None or self.bert_model is not None:
+        if getattr(packed, "_layers", None) is not None or getattr(self, "bert_model", None) is not None:
             return                           # (a trainable encoder changes every step: nothing to run ahead)
         dev = self._device
         if self._pf_stream is None or self._pf_stream.device != dev:
@@ -405,7 +405,7 @@ class Bert(nn.Module):
 
     def layers_for(self, packed):
         """All-layer encoder output of ``packed``: the prefetched one (the current stream waits for it) or computed now."""
-        if self.bert_model is not None:
+        if getattr(self, "bert_model", None) is not None:
             return self.bert_model(packed, training=self.training)
         layers = getattr(packed, "_layers", None)
         if layers is not None:
@@ -424,7 +424,7 @@ class Bert(nn.Module):
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
     def encode(self, groups):
         packed = PackedTokens(groups, self._device, pack=self.pack, mfma_long=self.weights.dtype != hip.DT_F32)
-        if self.bert_model is not None:
+        if getattr(self, "bert_model", None) is not None:
             return packed, self.bert_model(packed, training=self.training)
         return packed, bert_encode(self.weights, packed)
 
@@ -434,7 +434,7 @@ class Bert(nn.Module):
         dev = self._device
         desc = torch.from_numpy(np.concatenate([s, n, d])).to(dev)
         W = len(s)
-        if self.bert_model is not None:
+        if getattr(self, "bert_model", None) is not None:
             from .bert_train import pool_mix
             out = pool_mix(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows)
         else:

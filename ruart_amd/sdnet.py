@@ -287,7 +287,7 @@ class SDNet(nn.Module):
         backward (some 200 parameters accumulating on yet another stream) joined the three-stream graph and, on this ROCm
         stack, steps stopped completing after a few iterations at B = 64 (single-stream: stable); the overlap is worth 1 ms of a
         300 ms step there, so that mode runs on one stream."""
-        return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or self.Bert.bert_model is None)
+        return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or getattr(self.Bert, "bert_model", None) is None)
 
     def _layer_weights(self):
         """softmax(alpha)_l * gamma - the scalar each BERT layer is mixed with (SDNet.py:574-576)."""
@@ -395,7 +395,7 @@ class SDNet(nn.Module):
 
         def pooled(g):
             s_, l_, dst, rows = bi.spans[g]
-            if self.Bert.bert_model is not None:
+            if getattr(self.Bert, "bert_model", None) is not None:
                 return bert_train_pool_mix(lw, layers, s_, l_, dst, rows)
             return _PoolMix.apply(lw, layers, s_, l_, dst, rows, self.Bert.weights.dtype)
 
