@@ -140,6 +140,15 @@ int ruart_attn_fwd(const float* pa, const float* pk, const float* v, const unsig
 int ruart_attn_bwd(const float* pa, const float* pk, const float* v, const float* probs, const float* grad_out, const float* diag,
                    int diag_len, int relu, float* grad_pa, float* grad_pk, float* grad_v, float* grad_diag_partial,
                    float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3, void* stream);
+/* The same pair with a multiplier on the probabilities, for attention-probability dropout (Models/Bert/modeling.py:244-246):
+ * out = (P * prob_scale) . v with prob_scale (B, L1, L2) fp32 holding 0 or 1/(1-p) (NULL: plain call); the saved `probs` are the
+ * pre-dropout P, which is what the softmax backward needs; the backward takes the same prob_scale. */
+int ruart_attn_fwd_pscale(const float* pa, const float* pk, const float* v, const unsigned char* mask, const float* diag, int diag_len,
+                          int relu, const float* prob_scale, float* out, float* probs, int B, int L1, int L2, int h, int D3,
+                          void* stream);
+int ruart_attn_bwd_pscale(const float* pa, const float* pk, const float* v, const float* probs, const float* grad_out, const float* diag,
+                          int diag_len, int relu, const float* prob_scale, float* grad_pa, float* grad_pk, float* grad_v,
+                          float* grad_diag_partial, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream);
 
 /* Layers.py:167-168: F.layer_norm over the WHOLE tensor of n elements, no affine.  stats[0] = mean, stats[1] = rstd.
  * ws: 2 * 1024 floats of scratch. */

@@ -7,9 +7,9 @@ reference's own names (``Bert.bert_model.embeddings.word_embeddings.weight``, ``
 
   projections   ops.linear  -> ``ruart_gemm_x3`` (fp32 operands, three bf16 MFMA products) for x.W^T, dY.W and dY^T.X
   attention     per group of sequences, padded to the group's longest REAL length: ops.fused_attention -> ``ruart_attn_fwd/bwd``
-                (the reference's -10000 key bias and a hard mask agree to the last bit in fp32: exp(-10000 + s - max) == 0);
-                plain torch (bmm, softmax, dropout) when attention-probability dropout is active or a sequence exceeds the
-                kernel's 384-key panel
+                (the reference's -10000 key bias and a hard mask agree to the last bit in fp32: exp(-10000 + s - max) == 0),
+                attention-probability dropout as a multiplier inside the kernel (``ruart_attn_fwd_pscale``);
+                plain torch (bmm, softmax, dropout) only when a sequence exceeds the kernel's 384-key panel
   LayerNorm / GELU / embeddings / dropout   torch (row-wise, HBM-bound; TF-style LN == F.layer_norm with eps 1e-12)
 
 Dropout follows the reference: ``hidden_dropout_prob`` after the embeddings and after both output projections,
@@ -75,12 +75,16 @@ class BertModelTrainable(nn.Module):
             g = qkv.index_select(0, idx.reshape(-1)).view(N, Lg, 3, nh, hd).permute(2, 0, 3, 1, 4)      # (3, N, nh, Lg, hd)
             q, k, v = (g[i].reshape(N * nh, Lg, hd) for i in range(3))
             km = mask.view(N, 1, Lg).expand(N, nh, Lg).reshape(N * nh, Lg)
-            if (training and self.p_attn > 0) or Lg > 384:
+            drop = training and self.p_attn > 0
+            if Lg > 384:                                   # beyond the fused kernel's key panel
                 s = torch.bmm(q, k.transpose(1, 2)).masked_fill(~km.bool().unsqueeze(1), float("-inf"))
                 p = F.dropout(torch.softmax(s, dim=-1), self.p_attn, training)
                 ctx = torch.bmm(p, v)
             else:
-                ctx = ops.fused_attention(q, k, v, km)
+                ps = None
+                if drop:
+                    ps = (torch.rand(N * nh, Lg, Lg, device=q.device) >= self.p_attn).to(q.dtype).mul_(1.0 / (1.0 - self.p_attn))
+                ctx = ops.fused_attention(q, k, v, km, prob_scale=ps)
             outs.append(ctx.view(N, nh, Lg, hd).permute(0, 2, 1, 3).reshape(N * Lg, self.hidden))
         return torch.cat(outs, 0).index_select(0, plan["token_slot"])[:T]
 
@@ -90,7 +94,7 @@ class BertModelTrainable(nn.Module):
         plan = attention_plan(packed)
         T = packed.T
         ids, pos = packed.ids[:T].long(), packed.pos[:T].long()
-        x = P["embeddings.word_embeddings.weight"][ids] + P["embeddings.position_embeddings.weight"][pos] \
+        x = F.embedding(ids, P["embeddings.word_embeddings.weight"]) + F.embedding(pos, P["embeddings.position_embeddings.weight"]) \
             + P["embeddings.token_type_embeddings.weight"][0]
         x = F.dropout(self._ln(x, "embeddings.LayerNorm"), self.p_hidden, training)
         scale = 1.0 / float(np.sqrt(self.hidden // self.n_heads))

@@ -70,7 +70,8 @@ __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const flo
   }
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
-__device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols) {
+__device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols,
+                                          const float* mul = nullptr) {
   float v[4];                                  // 16 * CH = 1024 elements, 256 threads: all four loads in flight together
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -78,6 +79,7 @@ __device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src,
     const int c = e & 15, r = e >> 4;          // c: 16 source columns (fast), r: 64 source rows
     const int gr = r0 + r, gc = c0 + c;
     v[u] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
+    if (mul && gr < rows && gc < cols) v[u] *= mul[(size_t)gr * ld + gc];
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ probs, int L1, int L2, int h,
                                                        int D3, int* __restrict__ nan_flag, int relu, const float* __restrict__ diag,
-                                                       int diag_len) {
+                                                       int diag_len, const float* __restrict__ pscale) {
   const int b = blockIdx.y, i0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     bool bad = false;
     for (int j = c; j < L2p; j += 16) {
       const float p = (j < L2) ? Sr[j] * inv : 0.f;
-      Sr[j] = live ? p : 0.f;
+      // probability dropout (BERT, modeling.py:244-246): the context uses p * pscale, the saved probabilities stay pre-dropout
+      const float ps = (pscale && live && j < L2) ? pscale[((size_t)b * L1 + i0 + row) * L2 + j] : 1.f;
+      Sr[j] = live ? p * ps : 0.f;
       bad |= live && !(p == p);
       if (probs && live && j < L2) probs[((size_t)b * L1 + i0 + row) * L2 + j] = p;
     }
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
                                                          float* __restrict__ grad_a, float* __restrict__ dS, int L1, int L2, int h,
                                                          int D3, const float* __restrict__ pa, int relu,
                                                          const float* __restrict__ diag, int diag_len,
-                                                         float* __restrict__ grad_diag) {
+                                                         float* __restrict__ grad_diag, const float* __restrict__ pscale) {
   const int b = blockIdx.y, i0 = blockIdx.x * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
@@ -229,6 +233,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     const float* Pr = probs + ((size_t)b * L1 + (live ? i0 + row : 0)) * L2;
     float* Sr = S_s + row * ldS;
     float dot = 0.f;
+    if (pscale && live) {                  // d/dP of (P * pscale) . v
+      const float* Mr = pscale + ((size_t)b * L1 + i0 + row) * L2;
+      for (int j = c; j < L2; j += 16) Sr[j] *= Mr[j];
+    }
     for (int j = c; j < L2; j += 16) dot += Sr[j] * Pr[j];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
@@ -276,13 +284,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 
 // backward B: per (batch, 16 key rows): C[16 j][N] = X^T . Y with X (L1 x L2) in {dS, P}, Y (L1 x N) in {a, gO}
 __device__ __forceinline__ void tn_product(const float* X, int L1, int L2, int j0, const float* Y, int N, float* C, float* xt_s,
-                                           float* y_s, Act yact, const float* out_gate) {
+                                           float* y_s, Act yact, const float* out_gate, const float* xmul = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int n0 = 0; n0 < N; n0 += CH) {
     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < L1; r0 += CH) {
       __syncthreads();
-      stage_t16(xt_s, LDA_, X, L2, r0, L1, j0, L2);     // xt_s[j][i]
+      stage_t16(xt_s, LDA_, X, L2, r0, L1, j0, L2, xmul);     // xt_s[j][i]
       stage(y_s, LDB_, CH, Y, N, r0, L1, n0, N, yact);   // y_s[i][n]
       __syncthreads();
       const int kc = min(CH, (L1 - r0 + 3) & ~3);
@@ -304,14 +312,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
                                                           const float* __restrict__ dS, const float* __restrict__ gout,
                                                           float* __restrict__ grad_k, float* __restrict__ grad_v, int L1, int L2, int h,
                                                           int D3, const float* __restrict__ pk, int relu,
-                                                          const float* __restrict__ diag, int diag_len) {
+                                                          const float* __restrict__ diag, int diag_len,
+                                                          const float* __restrict__ pscale) {
   const int b = blockIdx.y, j0 = blockIdx.x * 16;
   float* xt_s = dsm;                   // [16][LDA_]
   float* y_s = xt_s + 16 * LDA_;       // [CH][LDB_]
   const size_t pb = (size_t)b * L1 * L2;
   tn_product(dS + pb, L1, L2, j0, a + (size_t)b * L1 * h, h, grad_k + (size_t)b * L2 * h, xt_s, y_s, Act{relu, diag, diag_len},
              (relu && pk) ? pk + (size_t)b * L2 * h : nullptr);
-  tn_product(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s, no_act(), nullptr);
+  tn_product(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s, no_act(), nullptr,
+             pscale ? pscale + pb : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,9 +526,15 @@ __global__ __launch_bounds__(256) void attn1_bwd_kernel(const float* __restrict_
 
 extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
                               int diag_len, int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream) {
+  return ruart_attn_fwd_pscale(a, k, v, mask, diag, diag_len, relu, nullptr, out, probs, B, L1, L2, h, D3, stream);
+}
+
+extern "C" int ruart_attn_fwd_pscale(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
+                                     int diag_len, int relu, const float* prob_scale, float* out, float* probs, int B, int L1, int L2,
+                                     int h, int D3, void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
-  if (L1 == 1 && !relu && diag_len == 0) {              // single-query fast path
+  if (L1 == 1 && !relu && diag_len == 0 && !prob_scale) {              // single-query fast path
     hipLaunchKernelGGL(attn1_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, k, v, mask, out, probs, L2, h, D3,
                        ruart_nan_flag_ptr);
     RUART_CHECK_LAUNCH();
@@ -527,7 +543,7 @@ extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, co
   const dim3 grid(ceil_div(L1, 16), B), block(256);
   attn_allow_big_lds();
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
-                     ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len);
+                     ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len, prob_scale);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -535,9 +551,17 @@ extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, co
 extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
                               const float* diag, int diag_len, int relu, float* grad_a, float* grad_k, float* grad_v,
                               float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream) {
+  return ruart_attn_bwd_pscale(a, k, v, probs, grad_out, diag, diag_len, relu, nullptr, grad_a, grad_k, grad_v, grad_diag, ds_ws, B, L1,
+                               L2, h, D3, stream);
+}
+
+extern "C" int ruart_attn_bwd_pscale(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
+                                     const float* diag, int diag_len, int relu, const float* prob_scale, float* grad_a, float* grad_k,
+                                     float* grad_v, float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3,
+                                     void* stream) {
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
-  if (L1 == 1 && !relu && diag_len == 0) {              // single-query fast path (ds_ws unused)
+  if (L1 == 1 && !relu && diag_len == 0 && !prob_scale) {              // single-query fast path (ds_ws unused)
     hipLaunchKernelGGL(attn1_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, k, v, probs, grad_out, grad_a, grad_k, grad_v,
                        L2, h, D3);
     RUART_CHECK_LAUNCH();
@@ -548,11 +572,11 @@ extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, co
   attn_allow_big_lds();
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
                      grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,
-                     (diag_len > 1) ? grad_diag : nullptr);
+                     (diag_len > 1) ? grad_diag : nullptr, prob_scale);
   RUART_CHECK_LAUNCH();
   const size_t lds = sizeof(float) * (16 * LDA_ + CH * LDB_);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
-                     grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len);
+                     grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len, prob_scale);
   RUART_CHECK_LAUNCH();
   return 0;
 }

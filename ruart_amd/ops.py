@@ -51,7 +51,7 @@ class _FusedAttention(torch.autograd.Function):
     """out = softmax_j(mask(a . k^T)) . v with a = act(pa) * diag, k = act(pk)   (Models/Layers.py:228-231, 244, 275-288)."""
 
     @staticmethod
-    def forward(ctx, pa, pk, v, mask, diag, relu):
+    def forward(ctx, pa, pk, v, mask, diag, relu, pscale=None):
         lib = hip.load()
         for t in (pa, pk, v):
             hip.require_gpu(t, torch.float32)
@@ -61,17 +61,17 @@ class _FusedAttention(torch.autograd.Function):
         dl = 0 if diag is None else diag.numel()
         out = torch.empty(B, L1, D3, dtype=torch.float32, device=pa.device)
         probs = torch.empty(B, L1, L2, dtype=torch.float32, device=pa.device)
-        rc = lib.ruart_attn_fwd(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(mask), hip.ptr(diag), dl, int(relu), hip.ptr(out),
-                                hip.ptr(probs), B, L1, L2, h, D3, hip.stream_ptr())
+        rc = lib.ruart_attn_fwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(mask), hip.ptr(diag), dl, int(relu),
+                                       hip.ptr(pscale), hip.ptr(out), hip.ptr(probs), B, L1, L2, h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_fwd")
-        ctx.save_for_backward(pa, pk, v, probs, diag)
+        ctx.save_for_backward(pa, pk, v, probs, diag, pscale)
         ctx.relu = int(relu)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = hip.load()
-        pa, pk, v, probs, diag = ctx.saved_tensors
+        pa, pk, v, probs, diag, pscale = ctx.saved_tensors
         B, L1, h = pa.shape
         L2, D3 = pk.shape[1], v.shape[2]
         dl = 0 if diag is None else diag.numel()
@@ -80,19 +80,21 @@ class _FusedAttention(torch.autograd.Function):
         ds = torch.empty_like(probs)
         gdiag = (torch.empty(B * ((L1 + 15) // 16), h, dtype=torch.float32, device=pa.device)
                  if (dl > 1 and ctx.needs_input_grad[4]) else None)
-        rc = lib.ruart_attn_bwd(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
-                                hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2, h, D3,
-                                hip.stream_ptr())
+        rc = lib.ruart_attn_bwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
+                                       hip.ptr(pscale), hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2,
+                                       h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_bwd")
-        return ga, gk, gv, None, (gdiag.sum(0).view_as(diag) if gdiag is not None else None), None
+        return ga, gk, gv, None, (gdiag.sum(0).view_as(diag) if gdiag is not None else None), None, None
 
 
-def fused_attention(a, k, v, mask, diag=None, relu=False):
+def fused_attention(a, k, v, mask, diag=None, relu=False, prob_scale=None):
     """a (B,L1,h), k (B,L2,h), v (B,L2,D3) fp32; mask (B,L2) uint8/bool (0 = masked key).  With ``relu`` / ``diag`` the
-    activation of the reference's AttentionScore is applied inside the kernel: a <- ReLU(a) * diag, k <- ReLU(k)."""
+    activation of the reference's AttentionScore is applied inside the kernel: a <- ReLU(a) * diag, k <- ReLU(k).
+    ``prob_scale`` (B,L1,L2) fp32 of 0 / 1/(1-p): dropout on the attention probabilities (BERT)."""
     m = mask.to(torch.uint8).contiguous()
     d = None if diag is None else diag.contiguous().view(-1)
-    return _FusedAttention.apply(a.contiguous(), k.contiguous(), v.contiguous(), m, d, relu)
+    ps = None if prob_scale is None else prob_scale.contiguous()
+    return _FusedAttention.apply(a.contiguous(), k.contiguous(), v.contiguous(), m, d, relu, ps)
 
 
 # ---------------------------------------------------------------------------------------------------------

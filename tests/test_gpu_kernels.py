@@ -292,6 +292,41 @@ def test_fused_attention_shapes(B, L1, L2, h, D3):
         assert maxerr(got, want) < 5e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,L1,L2,h,D3,relu", [(5, 9, 9, 64, 64, False), (2, 50, 50, 64, 64, False), (3, 1, 12, 64, 64, False),
+                                               (2, 37, 21, 30, 17, True), (2, 20, 300, 16, 40, False)])
+def test_fused_attention_probability_dropout(B, L1, L2, h, D3, relu):
+    """ruart_attn_fwd/bwd_pscale: out = (softmax(mask(a.k^T)) * prob_scale) . v with the multiplier of BERT's attention-probability
+    dropout (modeling.py:244-246); output and all three gradients against torch autograd on the CPU."""
+    from ruart_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 100 + L1 + L2)
+    a, k, v = torch.randn(B, L1, h, generator=g), torch.randn(B, L2, h, generator=g), torch.randn(B, L2, D3, generator=g)
+    mask = torch.ones(B, L2, dtype=torch.uint8)
+    for b in range(B):
+        mask[b, int(torch.randint(1, L2 + 1, (1,), generator=g)):] = 0
+    ps = (torch.rand(B, L1, L2, generator=g) >= 0.3).float() / 0.7
+    diag = torch.rand(h, generator=g) + 0.5 if relu else None
+    ac, kc, vc = [t.clone().requires_grad_() for t in (a, k, v)]
+    aa, kk = (torch.relu(ac) * diag, torch.relu(kc)) if relu else (ac, kc)
+    s = torch.bmm(aa, kk.transpose(1, 2)).masked_fill(mask.eq(0).unsqueeze(1), float("-inf"))
+    ref = torch.bmm(torch.softmax(s, 2) * ps, vc)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    ad, kd, vd = [t.to(d).requires_grad_() for t in (a, k, v)]
+    y = ops.fused_attention(ad, kd, vd, mask.to(d), diag=None if diag is None else diag.to(d), relu=relu, prob_scale=ps.to(d))
+    y.backward(gy.to(d))
+    assert maxerr(y, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    for got, want in ((ad.grad, ac.grad), (kd.grad, kc.grad), (vd.grad, vc.grad)):
+        assert maxerr(got, want) < 5e-5 * max(1.0, float(want.abs().max()))
+    # no multiplier == the plain entry point, bit for bit (L1 == 1 without a multiplier takes the single-query kernel instead)
+    if L1 == 1:
+        return
+    y0 = ops.fused_attention(ad.detach(), kd.detach(), vd.detach(), mask.to(d), diag=None if diag is None else diag.to(d), relu=relu)
+    y1 = ops.fused_attention(ad.detach(), kd.detach(), vd.detach(), mask.to(d), diag=None if diag is None else diag.to(d), relu=relu,
+                             prob_scale=torch.ones(B, L1, L2, device=d))
+    assert torch.equal(y0, y1)
+
+
 def test_whole_layer_norm(layers_golden):
     from ruart_amd import ops
     z = layers_golden
