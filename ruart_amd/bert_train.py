@@ -139,10 +139,14 @@ def attention_plan(packed):
     return plan
 
 
-def pool_mix(layer_w, layers, span_start, span_len, dst_row, n_rows):
-    """Differentiable form of ``ruart_bert_pool_mix`` (Bert.py:149-165 + SDNet.py:573-581): mix the layers, then average every
-    word's piece span.  Gradients reach both the layer weights and the encoder."""
-    mixed = torch.einsum("l,lth->th", layer_w.to(layers.dtype), layers)
+def mix_layers(layer_w, layers):
+    """sum_l layer_w[l] * layers[l]  (SDNet.py:573-581) - as a broadcast multiply and a reduction over the layer axis: the library
+    GEMM an einsum lowers this to (M = 1, K = n_layers, N = T * H) took 6 ms per call at B = 64."""
+    return (layers * layer_w.to(layers.dtype).view(-1, 1, 1)).sum(0)
+
+
+def pool_words(mixed, span_start, span_len, dst_row, n_rows):
+    """Average every word's piece span of the mixed stream (Bert.py:149-165); rows without a word stay zero."""
     W = span_start.numel()
     out = mixed.new_zeros(n_rows, mixed.size(1))
     if W == 0:
@@ -153,3 +157,9 @@ def pool_mix(layer_w, layers, span_start, span_len, dst_row, n_rows):
     piece = span_start.long()[word_of_piece] + (torch.arange(word_of_piece.numel(), device=ln.device) - first[word_of_piece])
     rows = mixed.index_select(0, piece) / ln[word_of_piece].unsqueeze(1).to(mixed.dtype)
     return out.index_add(0, dst_row.long()[word_of_piece], rows)
+
+
+def pool_mix(layer_w, layers, span_start, span_len, dst_row, n_rows):
+    """Differentiable form of ``ruart_bert_pool_mix``: mix the layers, then average every word's piece span.  Gradients reach
+    both the layer weights and the encoder."""
+    return pool_words(mix_layers(layer_w, layers), span_start, span_len, dst_row, n_rows)

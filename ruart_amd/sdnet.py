@@ -25,7 +25,7 @@ from . import layers as L
 from . import ops
 from .batch import BatchIndex
 from .bert import Bert, _PoolMix, bert_encode
-from .bert_train import pool_mix as bert_train_pool_mix
+from . import bert_train
 from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RNN_from_opt, dropout, row_dropout
 
 # The forward runs its question / object / OCR branches on three streams and several modules (deep attention, the high-level
@@ -393,10 +393,13 @@ class SDNet(nn.Module):
         use_streams = self._use_streams()
         s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
 
+        trainable = getattr(self.Bert, "bert_model", None) is not None
+        mixed = bert_train.mix_layers(lw, layers) if trainable else None     # once for the three groups
+
         def pooled(g):
             s_, l_, dst, rows = bi.spans[g]
-            if getattr(self.Bert, "bert_model", None) is not None:
-                return bert_train_pool_mix(lw, layers, s_, l_, dst, rows)
+            if trainable:
+                return bert_train.pool_words(mixed, s_, l_, dst, rows)
             return _PoolMix.apply(lw, layers, s_, l_, dst, rows, self.Bert.weights.dtype)
 
         def front(items, idx, mix):
@@ -405,7 +408,7 @@ class SDNet(nn.Module):
                 words = torch.cat([words, self._prealign(raw, idx, q_raw, q_mask)], -1)
             return self._multi2one_last(words, idx)                             # (B, max_num, 300)
 
-        _fork(main, (s_q, s_od), [lw, layers, q_mask])
+        _fork(main, (s_q, s_od), [lw, layers, q_mask] + ([mixed] if trainable else []))
         with torch.cuda.stream(s_q):
             q_input, q_raw = self._embed_question(q_list, pooled(0).view(Bq, Q, H))
             ev_q = s_q.record_event() if use_streams else None
