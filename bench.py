@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="rehearsal on one GPU: a world-size-1 RCCL process group, so the gradient hooks, the bucketed all-reduce and "
+                         "the barriers of the N > 1 path all run")
     ap.add_argument("--unlock-bert", action="store_true",
                     help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
     ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
@@ -67,14 +70,14 @@ def note(msg):
         print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
-def build_trainer(opt, cfg, device, seed=1033):
+def build_trainer(opt, cfg, device, seed=1033, process_group=None):
     from ruart_amd import synth
     from ruart_amd.trainer import SDNetTrainer
     opt = dict(opt)
     opt["bert_state"] = synth.make_bert_weights(cfg, seed=seed, w_std=0.02)
     opt["bert_config"] = cfg
     sw = synth.make_sdnet_weights(opt, seed=seed)
-    tr = SDNetTrainer(opt, device=device)
+    tr = SDNetTrainer(opt, device=device, process_group=process_group)
     tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
     missing, unexpected = tr.network.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
     assert not unexpected and all(k.startswith("Bert.bert_model.") for k in missing), (missing, unexpected)
@@ -181,9 +184,17 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or a.force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if a.force_dp and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # the gradient all-reduce sits on the step's critical path (the optimizer waits for it) while the next batch's encoder
+        # GEMMs fill the device from a normal-priority stream: give RCCL's stream the priority of the step's own streams
+        pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("RUART_RCCL_PRIORITY", "1") != "0")
+        dist.init_process_group("nccl", device_id=device, pg_options=pg_opts)
 
     from ruart_amd import hip, synth
     from ruart_amd.arguments import default_opt
@@ -198,7 +209,8 @@ def main():
         a.no_roofline = True                     # the 16-bit encoder GEMM is not on this path
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
     note("building model")
-    tr, _ = build_trainer(opt, cfg, device)
+    tr, _ = build_trainer(opt, cfg, device, process_group=dist.group.WORLD if a.force_dp else None)
+    dp = world > 1 or a.force_dp
     note("model ready; staging %d batches" % a.n_batches)
 
     # pre-stage synthetic batches (different data per rank), index vectors included
@@ -225,7 +237,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
 
     for i in range(a.warmup):
@@ -238,7 +250,7 @@ def main():
         step(i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -304,7 +316,7 @@ def main():
             note("cpu baseline (oracle) ...")
             out["cpu_baseline"] = cpu_baseline(opt, cfg, a.cpu_samples)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,13 +14,27 @@ asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
   * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
     win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order and each
     bucket's all-reduce is launched asynchronously as soon as its last gradient is produced (strictly in bucket order,
-    so all ranks issue identical collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales by 1/world and scatters back;
+    so all ranks issue identical collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales each bucket by 1/world in one launch and points every parameter's ``.grad`` at its slice of the bucket (no copy back);
   * works unchanged on the gloo backend (CPU tensors) - that is how the N>1 path is tested without GPUs.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 UNUSED_PREFIXES = ("get_answer.rnn.", "Bert.bert_model.pooler.")     # never reached by a gradient
+
+
+def init_process_group(device, backend="nccl", **kw):
+    """``dist.init_process_group`` for one rank per GPU with RCCL's stream at HIGH priority.  The bucketed all-reduce is on the
+    step's critical path (the optimizer waits for it) while the next batch's frozen-encoder GEMMs - 256 workgroups that own every
+    CU's registers - arrive on a normal-priority stream; on a normal-priority stream RCCL's kernels queue behind them: measured on
+    one MI355X with a world-size-1 group, 23-24 ms per step against 20.2 with the priority raised (19.9 without DP)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        kw.setdefault("pg_options", dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
+        kw.setdefault("device_id", torch.device(device))
+    return dist.init_process_group(backend, **kw)
 
 
 class GradSync:
@@ -101,13 +115,17 @@ class GradSync:
         for bi in range(len(self.buckets)):
             self._work[bi].wait()
             flat = self._flat[bi]
+            if self.world > 1:
+                flat.mul_(inv)                         # one launch per bucket
             o = 0
             for v, (_, p, rows) in zip(self._views(bi), self.buckets[bi]):
                 n = v.numel()
-                v.copy_(flat[o:o + n].view_as(v) * inv)
-                o += n
-                if rows is not None:
+                if rows is None:
+                    p.grad = flat[o:o + n].view_as(p)      # the averaged gradient IS the bucket slice: no copy back
+                else:
+                    v.copy_(flat[o:o + n].view_as(v))
                     p.grad[rows:].zero_()
+                o += n
             self._flat[bi] = None
         self._reset()
 
