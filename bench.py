@@ -232,6 +232,9 @@ def main():
         else:
             tr.network.eval()
             tr.network.drop_emb = False
+            if not a.no_prefetch:                 # same pipeline as training: the next batch's encoder pass beside this trunk
+                nb = batches[(i + 1) % len(batches)]
+                tr.network.prefetch_bert(nb[0], nb[1], nb[2])
             with torch.no_grad():
                 tr.network(b[0], b[1], b[2])
 

@@ -208,12 +208,15 @@ class SDNetTrainer(BaseTrainer):
         return loss_val
 
     # -- inference --------------------------------------------------------------------------------------------
-    def predict(self, batch, all_ans=False):
-        """Models/SDNetTrainer.py:378-451: arg-max over VALID answer slots, ANLS / ACC when answers are known."""
+    def predict(self, batch, all_ans=False, next_batch=None):
+        """Models/SDNetTrainer.py:378-451: arg-max over VALID answer slots, ANLS / ACC when answers are known.
+        ``next_batch`` (already through ToCUDA): its frozen-encoder pass is started beside this batch's trunk, as in ``update``."""
         from .metrics import note_stvqa, note_textvqa
         self.network.eval()
         self.network.drop_emb = False
         q_list, ocr_list, od_list, gt_list, extra_info = batch
+        if next_batch is not None:
+            self.network.prefetch_bert(next_batch[0], next_batch[1], next_batch[2])
         with torch.no_grad():
             scores, _ = self.network(q_list, ocr_list, od_list)
             loss = self.loss_func(scores, gt_list).item() if gt_list is not None else 0
@@ -262,9 +265,14 @@ class SDNetTrainer(BaseTrainer):
             else val_data
         loss = ANLS = ACC = n = nb = 0
         res, save_res = [], []
-        for batch in loader:
-            batch = self.ToCUDA(batch)
-            l, a, c, r, sr = self.predict(batch)
+        it = iter(loader)
+        nxt = next(it, None)
+        nxt = self.ToCUDA(nxt) if nxt is not None else None
+        while nxt is not None:
+            batch = nxt
+            nxt = next(it, None)
+            nxt = self.ToCUDA(nxt) if nxt is not None else None       # lookahead: the next batch's encoder pass runs beside this trunk
+            l, a, c, r, sr = self.predict(batch, next_batch=nxt)
             loss, ANLS, ACC, n, nb = loss + l, ANLS + a, ACC + c, n + len(r), nb + 1
             res.extend(r)
             save_res.extend(sr)
