@@ -283,10 +283,9 @@ class SDNet(nn.Module):
             self.Bert.prefetch(self.prepare(*nxt).packed)
 
     def _use_streams(self):
-        """Question / object / OCR branches on three streams - with a frozen encoder.  With a trainable one the encoder's
-        backward (some 200 parameters accumulating on yet another stream) joined the three-stream graph and, on this ROCm
-        stack, steps stopped completing after a few iterations at B = 64 (single-stream: stable); the overlap is worth 1 ms of a
-        300 ms step there, so that mode runs on one stream."""
+        """Question / object / OCR branches on three streams - with a frozen encoder.  The trainable encoder's step is 10x longer
+        and gains nothing measurable from the overlap; its first version (library GEMMs of extreme shape running on the three
+        streams at once) also stopped completing steps at B = 64 - DESIGN.md section 5 - so that mode stays on one stream."""
         return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or getattr(self.Bert, "bert_model", None) is None)
 
     def _layer_weights(self):
