@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
+    ap.add_argument("--stress", action="store_true",
+                    help="secondary: BASELINE's stress shapes - 300 OCR items, 100 objects, bert-large 24 x 1024 (use with --precision bf16)")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on one GPU: a world-size-1 RCCL process group, so the gradient hooks, the bucketed all-reduce and "
                          "the barriers of the N > 1 path all run")
@@ -208,6 +210,12 @@ def main():
         opt.pop("LOCK_BERT")
         a.no_roofline = True                     # the 16-bit encoder GEMM is not on this path
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
+    n_ocr, n_od = 100, 36
+    if a.stress:
+        opt.update(BERT_LARGE=True, BERT_large_model_file="unused", max_ocr_num=300, max_od_num=100)
+        cfg = synth.bert_config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+        n_ocr, n_od = 300, 100
+        a.no_roofline = a.no_cpu_baseline = True
     note("building model")
     tr, _ = build_trainer(opt, cfg, device, process_group=dist.group.WORLD if a.force_dp else None)
     dp = world > 1 or a.force_dp
@@ -216,7 +224,7 @@ def main():
     # pre-stage synthetic batches (different data per rank), index vectors included
     batches = []
     for i in range(a.n_batches):
-        b = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=100, n_od=36)
+        b = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=n_ocr, n_od=n_od)
         batches.append(tr.ToCUDA(b))
     bi = batches[0][0]["_ruart_index"]
     real_tokens = bi.packed.T
@@ -302,16 +310,17 @@ def main():
                     "gemm_share_of_step": round(ms_i / a.steps / (dt / a.steps * 1e3), 3)}
 
     if rank == 0:
-        out = {"metric": "VQA samples/sec fwd+bwd (B=64, q=30, ocr=100)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=100)",
+        out = {"metric": ("VQA samples/sec fwd+bwd (B=64, q=30, ocr=%d)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=%d)") % n_ocr,
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "f32 storage, split-bf16 MFMA" if a.unlock_bert and a.precision != "fp32" else
                         {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA"}[a.precision],
                "data": "synthetic",
-               "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, 100 OCR items, "
-                                      "36 objects, bert-base 12x768 %s, SDNet trunk fwd+bwd, Adamax"
-                                      % (a.batch, "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
+               "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, %d OCR items, "
+                                      "%d objects, %s %s, SDNet trunk fwd+bwd, Adamax"
+                                      % (a.batch, n_ocr, n_od, "bert-large 24x1024" if a.stress else "bert-base 12x768",
+                                         "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
                           "parallelism": "dp%d" % world, "mode": a.mode},
                "roofline": roof}
