@@ -248,6 +248,11 @@ class SDNetTrainer(BaseTrainer):
                 ANLS += a if a >= 0.5 else 0
         return loss, ANLS, ACC, res, save_res
 
+    def _is_main(self):
+        """Rank 0 (or no process group): the only rank that creates the run folder and writes checkpoints / predictions."""
+        d = torch.distributed
+        return not (d.is_available() and d.is_initialized()) or d.get_rank(self.process_group) == 0
+
     def _loader(self, data, sampler, workers=0):
         from torch.utils.data import DataLoader
         collate = VQA_collate(self.opt, prepare_index=workers > 0).VQA_collate_fun
@@ -278,7 +283,7 @@ class SDNetTrainer(BaseTrainer):
             save_res.extend(sr)
         n_items = len(val_data) if is_dataset else n
         loss, ANLS, ACC = loss / max(nb, 1), ANLS / max(n_items, 1), ACC / max(n_items, 1)
-        if not is_dataset:
+        if not is_dataset or not self._is_main():
             return loss, ANLS, ACC, res
         if mode == "test":
             end = len(val_data) % self.batch_size
@@ -322,8 +327,9 @@ class SDNetTrainer(BaseTrainer):
         batch_st = 0
         if train_loader is None:
             from .dataset import VQA_Dataset
-            self.getSaveFolder()
-            self.saveConf()
+            if self._is_main():
+                self.getSaveFolder()
+                self.saveConf()
             self._setup_from_meta()
             if "RESUME" in self.opt:
                 self.load_model(os.path.join(self.opt["datadir"], self.opt["MODEL_PATH"]))
