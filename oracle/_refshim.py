@@ -9,6 +9,7 @@ What is shimmed (all ordinary missing-module / no-device conditions, SURVEY.md Â
   * ``spacy`` / ``fasttext`` are not installed: stub modules; only ``len(POS)`` and
     ``len(ENT)`` reach the model (Models/SDNet.py:123,128), so the stub exposes
     50 tagger labels and 74 entity moves  => table sizes 51 / 75.
+  * ``h5py`` (Models/SDNetTrainer.py:19, image-feature loading only) is not installed: empty stub module.
   * ``.cuda()`` is hard-coded in forward (Models/SDNet.py:281-299 ...): patched to
     identity so the reference runs as a PyTorch-CPU program.
 """
@@ -44,6 +45,8 @@ def install():
         ft = types.ModuleType("fasttext")
         ft.load_model = lambda *a, **k: None
         sys.modules["fasttext"] = ft
+    if "h5py" not in sys.modules:                 # imported at the top of Models/SDNetTrainer.py:19, used only for image features
+        sys.modules["h5py"] = types.ModuleType("h5py")
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     if REF not in sys.path:

@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -17,6 +17,7 @@ Reference entry points exercised (file:line in /root/reference):
     Models/Layers.py:124-180,182-295,320-341,352-468,471-534
     Models/SDNet.py:253-437           SDNet.forward
     Models/SDNetTrainer.py:510-518    instance_bce_with_logits
+    Models/SDNetTrainer.py:378-451    SDNetTrainer.predict (answer decode + ANLS / ACC), predict_decode.json
     Utils/phoc.py:8-12 (+ cphoc.so)   build_phoc, phoc.npz
     Utils/VQA_Dataset.py:13-437       VQA_Dataset (+ Models/Bert/tokenization.py BertTokenizer), dataset_*.json[.gz] fixtures
 """
@@ -591,8 +592,69 @@ def gen_phoc():
          ones=rows.sum(1).astype(np.int32))
 
 
+def predict_cases(seed=3):
+    """Score matrices for the answer decode: random ones plus the orders that matter - sentinel on top, a padding slot on top,
+    the no-answer slot on top / second, a sample whose only item is the sentinel, exact answers, ten-answer (TextVQA style) lists."""
+    g = np.random.default_rng(seed)
+    n_slots = 13                                   # max_ocr_num 12 + no-answer
+    words = ["stop", "exit", "coca cola", "north", "bus", "2nd", "cafe", "park", "shop", "street", "sign"]
+    cases = []
+    for i in range(24):
+        n = [1, 2, 5, 12, 7, 3][i % 6]             # items incl. the trailing <ocr> sentinel
+        ocr = [words[int(k)] for k in g.integers(0, len(words), size=n - 1)] + ["<ocr>"]
+        p = g.random(n_slots).astype(np.float32)
+        mode = i % 8
+        if mode == 1:
+            p[n - 1] = 2.0                          # sentinel first
+        elif mode == 2 and n < 12:
+            p[n] = 2.0                              # padding slot first
+        elif mode == 3:
+            p[-1] = 2.0                             # no-answer first
+        elif mode == 4:
+            p[n - 1], p[-1] = 3.0, 2.0              # sentinel, then no-answer
+        elif mode == 5 and n < 11:
+            p[n], p[n + 1] = 3.0, 2.5               # two padding slots first
+        answers = [None, [ocr[0]], ["Stop", "stopp"], [w for w in (ocr * 10)[:10]], ["zzz"]][i % 5]
+        cases.append({"prob": p.tolist(), "num_cnt": n, "ocr_list": ocr, "answers": answers, "q_id": 500 + i})
+    return cases, n_slots
+
+
+def gen_predict():
+    """Models/SDNetTrainer.py:378-451 with the network replaced by a function that returns prepared scores: the reference's own
+    decode loop, ANLS / ACC accumulation and result records, with and without the no-answer slot."""
+    import json
+    import types
+    import Models.SDNetTrainer as M
+    cases, n_slots = predict_cases()
+    out = {"cases": cases, "n_slots": n_slots, "expected": {}}
+    for name, no_answer in (("no_answer", True), ("plain", False)):
+        width = n_slots if no_answer else n_slots - 1
+        scores = torch.tensor([c["prob"][:width] for c in cases])
+        opt = {"label_no_answer": True} if no_answer else {}
+
+        class Net:
+            drop_emb = False
+
+            def eval(self):
+                pass
+
+            def __call__(self, q, ocr, od):
+                return scores, None
+
+        fake = types.SimpleNamespace(network=Net(), opt=opt, fixed_answers_len=0, fixed_answers_entry=None,
+                                     loss_func=lambda s, g: torch.zeros(()))
+        batch = (None, {"num_cnt": [c["num_cnt"] for c in cases]}, None, torch.zeros(len(cases), width),
+                 [{"q_id": c["q_id"], "answers": c["answers"], "ocr_list": c["ocr_list"], "image_path": "x"} for c in cases])
+        loss, anls, acc, res, save_res = M.SDNetTrainer.predict(fake, batch)
+        out["expected"][name] = {"ANLS": float(anls), "ACC": float(acc), "res": res, "save_res": save_res}
+        print(name, "ANLS %.4f ACC %.4f" % (anls, acc), [r["idx"] for r in save_res])
+    with open(os.path.join(OUT, "predict_decode.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote predict_decode.json", os.path.getsize(os.path.join(OUT, "predict_decode.json")) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc", "predict"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
@@ -609,3 +671,5 @@ if __name__ == "__main__":
         gen_dataset()
     if "phoc" in which:
         gen_phoc()
+    if "predict" in which:
+        gen_predict()

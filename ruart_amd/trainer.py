@@ -45,6 +45,41 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
+def decode_predictions(scores, num_cnt, extra_info, opt):
+    """The answer decode of Models/SDNetTrainer.py:391-450 for scores (B, n_slots) on any device: per sample the reference walks
+    the slots by descending score, skips the ``<OCR>`` sentinel and the padding slots (>= num_cnt), stops at the first real OCR
+    token - or at the no-answer slot (last column, ``label_no_answer``) if that comes first.  A descending walk that stops at the
+    first admissible slot is a masked arg-max, done here in one device op for the batch.  When nothing is admissible the
+    reference's loop runs out and is left with the LOWEST-scored slot; that case is reproduced too.
+    Returns (ANLS sum, ACC sum, res, save_res) as the reference's ``predict`` does after the loss."""
+    from .metrics import note_stvqa, note_textvqa
+    if "label_yesno" in opt or "fixed_answers" in opt:
+        raise NotImplementedError("yes/no and fixed-answer slots are outside the accelerated path (SURVEY section 8)")
+    B, n_slots = scores.shape
+    no_answer = "label_no_answer" in opt
+    cnt = torch.as_tensor(list(num_cnt), device=scores.device)
+    sentinel = torch.as_tensor([len(e["ocr_list"]) - 1 for e in extra_info], device=scores.device)
+    ar = torch.arange(n_slots, device=scores.device).unsqueeze(0)
+    valid = (ar < cnt.unsqueeze(1)) & (ar != sentinel.unsqueeze(1))
+    if no_answer:
+        valid[:, -1] = True
+    best = scores.masked_fill(~valid, -1.0).argmax(dim=1)
+    idxs = torch.where(valid.any(dim=1), best, scores.argmin(dim=1)).cpu().tolist()
+    prob = scores.detach().cpu()
+    res, save_res, ANLS, ACC = [], [], 0, 0
+    for i, idx in enumerate(idxs):
+        answer = extra_info[i]["ocr_list"][idx] if idx < int(num_cnt[i]) else "unanswerable"
+        res.append({"question_id": extra_info[i]["q_id"], "answer": answer})
+        save_res.append({"question_id": extra_info[i]["q_id"], "prediction": answer, "answers": extra_info[i]["answers"],
+                         "score": prob[i, idx].item(), "idx": idx, "ids_len": n_slots, "ocr_list": extra_info[i]["ocr_list"]})
+        if extra_info[i]["answers"] is not None:
+            a = note_stvqa(extra_info[i]["answers"], answer)
+            c = note_textvqa(extra_info[i]["answers"], answer)
+            ACC += min(c * 10 / 3.0, 1) if len(extra_info[i]["answers"]) == 10 else min(c * 10, 1)
+            ANLS += a if a >= 0.5 else 0
+    return ANLS, ACC, res, save_res
+
+
 class BaseTrainer:
     """Models/BaseTrainer.py:6-69: option plumbing, the feature folder, the run folder."""
 
@@ -211,7 +246,6 @@ class SDNetTrainer(BaseTrainer):
     def predict(self, batch, all_ans=False, next_batch=None):
         """Models/SDNetTrainer.py:378-451: arg-max over VALID answer slots, ANLS / ACC when answers are known.
         ``next_batch`` (already through ToCUDA): its frozen-encoder pass is started beside this batch's trunk, as in ``update``."""
-        from .metrics import note_stvqa, note_textvqa
         self.network.eval()
         self.network.drop_emb = False
         q_list, ocr_list, od_list, gt_list, extra_info = batch
@@ -221,31 +255,7 @@ class SDNetTrainer(BaseTrainer):
             scores, _ = self.network(q_list, ocr_list, od_list)
             loss = self.loss_func(scores, gt_list).item() if gt_list is not None else 0
         self.network.check_nan()
-        B, n_slots = scores.shape
-        # valid slot k for sample i: k < num_cnt[i] and k != len(ocr_list_i) - 1 (the <OCR> sentinel); the no-answer slot
-        # (last column) always terminates the scan.  Descending-score scan == masked arg-max.
-        num_cnt = torch.as_tensor(ocr_list["num_cnt"], device=scores.device)
-        sentinel = torch.as_tensor([len(e["ocr_list"]) - 1 for e in extra_info], device=scores.device)
-        ar = torch.arange(n_slots, device=scores.device).unsqueeze(0)
-        valid = (ar < num_cnt.unsqueeze(1)) & (ar != sentinel.unsqueeze(1))
-        if "label_no_answer" in self.opt:
-            valid[:, -1] = True
-        idxs = scores.masked_fill(~valid, -1.0).argmax(dim=1).cpu().tolist()
-        prob = scores.detach().cpu()
-        res, save_res, ANLS, ACC = [], [], 0, 0
-        for i, idx in enumerate(idxs):
-            if "label_no_answer" in self.opt and idx == n_slots - 1:
-                answer = "unanswerable"
-            else:
-                answer = extra_info[i]["ocr_list"][idx]
-            res.append({"question_id": extra_info[i]["q_id"], "answer": answer})
-            save_res.append({"question_id": extra_info[i]["q_id"], "prediction": answer, "answers": extra_info[i]["answers"],
-                             "score": prob[i, idx].item(), "idx": idx, "ids_len": n_slots, "ocr_list": extra_info[i]["ocr_list"]})
-            if extra_info[i]["answers"] is not None:
-                a = note_stvqa(extra_info[i]["answers"], answer)
-                c = note_textvqa(extra_info[i]["answers"], answer)
-                ACC += min(c * 10 / 3.0, 1) if len(extra_info[i]["answers"]) == 10 else min(c * 10, 1)
-                ANLS += a if a >= 0.5 else 0
+        ANLS, ACC, res, save_res = decode_predictions(scores, ocr_list["num_cnt"], extra_info, self.opt)
         return loss, ANLS, ACC, res, save_res
 
     def _is_main(self):

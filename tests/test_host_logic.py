@@ -292,3 +292,27 @@ def test_msgpack_readers_round_trip(tmp_path):
     assert opt["char_vocab_size"] == 2 and emb["glove_embedding"].tolist() == meta["glove_embedding"]
     assert set(emb) == {"glove_embedding", "fast_embedding"}
     assert load_msgpack(str(tmp_path / "dev-preprocessed.msgpack"))["data"][0]["question"] == "café?"
+
+
+@pytest.mark.parametrize("variant", ["no_answer", "plain"])
+def test_predict_decode_matches_reference(golden_dir, variant):
+    """``trainer.decode_predictions`` (masked arg-max) against the reference's own ``SDNetTrainer.predict`` decode loop
+    (Models/SDNetTrainer.py:391-450, run with a stub network that returns these scores): chosen slot, answer string, score,
+    ANLS and ACC sums - sentinel / padding / no-answer slots on top and the nothing-admissible case included."""
+    import json
+    from ruart_amd.trainer import decode_predictions
+    with open(os.path.join(golden_dir, "predict_decode.json")) as f:
+        z = json.load(f)
+    cases, want = z["cases"], z["expected"][variant]
+    width = z["n_slots"] if variant == "no_answer" else z["n_slots"] - 1
+    scores = torch.tensor([c["prob"][:width] for c in cases])
+    extra = [{"q_id": c["q_id"], "answers": c["answers"], "ocr_list": c["ocr_list"], "image_path": "x"} for c in cases]
+    opt = {"label_no_answer": True} if variant == "no_answer" else {}
+    anls, acc, res, save_res = decode_predictions(scores, [c["num_cnt"] for c in cases], extra, opt)
+    assert res == want["res"]
+    assert [r["idx"] for r in save_res] == [r["idx"] for r in want["save_res"]]
+    for got, ref in zip(save_res, want["save_res"]):
+        assert got == ref, (got, ref)
+    assert abs(anls - want["ANLS"]) < 1e-9 and abs(acc - want["ACC"]) < 1e-9
+    with pytest.raises(NotImplementedError):
+        decode_predictions(scores, [c["num_cnt"] for c in cases], extra, {"label_yesno": True})
