@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -17,6 +17,7 @@ Reference entry points exercised (file:line in /root/reference):
     Models/Layers.py:124-180,182-295,320-341,352-468,471-534
     Models/SDNet.py:253-437           SDNet.forward
     Models/SDNetTrainer.py:510-518    instance_bce_with_logits
+    Models/SDNetTrainer.py:296-376    SDNetTrainer.setup_model + update (three optimizer steps), trainer_update.npz
     Models/SDNetTrainer.py:378-451    SDNetTrainer.predict (answer decode + ANLS / ACC), predict_decode.json
     Utils/phoc.py:8-12 (+ cphoc.so)   build_phoc, phoc.npz
     Utils/VQA_Dataset.py:13-437       VQA_Dataset (+ Models/Bert/tokenization.py BertTokenizer), dataset_*.json[.gz] fixtures
@@ -653,8 +654,58 @@ def gen_predict():
     print("wrote predict_decode.json", os.path.getsize(os.path.join(OUT, "predict_decode.json")) // 1024, "KB")
 
 
+def gen_update():
+    """Three calls of the reference's own ``SDNetTrainer.update`` (Models/SDNetTrainer.py:330-376: forward, BCE_D1 loss, backward,
+    clip_grad_norm_ 10, Adamax, re-pinning of embedding rows >= tune_partial) on one small batch, dropout configured to 0
+    everywhere (conf DROPOUT / dropout_emb and BERT's own, which train() re-enables).  The trainer object is created without its
+    __init__ (that one opens the preprocessing artefacts); setup_model and update are the reference's."""
+    import Models.SDNetTrainer as M
+    opt = default_opt(vocab_size=1500, DROPOUT=0.0, dropout_emb=0.0)
+    bert_cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    seed = 1033
+    bw = synth.make_bert_weights(bert_cfg, seed=seed)
+    opt = dict(opt)
+    opt["BERT_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    opt["cuda"] = False
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    tr = M.SDNetTrainer.__new__(M.SDNetTrainer)
+    tr.opt, tr.use_cuda, tr.fixed_answers_len, tr.fixed_answers_entry = opt, False, 0, None
+    M.set_dropout_prob(0.0)
+    tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]).clone(), "fast_embedding": T(sw["fast_embed.weight"]).clone()})
+    missing, unexpected = tr.network.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing)
+    # On a GPU `network.cuda()` gives the parameters new storage while `fixed_embedding_fast/glove` (plain attributes, views of the
+    # CPU tables, Models/SDNet.py:78-81) keep the initial values - that is what makes the re-pinning of :369-373 work.  Under the
+    # harness's `.cuda()` -> identity shim they would alias the live weights and the re-pinning would be a no-op: un-alias them.
+    for k in ("fixed_embedding_fast", "fixed_embedding_glove"):
+        setattr(tr.network, k, getattr(tr.network, k).clone())
+    before = {n: p.detach().clone() for n, p in tr.network.named_parameters() if not n.startswith("Bert.")}
+    batch = synth.synthetic_batch(opt, 3, seed=29, n_q=12, n_ocr=20, n_od=6, bert_vocab=2000, ragged=True)
+    losses = [tr.update(batch, i) for i in range(3)]
+    print("losses", losses)
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(29), B=np.array(3), vocab_size=np.array(1500), losses=np.array(losses),
+                  lr=np.array(float(opt["lr"])))
+    names, dnorm, pnorm = [], [], []
+    for n, p in tr.network.named_parameters():
+        if n.startswith("Bert."):
+            continue
+        names.append(n)
+        dnorm.append(float((p.detach() - before[n]).double().norm()))
+        pnorm.append(float(p.detach().double().norm()))
+    arrays["names"], arrays["delta_norms"], arrays["param_norms"] = np.array(names), np.array(dnorm), np.array(pnorm)
+    prm = dict(tr.network.named_parameters())
+    for k in ("alphaBERT", "gammaBERT", "ques_merger.linear.weight", "get_answer.noanswer_w.weight"):
+        arrays["after:" + k] = prm[k].detach().numpy().copy()
+    arrays["after:fast_embed.weight[:40,:16]"] = prm["fast_embed.weight"].detach()[:40, :16].numpy().copy()
+    arrays["after:fast_embed.weight[1000:1004,:16]"] = prm["fast_embed.weight"].detach()[1000:1004, :16].numpy().copy()
+    for k in ("fast_embed.weight", "glove_embed.weight"):          # how far every row of the word tables moved
+        arrays["rowdelta:" + k] = (prm[k].detach() - before[k]).double().norm(dim=1).numpy().astype(np.float32)
+    save("trainer_update", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc", "predict"]
+    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc", "predict", "update"]
     if "layers" in which:
         gen_layers()
     if "bert" in which:
@@ -673,3 +724,5 @@ if __name__ == "__main__":
         gen_phoc()
     if "predict" in which:
         gen_predict()
+    if "update" in which:
+        gen_update()

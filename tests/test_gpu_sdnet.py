@@ -528,3 +528,59 @@ def test_unlocked_bert_trains_with_the_fused_optimizer():
     path = "/tmp/ruart_ckpt_unlocked.pt"
     tr.save_for_predict(path)
     assert not any(k.startswith("Bert") for k in torch.load(path, map_location="cpu")["state_dict"]["network"])
+
+
+@pytest.mark.parametrize("precision,tol_l,tol_d", [("fp32", 2e-4, 5e-3), ("fp16", 2e-2, 8e-2)])
+def test_three_optimizer_steps_vs_reference_update(golden_dir, precision, tol_l, tol_d):
+    """``SDNetTrainer.update`` end to end against three calls of the reference's own update() (Models/SDNetTrainer.py:330-376) on
+    the same batch: forward, BCE_D1, backward, global-norm clip 10, Adamax, re-pinning of the embedding rows >= tune_partial -
+    here through the fused clip + Adamax kernels.  Compared: the three losses, how far every tensor moved (norm of the update),
+    and the values of small tensors.  (Adamax's first step is lr * sign(g): entries whose gradient is rounding noise may go
+    either way, so element-wise checks allow 2 lr.)"""
+    from ruart_amd.trainer import SDNetTrainer
+    z = np.load(os.path.join(golden_dir, "trainer_update.npz"))
+    opt = default_opt(vocab_size=int(z["vocab_size"]), cuda=True, DROPOUT=0.0, dropout_emb=0.0, bert_precision=precision)
+    cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=int(z["seed"])), cfg
+    sw = synth.make_sdnet_weights(opt, seed=int(z["seed"]))
+    tr = SDNetTrainer(opt, device="cuda:0")
+    tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    tr.network.load_state_dict({k: T(v) for k, v in sw.items()})
+    before = {n: p.detach().clone() for n, p in tr.network.named_parameters()}
+    batch = tr.ToCUDA(synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=12, n_ocr=20, n_od=6, bert_vocab=2000,
+                                            ragged=True))
+    losses = [tr.update(batch, i) for i in range(3)]
+    assert np.abs(np.array(losses) - z["losses"]).max() < tol_l * 70, (losses, z["losses"].tolist())
+    prm = dict(tr.network.named_parameters())
+    lr = float(z["lr"])
+    worst = (0.0, "")
+    for name, dref in zip(z["names"].tolist(), z["delta_norms"].tolist()):
+        d = float((prm[name].detach() - before[name]).double().norm())
+        if dref < 1e-12:
+            assert d < 1e-12, name                          # never-updated tensors (dead GRU, fixed scalars) stay put
+            continue
+        if name == "ques_merger.linear.bias":
+            # a constant added to every score of a softmax: its true gradient is zero; the reference's is rounding noise
+            # (~1e-9) that Adamax turns into a random walk, the fused kernel does not materialise it - no output depends on it
+            assert d == 0.0
+            continue
+        worst = max(worst, (abs(d - dref) / dref, name))
+    assert worst[0] < tol_d, worst
+    for k in ("fast_embed.weight", "glove_embed.weight"):          # which rows of the word tables moved, and how far
+        ref = z["rowdelta:" + k]
+        got = (prm[k].detach() - before[k]).double().norm(dim=1).cpu().numpy()
+        assert np.array_equal(got > 0, ref > 0), k             # same rows (none >= tune_partial; the question's padding row 0 too)
+        assert np.abs(got - ref).max() < (2e-4 if precision == "fp32" else 4e-3), (k, float(np.abs(got - ref).max()))
+    for k in z.files:
+        if not k.startswith("after:"):
+            continue
+        name = k[6:].split("[")[0]
+        got = prm[name].detach().cpu().numpy()
+        if "[:40,:16]" in k:
+            got = got[:40, :16]
+        elif "[1000:1004,:16]" in k:
+            got = got[1000:1004, :16]                       # rows >= tune_partial: re-pinned to their initial values
+            assert np.array_equal(got, sw["fast_embed.weight"][1000:1004, :16])
+        frac_off = float((np.abs(got - z[k]) > 2.05 * lr).mean())
+        assert frac_off <= (0.0 if precision == "fp32" else 0.02), (k, frac_off, float(np.abs(got - z[k]).max()))
+    print("update parity %s: losses %s, worst update-norm rel err %.2e (%s)" % (precision, losses, worst[0], worst[1]))
