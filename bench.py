@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the encoder inline instead of one step ahead")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="secondary: every timed step starts from the collated HOST batch (ids, masks, positions and the host-built "
+                         "batch index, as a DataLoader worker with VQA_collate(prepare_index=True) hands it over) and ships it itself")
     ap.add_argument("--stress", action="store_true",
                     help="secondary: BASELINE's stress shapes - 300 OCR items, 100 objects, bert-large 24 x 1024 (use with --precision bf16)")
     ap.add_argument("--force-dp", action="store_true",
@@ -226,22 +229,47 @@ def main():
     for i in range(a.n_batches):
         b = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=n_ocr, n_od=n_od)
         batches.append(tr.ToCUDA(b))
+    host_batches = None
+    if a.include_h2d:                            # what a loader worker produces: tensors on the host + the numpy batch index
+        from ruart_amd.batch import BatchIndex
+        host_batches = []
+        for i in range(max(a.n_batches, 3)):     # three objects in rotation: current, lookahead, and the one just retired
+            hb = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=n_ocr, n_od=n_od)
+            hb[0]["_ruart_host_index"] = BatchIndex(hb[0], hb[1], hb[2], opt)
+            if not os.environ.get("RUART_BENCH_PAGEABLE"):       # what DataLoader(pin_memory=True) does on its pinning thread
+                from torch.utils.data._utils.pin_memory import pin_memory as _pin
+                hb = _pin(hb)
+            host_batches.append(hb)
     bi = batches[0][0]["_ruart_index"]
     real_tokens = bi.packed.T
     torch.cuda.synchronize()
     note("batches staged: %d real word pieces per batch" % real_tokens)
 
+    def fresh(i):
+        """The batch of step i: pre-staged on the device (default) or shipped from its host copy now (--include-h2d)."""
+        if host_batches is None:
+            return batches[i % len(batches)]
+        hb = host_batches[i % len(host_batches)]
+        hb[0].pop("_ruart_index", None)          # forget the previous round's device copy: ToCUDA ships everything again
+        hb[0]["_ruart_host_index"].device = None
+        return tr.ToCUDA(hb)
+
+    staged = {}
+
     def step(i):
-        b = batches[i % len(batches)]
+        b = staged.pop(i, None) or fresh(i)
+        if host_batches is not None and not a.no_prefetch:
+            staged[i + 1] = fresh(i + 1)           # the lookahead batch has to be on the device for its encoder pass
         if a.mode == "train":
             # steady-state pipeline: the frozen encoder pass of the NEXT batch overlaps this step's trunk; every timed step
             # still launches exactly one encoder pass and one full trunk forward/backward/optimizer step
-            tr.update(b, i, next_batch=None if a.no_prefetch else batches[(i + 1) % len(batches)])
+            nb = None if a.no_prefetch else (staged[i + 1] if host_batches is not None else batches[(i + 1) % len(batches)])
+            tr.update(b, i, next_batch=nb)
         else:
             tr.network.eval()
             tr.network.drop_emb = False
             if not a.no_prefetch:                 # same pipeline as training: the next batch's encoder pass beside this trunk
-                nb = batches[(i + 1) % len(batches)]
+                nb = staged[i + 1] if host_batches is not None else batches[(i + 1) % len(batches)]
                 tr.network.prefetch_bert(nb[0], nb[1], nb[2])
             with torch.no_grad():
                 tr.network(b[0], b[1], b[2])

@@ -221,23 +221,46 @@ class BatchIndex:
         if device is not None:
             self.to(device)
 
+    # -- host staging: the five flat buffers ``to`` ships, as torch tensors (so a DataLoader can pin them) -----------------------
+    def _staged(self):
+        h = self.__dict__.get("_h")
+        if h is None:
+            items = self.ocr.pack_host() + self.od.pack_host()
+            h = {"item_sizes": [len(a) for a in items],
+                 "items": torch.from_numpy(np.concatenate(items)) if sum(len(a) for a in items) else torch.zeros(0, dtype=torch.long),
+                 "ocr_mask": torch.from_numpy(self.ocr.mask), "od_mask": torch.from_numpy(self.od.mask)}
+            if self._emb_host:
+                h["emb"] = torch.from_numpy(np.concatenate([np.concatenate(self._emb_host[k]) for k in self._emb_host]).astype(np.int32))
+            if self.packed is not None:
+                h["packed"] = torch.from_numpy(self.packed.host)
+                h["spans"] = torch.from_numpy(self._spans_host[0])
+            self._h = h
+        return h
+
+    def pin_memory(self):
+        """Called by ``DataLoader(pin_memory=True)`` on its pinning thread: page-locks the staged buffers so that ``to`` is five
+        asynchronous copies instead of five blocking ones."""
+        h = self._staged()
+        for k, v in h.items():
+            if isinstance(v, torch.Tensor):
+                h[k] = v.pin_memory()
+        return self
+
     def to(self, device):
         if self.device is not None and self.device == torch.device(device):
             return self
         self.device = torch.device(device)
-        host = self.ocr.pack_host() + self.od.pack_host()
-        sizes = [len(a) for a in host]
-        buf = torch.from_numpy(np.concatenate(host)).to(self.device, non_blocking=True) if sum(sizes) else torch.zeros(0, dtype=torch.long, device=self.device)
-        parts = list(torch.split(buf, sizes))
+        h = self._staged()
+        buf = h["items"].to(self.device, non_blocking=True)
+        parts = list(torch.split(buf, h["item_sizes"]))
         n = len(ItemIndex._FIELDS)
         self.ocr.bind(parts[:n])
         self.od.bind(parts[n:])
-        self.ocr_mask = torch.from_numpy(self.ocr.mask).to(self.device, non_blocking=True)
-        self.od_mask = torch.from_numpy(self.od.mask).to(self.device, non_blocking=True)
+        self.ocr_mask = h["ocr_mask"].to(self.device, non_blocking=True)
+        self.od_mask = h["od_mask"].to(self.device, non_blocking=True)
         if self._emb_host:
             keys = list(self._emb_host)
-            flat = np.concatenate([np.concatenate(self._emb_host[k]) for k in keys]).astype(np.int32)
-            dev = torch.from_numpy(flat).to(self.device, non_blocking=True)
+            dev = h["emb"].to(self.device, non_blocking=True)
             o = 0
             for k in keys:
                 parts = []
@@ -248,9 +271,9 @@ class BatchIndex:
             self.ocr.emb_sort = {k[1]: v for k, v in self.emb_sort.items() if k[0] == "ocr"}
             self.od.emb_sort = {k[1]: v for k, v in self.emb_sort.items() if k[0] == "od"}
         if self.packed is not None:
-            self.packed.bind(self.device)
-            cat, shapes = self._spans_host
-            dev = torch.from_numpy(cat).to(self.device, non_blocking=True)
+            self.packed.bind(self.device, h["packed"])
+            shapes = self._spans_host[1]
+            dev = h["spans"].to(self.device, non_blocking=True)
             o = 0
             self.spans = []
             for W, rows in shapes:

@@ -167,10 +167,11 @@ class PackedTokens:
         self.__dict__.update(state)
         self.buf = None
 
-    def bind(self, device):
-        """One H2D copy of the int32 descriptor buffer; builds the C struct the encoder entry point takes."""
+    def bind(self, device, host_tensor=None):
+        """One H2D copy of the int32 descriptor buffer (``host_tensor``: the same buffer as a - possibly pinned - torch tensor);
+        builds the C struct the encoder entry point takes."""
         T, Tp, nb, nlb = self.T, self.Tp, self.n_blocks, self.n_long_blocks
-        dev = torch.from_numpy(self.host).to(device, non_blocking=True)
+        dev = (host_tensor if host_tensor is not None else torch.from_numpy(self.host)).to(device, non_blocking=True)
         self.buf = dev
         o = 0
         self.ids = dev[o:o + Tp]; o += Tp

@@ -266,7 +266,9 @@ class SDNetTrainer(BaseTrainer):
     def _loader(self, data, sampler, workers=0):
         from torch.utils.data import DataLoader
         collate = VQA_collate(self.opt, prepare_index=workers > 0).VQA_collate_fun
-        return DataLoader(data, batch_sampler=sampler, collate_fn=collate, num_workers=workers)
+        # pinned batches (tensors and, through BatchIndex.pin_memory, the host-built index): ToCUDA becomes asynchronous copies
+        return DataLoader(data, batch_sampler=sampler, collate_fn=collate, num_workers=workers,
+                          pin_memory=self.device.type == "cuda")
 
     def evaluate(self, val_data, batch_i=0, mode="dev"):
         """Models/SDNetTrainer.py:127-176.  ``val_data`` is a ``VQA_Dataset`` (batched here in the reference's deterministic

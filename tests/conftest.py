@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's own DataLoader pinning helper calls Tensor.pin_memory(device) / is_pinned(device), which torch 2.10 deprecates
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")
