@@ -8,6 +8,8 @@ matrices and bool masks, python offset / count lists, ``position (B, max_num, 8)
 once per batch on the host and shipped in ONE host-to-device copy.  OCR / object words live in a packed
 (real words, D) matrix from then on - the padded (items, 20, 1388) tensor of the reference is never materialised.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -38,9 +40,21 @@ class VQA_collate:
 
     @staticmethod
     def _pad_rows(rows, width):
-        out = np.zeros((len(rows), width), dtype=np.int64)
-        for i, r in enumerate(rows):
-            out[i, :len(r)] = r
+        """Ragged python lists -> zero-padded (len(rows), width) int64 - one flat gather instead of a numpy assignment per row
+        (a batch has ~9 000 item rows per key).  A row longer than ``width`` is an error, as in the reference (:497)."""
+        n = len(rows)
+        out = np.zeros((n, width), dtype=np.int64)
+        if n == 0:
+            return torch.from_numpy(out)
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=n)
+        if lens.max() > width:
+            bad = int(np.argmax(lens > width))
+            raise ValueError("row %d holds %d ids, the padded width is %d" % (bad, int(lens[bad]), width))
+        total = int(lens.sum())
+        if total:
+            flat = np.fromiter(itertools.chain.from_iterable(rows), dtype=np.int64, count=total)
+            starts = np.cumsum(lens) - lens
+            out[np.repeat(np.arange(n), lens), np.arange(total) - np.repeat(starts, lens)] = flat
         return torch.from_numpy(out)
 
     def item_collate(self, item_list, max_len, max_bert_len, max_num):
@@ -83,12 +97,13 @@ def offsets_to_array(offsets, n_rows, width):
     """python list [rows][words][2] -> (rows, width, 2) int64, zero padded; tolerates the reference's flat
     ``[1, 1]`` for an item without words (Utils/VQA_Dataset.py:426-427)."""
     arr = np.zeros((n_rows, width, 2), dtype=np.int64)
-    for n, row in enumerate(offsets):
-        if len(row) and not isinstance(row[0], (list, tuple)):
-            continue
-        k = min(len(row), width)
-        if k:
-            arr[n, :k] = np.asarray(row[:k], dtype=np.int64)
+    rows = [() if (len(r) and not isinstance(r[0], (list, tuple))) else (r if len(r) <= width else r[:width]) for r in offsets]
+    lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))
+    total = int(lens.sum())
+    if total:
+        flat = np.fromiter(itertools.chain.from_iterable(itertools.chain.from_iterable(rows)), dtype=np.int64, count=2 * total)
+        starts = np.cumsum(lens) - lens
+        arr[np.repeat(np.arange(len(rows)), lens), np.arange(total) - np.repeat(starts, lens)] = flat.reshape(total, 2)
     return arr
 
 

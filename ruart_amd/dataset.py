@@ -77,6 +77,7 @@ class VQA_Dataset(Dataset):
             self.es_ocr_len = int(opt["ES_ocr_len"])
             self.es_sort_way = opt["ES_sort_way"]
         self.bert_tokenizer = None
+        self._bert_memo = {}
         if "BERT" in opt:
             key = "BERT_large_tokenizer_file" if "BERT_LARGE" in opt else "BERT_tokenizer_file"
             self.bert_tokenizer = BertTokenizer.from_pretrained(os.path.join(opt["datadir"], opt[key]))
@@ -200,20 +201,28 @@ class VQA_Dataset(Dataset):
 
     def bertify(self, words):
         """[CLS] + word pieces + [SEP] as ids, and for a word list the [start, end) piece span of every word
-        (VQA_Dataset.py:415-436)."""
+        (VQA_Dataset.py:415-436).  Word lists are memoised whole: scene-text items repeat across candidates and samples."""
         if self.bert_tokenizer is None:
             return None
-        bpe, offsets = ["[CLS]"], []
+        tok = self.bert_tokenizer
         if isinstance(words, list):
-            for word in words:
-                pieces = self.bert_tokenizer.tokenize(word)
-                offsets.append([len(bpe), len(bpe) + len(pieces)])
-                bpe.extend(pieces)
-            if len(words) == 0:
-                offsets = [1, 1]
-        elif isinstance(words, str):
-            bpe += self.bert_tokenizer.tokenize(words)
-        else:
-            raise AssertionError("BERT tokenizer is wrong")
-        bpe.append("[SEP]")
-        return self.bert_tokenizer.convert_tokens_to_ids(bpe), offsets
+            key = tuple(words)
+            hit = self._bert_memo.get(key)
+            if hit is None:
+                ids, offsets, n = [tok.vocab["[CLS]"]], [], 1
+                for word in words:
+                    pieces = tok.convert_tokens_to_ids(tok.tokenize(word))
+                    offsets.append([n, n + len(pieces)])
+                    ids.extend(pieces)
+                    n += len(pieces)
+                if len(words) == 0:
+                    offsets = [1, 1]
+                ids.append(tok.vocab["[SEP]"])
+                hit = (ids, offsets)
+                if len(self._bert_memo) < 1 << 20:
+                    self._bert_memo[key] = hit
+            return list(hit[0]), [list(o) if isinstance(o, list) else o for o in hit[1]]
+        if isinstance(words, str):
+            bpe = ["[CLS]"] + tok.tokenize(words) + ["[SEP]"]
+            return tok.convert_tokens_to_ids(bpe), []
+        raise AssertionError("BERT tokenizer is wrong")

@@ -128,9 +128,15 @@ class BertTokenizer:
         self.ids_to_tokens = collections.OrderedDict((i, t) for t, i in self.vocab.items())
         self.basic_tokenizer = BasicTokenizer(do_lower_case=do_lower_case)
         self.wordpiece_tokenizer = WordpieceTokenizer(vocab=self.vocab)
+        self._memo = {}                      # text -> pieces: scene-text words repeat across items and samples
 
     def tokenize(self, text):
-        return [p for w in self.basic_tokenizer.tokenize(text) for p in self.wordpiece_tokenizer.tokenize(w)]
+        hit = self._memo.get(text)
+        if hit is None:
+            hit = [p for w in self.basic_tokenizer.tokenize(text) for p in self.wordpiece_tokenizer.tokenize(w)]
+            if len(self._memo) < 1 << 20 and len(text) <= 64:
+                self._memo[text] = hit
+        return list(hit)
 
     def convert_tokens_to_ids(self, tokens):
         return [self.vocab[t] for t in tokens]           # KeyError on a token outside the vocabulary, as in the reference
