@@ -28,8 +28,11 @@ class VQA_collate:
     def VQA_collate_fun(self, batch):
         o = self.opt
         q_list = self.que_collate([t["q"] for t in batch], o["max_q_len"], o["max_q_bert_len"])
-        ocr_list = self.item_collate([t["ocr"] for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"])
-        od_list = self.item_collate([t["od"] for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"])
+        flats = [t.get("_flat") for t in batch]
+        ocr_f = [f["ocr"] for f in flats] if all(f is not None for f in flats) else None
+        od_f = [f["od"] for f in flats] if ocr_f is not None else None
+        ocr_list = self.item_collate([t["ocr"] for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"], ocr_f)
+        od_list = self.item_collate([t["od"] for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"], od_f)
         gt_list = self.gt_collate([t["gt"] for t in batch])
         if self.prepare_index:
             q_list["_ruart_host_index"] = BatchIndex(q_list, ocr_list, od_list, o)
@@ -57,25 +60,55 @@ class VQA_collate:
             out[np.repeat(np.arange(n), lens), np.arange(total) - np.repeat(starts, lens)] = flat
         return torch.from_numpy(out)
 
-    def item_collate(self, item_list, max_len, max_bert_len, max_num):
+    @staticmethod
+    def _scatter(flat, lens, width, tail=()):
+        """Values back to back + a length per row -> zero-padded (rows, width[, *tail]) array."""
+        n = len(lens)
+        out = np.zeros((n, width) + tuple(tail), dtype=flat.dtype)
+        total = int(lens.sum())
+        if total:
+            if lens.max() > width:
+                bad = int(np.argmax(lens > width))
+                raise ValueError("row %d holds %d entries, the padded width is %d" % (bad, int(lens[bad]), width))
+            starts = np.cumsum(lens) - lens
+            out[np.repeat(np.arange(n), lens), np.arange(total) - np.repeat(starts, lens)] = flat
+        return out
+
+    def item_collate(self, item_list, max_len, max_bert_len, max_num, flats=None):
+        """``flats``: the per-sample flat arrays ``VQA_Dataset`` attaches (``sample['_flat'][group]``); with them the id matrices
+        are a concatenation and one scatter per key instead of a walk over every item dict."""
         res = {}
         B = len(item_list)
         flat = [it for sample in item_list for it in sample]
+        wk = "fasttext" if "FastText" in self.opt else "glove"
+        fast = flats is not None and all(f for f in flats)
         for k in item_list[0][0].keys():
             if "offset" in k:
                 res[k] = [it[k] for it in flat]
+                if fast:
+                    vals = np.concatenate([f[k][0] for f in flats])
+                    lens = np.concatenate([f[k][1] for f in flats])
+                    res["_" + k + "_arr"] = self._scatter(vals, np.minimum(lens, max_len), max_len, tail=(2,)) if lens.max() <= max_len \
+                        else offsets_to_array(res[k], len(flat), max_len)
             elif k == "position":
                 pos = torch.zeros(B, max_num, 8)
                 for b, sample in enumerate(item_list):
-                    pos[b, :len(sample)] = torch.tensor([it[k] for it in sample], dtype=torch.float32)
+                    pos[b, :len(sample)] = torch.from_numpy(flats[b][k]) if fast else torch.tensor([it[k] for it in sample], dtype=torch.float32)
                 res[k] = pos
             else:
-                res[k] = self._pad_rows([it[k] for it in flat], max_bert_len if k in ("bert", "bert_only") else max_len)
+                width = max_bert_len if k in ("bert", "bert_only") else max_len
+                if fast:
+                    res[k] = torch.from_numpy(self._scatter(np.concatenate([f[k][0] for f in flats]),
+                                                            np.concatenate([f[k][1] for f in flats]), width))
+                else:
+                    res[k] = self._pad_rows([it[k] for it in flat], width)
         for k in [k for k in res if k in ("glove", "fasttext", "phoc", "bert", "bert_only")]:
             res[k + "_mask"] = ~res[k].eq(0)
         res["num_cnt"] = [len(sample) for sample in item_list]
-        wk = "fasttext" if "FastText" in self.opt else "glove"
-        res["len_cnt"] = [[len(it[wk]) for it in sample] for sample in item_list]
+        if fast:
+            res["len_cnt"] = [f[wk][1].tolist() for f in flats]
+        else:
+            res["len_cnt"] = [[len(it[wk]) for it in sample] for sample in item_list]
         return res
 
     def que_collate(self, q_list, max_len, max_bert_len):
@@ -204,7 +237,9 @@ class BatchIndex:
             spans = []
             for g, (items, wk) in enumerate(((q_list, wk_q), (ocr_list, wk_o), (od_list, wk_o))):
                 wm = _np(items[wk + "_mask"])
-                arr = items.get("bert_offsets_arr")
+                arr = items.get("_bert_offsets_arr")          # attached by the collate's fast path
+                if arr is None:
+                    arr = items.get("bert_offsets_arr")
                 if arr is None:
                     arr = offsets_to_array(items["bert_offsets"], wm.shape[0], wm.shape[1])
                 s, l, d, rows = word_spans(self.packed, g, None, wm, offsets_arr=arr)

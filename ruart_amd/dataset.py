@@ -12,9 +12,11 @@ pinned bit-exact against the reference's own class on a synthetic record set (``
 
 Not carried over (outside SURVEY section 8): the ``DEBUG`` length histograms, grid image features (``img_feature``) and the
 fixed-answer vocabulary (``fixed_answers``) - asking for them raises."""
+import itertools
 import logging
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -48,6 +50,29 @@ def load_meta(opt, folder=None):
     return meta["vocab"], meta["char_vocab"], emb
 
 
+def flatten_items(items):
+    """List of item dicts -> {key: (values back to back, length per item)} for the id keys, ``bert_offsets`` as an (n_words, 2)
+    array with the word count per item, ``position`` as (n_items, 8) float32."""
+    out = {}
+    n = len(items)
+    if n == 0:
+        return out
+    for k, v0 in items[0].items():
+        if k == "position":
+            out[k] = np.asarray([it[k] for it in items], dtype=np.float32).reshape(n, 8)
+        elif "offset" in k:
+            rows = [() if (len(it[k]) and not isinstance(it[k][0], (list, tuple))) else it[k] for it in items]
+            lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=n)
+            tot = int(lens.sum())
+            flat = np.fromiter(itertools.chain.from_iterable(itertools.chain.from_iterable(rows)), dtype=np.int64, count=2 * tot)
+            out[k] = (flat.reshape(tot, 2), lens)
+        else:
+            lens = np.fromiter((len(it[k]) for it in items), dtype=np.int64, count=n)
+            flat = np.fromiter(itertools.chain.from_iterable(it[k] for it in items), dtype=np.int64, count=int(lens.sum()))
+            out[k] = (flat, lens)
+    return out
+
+
 class VQA_Dataset(Dataset):
     def __init__(self, data, opt, mode="train", image_features=None, fixed_answers_entry=None):
         assert mode in ("train", "dev", "test")
@@ -78,6 +103,7 @@ class VQA_Dataset(Dataset):
             self.es_sort_way = opt["ES_sort_way"]
         self.bert_tokenizer = None
         self._bert_memo = {}
+        self._cache = {} if opt.get("ruart_cache_samples") else None   # finished samples by index (epochs revisit them)
         if "BERT" in opt:
             key = "BERT_large_tokenizer_file" if "BERT_LARGE" in opt else "BERT_tokenizer_file"
             self.bert_tokenizer = BertTokenizer.from_pretrained(os.path.join(opt["datadir"], opt[key]))
@@ -86,6 +112,8 @@ class VQA_Dataset(Dataset):
         return len(self.data)
 
     def __getitem__(self, index):
+        if self._cache is not None and index in self._cache:
+            return self._cache[index]
         datum = self.data[index]
         dedup = "remove_same" in self.opt
         ocr_items = self.get_list_from_datum(datum, self.ocr_name_list, od_ocr="ocr", remove_same=dedup)
@@ -95,12 +123,18 @@ class VQA_Dataset(Dataset):
         ocr_items = ocr_items[:self.max_ocr_num]
         od_items = od_items[:self.max_od_num]
         answers = datum.get("orign_answers")
-        return {"q": q,
-                "ocr": self.get_list_embedding(ocr_items, self.ocr_embedding),
-                "od": self.get_list_embedding(od_items, self.ocr_embedding),
-                "gt": self.get_label(ocr_items, q_id=datum["question_id"], answers=answers),
-                "extra_info": {"q_id": datum["question_id"], "answers": answers,
-                               "ocr_list": [t["original"] for t in ocr_items], "image_path": datum["filename"]}}
+        sample = {"q": q,
+                  "ocr": self.get_list_embedding(ocr_items, self.ocr_embedding),
+                  "od": self.get_list_embedding(od_items, self.ocr_embedding),
+                  "gt": self.get_label(ocr_items, q_id=datum["question_id"], answers=answers),
+                  "extra_info": {"q_id": datum["question_id"], "answers": answers,
+                                 "ocr_list": [t["original"] for t in ocr_items], "image_path": datum["filename"]}}
+        # the same content once more as flat arrays per key (ids of all items back to back + a length per item): what
+        # ``VQA_collate`` concatenates instead of walking ~9 000 item dicts per batch.  The reference-format lists above stay.
+        sample["_flat"] = {"ocr": flatten_items(sample["ocr"]), "od": flatten_items(sample["od"])}
+        if self._cache is not None:
+            self._cache[index] = sample
+        return sample
 
     # -- candidate lists (VQA_Dataset.py:293-349) ---------------------------------------------------------------
     def get_list_from_datum(self, datum, name_list, od_ocr="ocr", remove_same=False):

@@ -316,3 +316,30 @@ def test_predict_decode_matches_reference(golden_dir, variant):
     assert abs(anls - want["ANLS"]) < 1e-9 and abs(acc - want["ACC"]) < 1e-9
     with pytest.raises(NotImplementedError):
         decode_predictions(scores, [c["num_cnt"] for c in cases], extra, {"label_yesno": True})
+
+
+def test_collate_fast_path_equals_item_walk(golden_dir, tmp_path):
+    """Samples from ``VQA_Dataset`` carry flat arrays (``_flat``) that let ``VQA_collate`` concatenate instead of walking every
+    item dict; both routes must give identical batches - id matrices, masks, counts, positions, offsets (list and array form) -
+    and the batch index built from them must agree too.  Cached samples (``ruart_cache_samples``) are the same objects again."""
+    import copy
+    from ruart_amd.batch import BatchIndex
+    from ruart_amd.dataset import VQA_Dataset
+    inp, _, vocab = _dataset_fixture(golden_dir, tmp_path)
+    opt = default_opt(datadir="", BERT_tokenizer_file=vocab, ruart_cache_samples=True)
+    ds = VQA_Dataset(copy.deepcopy(inp["records"]), opt)
+    samples = [ds[i] for i in range(len(ds))]
+    assert all("_flat" in s_ for s_ in samples) and ds[1] is samples[1]
+    fast = VQA_collate(opt).VQA_collate_fun(samples)
+    slow = VQA_collate(opt).VQA_collate_fun([{k: v for k, v in s_.items() if k != "_flat"} for s_ in samples])
+    for a, b in zip(fast[:3], slow[:3]):
+        assert set(a) - {"_bert_offsets_arr"} == set(b)
+        for k, v in b.items():
+            assert torch.equal(a[k], v) if isinstance(v, torch.Tensor) else a[k] == v, k
+    assert torch.equal(fast[3], slow[3]) and fast[4] == slow[4]
+    for g in (1, 2):
+        want = offsets_to_array(slow[g]["bert_offsets"], slow[g]["fasttext"].shape[0], slow[g]["fasttext"].shape[1])
+        assert np.array_equal(fast[g]["_bert_offsets_arr"], want)
+    bf, bs = BatchIndex(fast[0], fast[1], fast[2], opt), BatchIndex(slow[0], slow[1], slow[2], opt)
+    assert np.array_equal(bf._spans_host[0], bs._spans_host[0]) and np.array_equal(bf.packed.host, bs.packed.host)
+    assert np.array_equal(bf.ocr.flat_word, bs.ocr.flat_word) and np.array_equal(bf.od.step_rows, bs.od.step_rows)

@@ -39,18 +39,36 @@ for i in range(a.batch * a.batches):
     recs.append({"question_id": i, "question": " ".join(q), "filename": "x.jpg", "orign_answers": ["stop"], "annotated_question": annotated(q),
                  "ocr_PMTD_ASTER": [item("ocr") for _ in range(88)], "ocr_PMTD_ASTER_gram2": [item("ocr") for _ in range(4)],
                  "ES_ocr": [item("ocr") for _ in range(10)], "OD_bottom-up": [item("od") for _ in range(35)]})
-opt = default_opt(datadir="", BERT_tokenizer_file=os.path.join(tmp, "vocab.txt"), max_od_num=36, vocab_size=20000)
+opt = default_opt(datadir="", BERT_tokenizer_file=os.path.join(tmp, "vocab.txt"), max_od_num=36, vocab_size=20000, ruart_cache_samples=True)
 ds = VQA_Dataset(recs, opt)
+coll = VQA_collate(opt, prepare_index=True).VQA_collate_fun
+warm = [ds[i] for i in range(a.batch)]               # first-call costs (thread pools, imports, allocator growth) stay out of the timing
+coll(warm)
+coll([{k: v for k, v in s_.items() if k != "_flat"} for s_ in warm])
+ds._cache.clear()
 t0 = time.perf_counter()
 samples = [ds[i] for i in range(len(ds))]
 t_item = (time.perf_counter() - t0) / len(ds)
-coll = VQA_collate(opt, prepare_index=True).VQA_collate_fun
 t0 = time.perf_counter()
-for b in range(a.batches):
-    out = coll(samples[b * a.batch:(b + 1) * a.batch])
-t_coll = (time.perf_counter() - t0) / a.batches
-per_batch = t_item * a.batch + t_coll
+again = [ds[i] for i in range(len(ds))]               # a later epoch: finished samples come from the per-index cache
+t_cached = (time.perf_counter() - t0) / len(ds)
+def timed(fast):
+    best = 1e9
+    for _ in range(3):                                # best of three: the first pass after a change of path pays allocator growth
+        t0 = time.perf_counter()
+        for b in range(a.batches):
+            bt = samples[b * a.batch:(b + 1) * a.batch]
+            coll(bt if fast else [{k: v for k, v in s_.items() if k != "_flat"} for s_ in bt])
+        best = min(best, (time.perf_counter() - t0) / a.batches)
+    return best
+
+
+t_walk = timed(False)
+t_coll = timed(True)
 print("items per sample: ocr %d, od %d" % (len(samples[0]["ocr"]), len(samples[0]["od"])))
-print("__getitem__ %.2f ms/sample (%.1f ms per batch of %d);  collate + batch index %.1f ms/batch;  total %.1f ms/batch"
-      % (t_item * 1e3, t_item * a.batch * 1e3, a.batch, t_coll * 1e3, per_batch * 1e3))
-print("one worker feeds %.0f samples/s; a 20 ms step (3 200 samples/s) needs %d workers" % (a.batch / per_batch, int(np.ceil(per_batch / 0.020))))
+print("__getitem__ %.2f ms/sample first visit, %.3f ms cached;  collate + batch index %.1f ms/batch (%.1f ms walking the item dicts)"
+      % (t_item * 1e3, t_cached * 1e3, t_coll * 1e3, t_walk * 1e3))
+for label, ti in (("first epoch", t_item), ("later epochs (ruart_cache_samples)", t_cached)):
+    per_batch = ti * a.batch + t_coll
+    print("%-36s %.1f ms/batch: one worker feeds %.0f samples/s; a 20 ms step (3 200 samples/s) needs %d worker(s)"
+          % (label, per_batch * 1e3, a.batch / per_batch, int(np.ceil(per_batch / 0.020))))
