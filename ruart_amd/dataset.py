@@ -107,6 +107,8 @@ class VQA_Dataset(Dataset):
         if "BERT" in opt:
             key = "BERT_large_tokenizer_file" if "BERT_LARGE" in opt else "BERT_tokenizer_file"
             self.bert_tokenizer = BertTokenizer.from_pretrained(os.path.join(opt["datadir"], opt[key]))
+            self._cls, self._sep = self.bert_tokenizer.vocab["[CLS]"], self.bert_tokenizer.vocab["[SEP]"]
+        self._word_memo = {}
 
     def __len__(self):
         return len(self.data)
@@ -235,7 +237,8 @@ class VQA_Dataset(Dataset):
 
     def bertify(self, words):
         """[CLS] + word pieces + [SEP] as ids, and for a word list the [start, end) piece span of every word
-        (VQA_Dataset.py:415-436).  Word lists are memoised whole: scene-text items repeat across candidates and samples."""
+        (VQA_Dataset.py:415-436).  Two memo levels - a word's piece ids, and whole word lists (scene-text items repeat across
+        candidates and samples); a memoised result is returned as the same list objects again: treat them as read-only."""
         if self.bert_tokenizer is None:
             return None
         tok = self.bert_tokenizer
@@ -243,19 +246,25 @@ class VQA_Dataset(Dataset):
             key = tuple(words)
             hit = self._bert_memo.get(key)
             if hit is None:
-                ids, offsets, n = [tok.vocab["[CLS]"]], [], 1
+                wmemo = self._word_memo
+                ids, offsets, n = [self._cls], [], 1
                 for word in words:
-                    pieces = tok.convert_tokens_to_ids(tok.tokenize(word))
-                    offsets.append([n, n + len(pieces)])
-                    ids.extend(pieces)
-                    n += len(pieces)
-                if len(words) == 0:
+                    pieces = wmemo.get(word)
+                    if pieces is None:
+                        pieces = tok.convert_tokens_to_ids(tok.tokenize(word))
+                        if len(wmemo) < 1 << 20:
+                            wmemo[word] = pieces
+                    m = n + len(pieces)
+                    offsets.append([n, m])
+                    ids += pieces
+                    n = m
+                if not words:
                     offsets = [1, 1]
-                ids.append(tok.vocab["[SEP]"])
+                ids.append(self._sep)
                 hit = (ids, offsets)
                 if len(self._bert_memo) < 1 << 20:
                     self._bert_memo[key] = hit
-            return list(hit[0]), [list(o) if isinstance(o, list) else o for o in hit[1]]
+            return hit
         if isinstance(words, str):
             bpe = ["[CLS]"] + tok.tokenize(words) + ["[SEP]"]
             return tok.convert_tokens_to_ids(bpe), []
