@@ -31,8 +31,8 @@ class VQA_collate:
         flats = [t.get("_flat") for t in batch]
         ocr_f = [f["ocr"] for f in flats] if all(f is not None for f in flats) else None
         od_f = [f["od"] for f in flats] if ocr_f is not None else None
-        ocr_list = self.item_collate([t["ocr"] for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"], ocr_f)
-        od_list = self.item_collate([t["od"] for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"], od_f)
+        ocr_list = self.item_collate([t.get("ocr") for t in batch], o["max_ocr_len"], o["max_ocr_bert_len"], o["max_ocr_num"], ocr_f)
+        od_list = self.item_collate([t.get("od") for t in batch], o["max_od_len"], o["max_od_bert_len"], o["max_od_num"], od_f)
         gt_list = self.gt_collate([t["gt"] for t in batch])
         if self.prepare_index:
             q_list["_ruart_host_index"] = BatchIndex(q_list, ocr_list, od_list, o)
@@ -76,24 +76,35 @@ class VQA_collate:
 
     def item_collate(self, item_list, max_len, max_bert_len, max_num, flats=None):
         """``flats``: the per-sample flat arrays ``VQA_Dataset`` attaches (``sample['_flat'][group]``); with them the id matrices
-        are a concatenation and one scatter per key instead of a walk over every item dict."""
+        are a concatenation and one scatter per key instead of a walk over every item dict.  Compact (cached) samples carry ONLY
+        the flat arrays: ``item_list`` entries are then None and the list-valued fields are rebuilt from the arrays."""
         res = {}
-        B = len(item_list)
-        flat = [it for sample in item_list for it in sample]
         wk = "fasttext" if "FastText" in self.opt else "glove"
         fast = flats is not None and all(f for f in flats)
-        for k in item_list[0][0].keys():
+        have_lists = item_list is not None and all(s_ is not None for s_ in item_list)
+        if not fast and not have_lists:
+            raise ValueError("samples carry neither item lists nor flat arrays")
+        B = len(flats) if fast else len(item_list)
+        flat = [it for sample in item_list for it in sample] if have_lists else None
+        keys = list(item_list[0][0].keys()) if have_lists else list(flats[0].keys())
+        counts = [len(s_) for s_ in item_list] if have_lists else [len(f[wk][1]) for f in flats]
+        for k in keys:
             if "offset" in k:
-                res[k] = [it[k] for it in flat]
                 if fast:
                     vals = np.concatenate([f[k][0] for f in flats])
                     lens = np.concatenate([f[k][1] for f in flats])
-                    res["_" + k + "_arr"] = self._scatter(vals, np.minimum(lens, max_len), max_len, tail=(2,)) if lens.max() <= max_len \
-                        else offsets_to_array(res[k], len(flat), max_len)
+                if have_lists:
+                    res[k] = [it[k] for it in flat]
+                else:                                  # the reference's list-of-lists form, from the arrays
+                    res[k] = [r.tolist() for r in np.split(vals, np.cumsum(lens)[:-1])]
+                if fast:
+                    res["_" + k + "_arr"] = self._scatter(vals, lens, max_len, tail=(2,)) if lens.max() <= max_len \
+                        else offsets_to_array(res[k], len(lens), max_len)
             elif k == "position":
                 pos = torch.zeros(B, max_num, 8)
-                for b, sample in enumerate(item_list):
-                    pos[b, :len(sample)] = torch.from_numpy(flats[b][k]) if fast else torch.tensor([it[k] for it in sample], dtype=torch.float32)
+                for b in range(B):
+                    pos[b, :counts[b]] = torch.from_numpy(flats[b][k]) if fast else \
+                        torch.tensor([it[k] for it in item_list[b]], dtype=torch.float32)
                 res[k] = pos
             else:
                 width = max_bert_len if k in ("bert", "bert_only") else max_len
@@ -104,7 +115,7 @@ class VQA_collate:
                     res[k] = self._pad_rows([it[k] for it in flat], width)
         for k in [k for k in res if k in ("glove", "fasttext", "phoc", "bert", "bert_only")]:
             res[k + "_mask"] = ~res[k].eq(0)
-        res["num_cnt"] = [len(sample) for sample in item_list]
+        res["num_cnt"] = counts
         if fast:
             res["len_cnt"] = [f[wk][1].tolist() for f in flats]
         else:

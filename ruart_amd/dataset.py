@@ -103,7 +103,7 @@ class VQA_Dataset(Dataset):
             self.es_sort_way = opt["ES_sort_way"]
         self.bert_tokenizer = None
         self._bert_memo = {}
-        self._cache = {} if opt.get("ruart_cache_samples") else None   # finished samples by index (epochs revisit them)
+        self._cache = {} if opt.get("ruart_cache_samples") else None   # finished (compact) samples by index: epochs revisit them
         if "BERT" in opt:
             key = "BERT_large_tokenizer_file" if "BERT_LARGE" in opt else "BERT_tokenizer_file"
             self.bert_tokenizer = BertTokenizer.from_pretrained(os.path.join(opt["datadir"], opt[key]))
@@ -135,6 +135,10 @@ class VQA_Dataset(Dataset):
         # ``VQA_collate`` concatenates instead of walking ~9 000 item dicts per batch.  The reference-format lists above stay.
         sample["_flat"] = {"ocr": flatten_items(sample["ocr"]), "od": flatten_items(sample["od"])}
         if self._cache is not None:
+            # compact form: the flat arrays ARE the items (~25 KB per sample instead of ~200 KB of python lists); the collate
+            # rebuilds the list-valued fields of the batch from them.  Returned on the first visit too, so that a cached dataset
+            # always hands out the same kind of sample.
+            sample = {k: v for k, v in sample.items() if k not in ("ocr", "od")}
             self._cache[index] = sample
         return sample
 

@@ -326,12 +326,19 @@ def test_collate_fast_path_equals_item_walk(golden_dir, tmp_path):
     from ruart_amd.batch import BatchIndex
     from ruart_amd.dataset import VQA_Dataset
     inp, _, vocab = _dataset_fixture(golden_dir, tmp_path)
-    opt = default_opt(datadir="", BERT_tokenizer_file=vocab, ruart_cache_samples=True)
-    ds = VQA_Dataset(copy.deepcopy(inp["records"]), opt)
-    samples = [ds[i] for i in range(len(ds))]
-    assert all("_flat" in s_ for s_ in samples) and ds[1] is samples[1]
-    fast = VQA_collate(opt).VQA_collate_fun(samples)
-    slow = VQA_collate(opt).VQA_collate_fun([{k: v for k, v in s_.items() if k != "_flat"} for s_ in samples])
+    opt = default_opt(datadir="", BERT_tokenizer_file=vocab)
+    full = [s_ for s_ in VQA_Dataset(copy.deepcopy(inp["records"]), opt)]
+    cached = VQA_Dataset(copy.deepcopy(inp["records"]), dict(opt, ruart_cache_samples=True))
+    samples = [cached[i] for i in range(len(cached))]
+    assert all("_flat" in s_ and "ocr" not in s_ for s_ in samples) and cached[1] is samples[1]      # compact, and cached
+    assert all("_flat" in s_ and "ocr" in s_ for s_ in full)
+    fast = VQA_collate(opt).VQA_collate_fun(samples)                                                  # from the flat arrays alone
+    mixed = VQA_collate(opt).VQA_collate_fun(full)                                                    # lists + flat arrays
+    slow = VQA_collate(opt).VQA_collate_fun([{k: v for k, v in s_.items() if k != "_flat"} for s_ in full])   # the item walk
+    for a, b in zip(mixed[:3], fast[:3]):
+        assert set(a) == set(b)
+        for k, v in b.items():
+            assert torch.equal(a[k], v) if isinstance(v, torch.Tensor) else (np.array_equal(a[k], v) if isinstance(v, np.ndarray) else a[k] == v), k
     for a, b in zip(fast[:3], slow[:3]):
         assert set(a) - {"_bert_offsets_arr"} == set(b)
         for k, v in b.items():
