@@ -26,6 +26,23 @@ import torch.nn.functional as F
 from . import ops
 
 
+class _Gather(torch.autograd.Function):
+    """y = x[idx] for an index map whose backward is known in closed form: rows of x that ``idx`` duplicates (the padding slots
+    all point at row 0) or drops receive no gradient in this graph, so dx is a second gather (``back``: for every row of x one
+    row of dy, or -1) instead of the atomic scatter-add autograd would run."""
+
+    @staticmethod
+    def forward(ctx, x, idx, back):
+        ctx.save_for_backward(back)
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (back,) = ctx.saved_tensors
+        gx = gy.index_select(0, back.clamp_min(0))
+        return gx * (back >= 0).to(gx.dtype).unsqueeze(1), None, None
+
+
 class _Node(nn.Module):
     """Name-only container: gives parameters the reference's dotted paths."""
 
@@ -70,9 +87,9 @@ class BertModelTrainable(nn.Module):
         T = qkv.size(0)
         nh, hd = self.n_heads, self.hidden // self.n_heads
         outs = []
-        for idx, mask in plan["groups"]:
+        for idx, mask, back in plan["groups"]:
             N, Lg = idx.shape
-            g = qkv.index_select(0, idx.reshape(-1)).view(N, Lg, 3, nh, hd).permute(2, 0, 3, 1, 4)      # (3, N, nh, Lg, hd)
+            g = _Gather.apply(qkv, idx.reshape(-1), back).view(N, Lg, 3, nh, hd).permute(2, 0, 3, 1, 4)  # (3, N, nh, Lg, hd)
             q, k, v = (g[i].reshape(N * nh, Lg, hd) for i in range(3))
             km = mask.view(N, 1, Lg).expand(N, nh, Lg).reshape(N * nh, Lg)
             drop = training and self.p_attn > 0
@@ -86,7 +103,7 @@ class BertModelTrainable(nn.Module):
                     ps = (torch.rand(N * nh, Lg, Lg, device=q.device) >= self.p_attn).to(q.dtype).mul_(1.0 / (1.0 - self.p_attn))
                 ctx = ops.fused_attention(q, k, v, km, prob_scale=ps)
             outs.append(ctx.view(N, nh, Lg, hd).permute(0, 2, 1, 3).reshape(N * Lg, self.hidden))
-        return torch.cat(outs, 0).index_select(0, plan["token_slot"])[:T]
+        return _Gather.apply(torch.cat(outs, 0), plan["token_slot"], plan["slot_token"])[:T]
 
     def forward(self, packed, training=False):
         """All layer outputs (n_layers, T, H) fp32 for the ``PackedTokens`` stream."""
@@ -125,6 +142,7 @@ def attention_plan(packed):
         raise NotImplementedError("the trainable encoder expects the packed stream (no padded slots)")
     dev = packed.ids.device
     groups, slot, base = [], np.zeros(packed.T, dtype=np.int64), 0
+    slot_token = []
     for gidx in packed.group_index:
         real = gidx >= 0
         cols = np.nonzero(real.any(0))[0]
@@ -132,9 +150,15 @@ def attention_plan(packed):
         g, m = gidx[:, :Lg], real[:, :Lg]
         n_idx, j_idx = np.nonzero(m)
         slot[g[m]] = base + n_idx * Lg + j_idx
-        groups.append((torch.from_numpy(np.where(m, g, 0).astype(np.int64)).to(dev), torch.from_numpy(m.astype(np.uint8)).to(dev)))
+        # backward map of this group's gather: packed token t <- its own padded slot (local to the group), others -1
+        back = np.full(packed.T, -1, dtype=np.int64)
+        back[g[m]] = n_idx * Lg + j_idx
+        groups.append((torch.from_numpy(np.where(m, g, 0).astype(np.int64)).to(dev), torch.from_numpy(m.astype(np.uint8)).to(dev),
+                       torch.from_numpy(back).to(dev)))
+        slot_token.append(np.where(m, g, -1).reshape(-1))  # padded slot -> the token it holds (or -1)
         base += g.shape[0] * Lg
-    plan = {"groups": groups, "token_slot": torch.from_numpy(slot).to(dev)}
+    plan = {"groups": groups, "token_slot": torch.from_numpy(slot).to(dev),
+            "slot_token": torch.from_numpy(np.concatenate(slot_token).astype(np.int64)).to(dev)}
     packed._train_plan = plan
     return plan
 
