@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on one GPU: a world-size-1 RCCL process group, so the gradient hooks, the bucketed all-reduce and "
                          "the barriers of the N > 1 path all run")
+    ap.add_argument("--train-gemm", default="x3", choices=["x3", "16"], help="with --unlock-bert: GEMM form of the trainable encoder")
     ap.add_argument("--unlock-bert", action="store_true",
                     help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
     ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
@@ -211,6 +212,7 @@ def main():
         opt["ruart_graph_trunk"] = bool(a.graph_trunk)
     if a.unlock_bert:
         opt.pop("LOCK_BERT")
+        opt["bert_train_gemm"] = a.train_gemm
         a.no_roofline = True                     # the 16-bit encoder GEMM is not on this path
     cfg = synth.bert_config()                       # bert-base-uncased shape, vocab 30522
     n_ocr, n_od = 100, 36

@@ -357,7 +357,7 @@ class Bert(nn.Module):
         if not self.pack:
             raise NotImplementedError("the trainable encoder runs on the packed token stream (bert_no_pack is for the frozen path)")
         state, cfg = self._source
-        self.bert_model = BertModelTrainable(state, cfg, self._device)
+        self.bert_model = BertModelTrainable(state, cfg, self._device, gemm=str(self.opt.get("bert_train_gemm", "x3")))
         self._source = None
 
     def lock(self):

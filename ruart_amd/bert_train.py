@@ -62,9 +62,12 @@ def _register(root, dotted, tensor):
 class BertModelTrainable(nn.Module):
     """State-dict compatible stand-in for the reference's ``BertModel`` (modeling.py:524-614) on the packed token stream."""
 
-    def __init__(self, state, cfg, device):
+    def __init__(self, state, cfg, device, gemm="x3"):
         super().__init__()
         self.cfg = dict(cfg)
+        # "x3": every projection and gradient on the split-bf16 kernel (fp32-class accuracy, the default);
+        # "16": x W^T in f16 and dY W in bf16 on the frozen path's MFMA GEMM, dW on the split-bf16 kernel (opt['bert_train_gemm'])
+        self._lin = ops.linear16 if gemm == "16" else ops.linear
         self.hidden = int(cfg["hidden_size"])
         self.n_layers = int(cfg["num_hidden_layers"])
         self.n_heads = int(cfg["num_attention_heads"])
@@ -121,11 +124,11 @@ class BertModelTrainable(nn.Module):
             a = pre + "attention.self."
             w_qkv = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0)
             b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0)
-            ctx = self._attention(ops.linear(x, w_qkv, b_qkv), plan, training)
-            o = ops.linear(ctx, P[pre + "attention.output.dense.weight"], P[pre + "attention.output.dense.bias"])
+            ctx = self._attention(self._lin(x, w_qkv, b_qkv), plan, training)
+            o = self._lin(ctx, P[pre + "attention.output.dense.weight"], P[pre + "attention.output.dense.bias"])
             x = self._ln(F.dropout(o, self.p_hidden, training) + x, pre + "attention.output.LayerNorm")
-            h = F.gelu(ops.linear(x, P[pre + "intermediate.dense.weight"], P[pre + "intermediate.dense.bias"]))
-            o = ops.linear(h, P[pre + "output.dense.weight"], P[pre + "output.dense.bias"])
+            h = F.gelu(self._lin(x, P[pre + "intermediate.dense.weight"], P[pre + "intermediate.dense.bias"]))
+            o = self._lin(h, P[pre + "output.dense.weight"], P[pre + "output.dense.bias"])
             x = self._ln(F.dropout(o, self.p_hidden, training) + x, pre + "output.LayerNorm")
             layers.append(x)
         return torch.stack(layers, 0)

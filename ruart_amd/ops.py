@@ -235,6 +235,63 @@ def linear(x, w, b=None, mask=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def _padded16(x, dtype, mult=256):
+    """fp32 (M, K) -> 16-bit (ceil(M / mult) * mult, K), zero rows at the end (the MFMA GEMM's row granularity)."""
+    M, K = x.shape
+    Mp = (M + mult - 1) // mult * mult
+    y = torch.empty(Mp, K, dtype=dtype, device=x.device)
+    y[:M].copy_(x)
+    if Mp > M:
+        y[M:].zero_()
+    return y
+
+
+def _gemm16(a16, w16, bias, M_out, dt):
+    """a16 (Mp, K) . w16 (N, K)^T (+ bias) -> fp32 (M_out, N) on ruart_gemm_16_nt (the encoder's 256x256 MFMA kernel)."""
+    lib = hip.load()
+    Mp, K = a16.shape
+    N = w16.shape[0]
+    out = torch.empty(Mp, N, dtype=torch.float32, device=a16.device)
+    hip.check(lib.ruart_gemm_16_nt(hip.ptr(a16), K, hip.ptr(w16), K, hip.ptr(bias), None, 0, dt, hip.ptr(out), N, hip.DT_F32, Mp, N, K,
+                                   hip.ACT_NONE, dt, hip.stream_ptr()), "ruart_gemm_16_nt")
+    return out[:M_out]
+
+
+class _Linear16(torch.autograd.Function):
+    """y = x W^T + b for fp32 x (M, K), W (N, K) with 16-bit MFMA operands (N, K multiples of 256 / 128): forward in f16 (11
+    significand bits; activations are O(1)-O(100)), dX = dY W in bf16 (gradients need the exponent range), both on the encoder's
+    GEMM kernel with on-the-fly casts; dW = dY^T X stays on the split-bf16 kernel (its reduction runs over all M rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return _gemm16(_padded16(x, torch.float16), w.to(torch.float16), b, x.shape[0], hip.DT_F16)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _gemm16(_padded16(gy, torch.bfloat16), w.t().contiguous().to(torch.bfloat16), None, gy.shape[0], hip.DT_BF16)
+        if ctx.needs_input_grad[1]:
+            gw = mm(gy.t(), x, mode="x3")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def linear16(x, w, b=None):
+    """``linear`` with 16-bit MFMA operands for the two row-parallel products (see _Linear16); falls back to ``linear`` for shapes
+    the encoder's GEMM does not take."""
+    N, K = w.shape
+    if not x.is_cuda or x.dim() != 2 or N % 256 or K % 256:
+        return linear(x, w, b)
+    return _Linear16.apply(x.contiguous(), w, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
 class _LstmRecurrence(torch.autograd.Function):
     """Sequential part of one (Bi)LSTM layer.  xproj (B,T,ndir*4h) already holds x W_ih^T + b_ih + b_hh."""
 
