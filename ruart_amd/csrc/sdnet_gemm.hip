@@ -104,7 +104,7 @@ struct Stager {
     }
   }
 
-  __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid) const {
+  __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid, bool with_lo = true) const {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       bf16x4_t h, l;
@@ -124,7 +124,7 @@ struct Stager {
         off = k * XT<TM>::TRS + (tid % (TM / 4)) * 8;
       }
       *reinterpret_cast<bf16x4_t*>(hi_img + off) = h;
-      *reinterpret_cast<bf16x4_t*>(lo_img + off) = l;
+      if (with_lo) *reinterpret_cast<bf16x4_t*>(lo_img + off) = l;
     }
   }
 };
@@ -146,7 +146,7 @@ __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, 
   }
 }
 
-template <int TM, int AMODE, int BMODE, bool VECA, bool VECB>
+template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP = 3>     // NP = 1: the hi.hi product only (plain bf16)
 __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
                                                             long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
                                                             int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
   }
   for (int t = kbeg; t < kend; ++t) {
     char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
-    sa.store(st, st + ARR, tid);
-    sb.store(st + 2 * ARR, st + 3 * ARR, tid);
+    sa.store(st, st + ARR, tid, NP == 3);
+    sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3);
     __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
     if (t + 1 < kend) {
       sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm);
@@ -196,17 +196,20 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ah[j] = frag<TM, AMODE>(st, wm * (TM / 2) + (jh * 4 + j) * 16, fr, fq);
-        al[j] = frag<TM, AMODE>(st + ARR, wm * (TM / 2) + (jh * 4 + j) * 16, fr, fq);
+        if (NP == 3) al[j] = frag<TM, AMODE>(st + ARR, wm * (TM / 2) + (jh * 4 + j) * 16, fr, fq);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bf16x8_t bh = frag<TM, BMODE>(st + 2 * ARR, wn * 64 + i * 16, fr, fq);
-        const bf16x8_t bl = frag<TM, BMODE>(st + 3 * ARR, wn * 64 + i * 16, fr, fq);
+        bf16x8_t bl = bh;
+        if (NP == 3) bl = frag<TM, BMODE>(st + 3 * ARR, wn * 64 + i * 16, fr, fq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4_t& c = acc[i][jh * 4 + j];
-          c = mfma_16x16x32(bl, ah[j], c);            // small terms first
-          c = mfma_16x16x32(bh, al[j], c);
+          if (NP == 3) {
+            c = mfma_16x16x32(bl, ah[j], c);          // small terms first
+            c = mfma_16x16x32(bh, al[j], c);
+          }
           c = mfma_16x16x32(bh, ah[j], c);
         }
       }
@@ -326,11 +329,11 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
   return p;
 }
 
-template <int TM, int AM, int BM_, bool VA, bool VB>
+template <int TM, int AM, int BM_, bool VA, bool VB, int NP = 3>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
                int N, int K, const Plan& p, float* ws, const float* a_scale, const float* b_scale, const float* c_scale, int rpm,
                const float* R, int ldr, int act, hipStream_t s) {
-  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB>;
+  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB, NP>;
   constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
@@ -348,6 +351,20 @@ extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b
   const Plan p = make_plan(M, N, K, a_k_contiguous ? 0 : 1, b_k_contiguous ? 0 : 1);
   if (splitk) *splitk = p.splitk;
   if (ws_bytes) *ws_bytes = p.splitk > 1 ? (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float) : 0;
+  return 0;
+}
+
+extern "C" int ruart_gemm_bf16_tn(const float* A, long long sam, const float* B, long long sbk, float* C, int ldc, int M, int N, int K,
+                                  float* ws, size_t ws_bytes, void* stream) {
+  // C (M, N) = A^T . B for A stored (K, M) with row stride sam... see the header: both operands row-contiguous, 16-byte aligned
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (sam & 3) || (sbk & 3)) return (int)hipErrorInvalidValue;
+  Plan p = make_plan(M, N, K, 1, 1);
+  if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) p.splitk = 1;
+  if (p.tm != 128) return (int)hipErrorInvalidValue;
+  launch_x3<128, 1, 1, true, true, 1>(A, 1, sam, B, sbk, 1, nullptr, C, ldc, M, N, K, p, ws, nullptr, nullptr, nullptr, 1, nullptr, 0,
+                                      RUART_ACT_NONE, (hipStream_t)stream);
+  RUART_CHECK_LAUNCH();
   return 0;
 }
 

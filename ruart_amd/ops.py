@@ -276,10 +276,28 @@ class _Linear16(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _gemm16(_padded16(gy, torch.bfloat16), w.t().contiguous().to(torch.bfloat16), None, gy.shape[0], hip.DT_BF16)
         if ctx.needs_input_grad[1]:
-            gw = mm(gy.t(), x, mode="x3")
+            gw = _dw_bf16(gy, x)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum(0)
         return gx, gw, gb
+
+
+def _dw_bf16(gy, x):
+    """dW (N, K) = gy^T . x for gy (rows, N), x (rows, K) fp32: one bf16 MFMA product with fp32 accumulation
+    (ruart_gemm_bf16_tn), or the split-bf16 kernel when the operands are not laid out for it."""
+    lib = hip.load()
+    rows, N = gy.shape
+    K = x.shape[1]
+    if not (gy.is_contiguous() and x.is_contiguous() and N % 4 == 0 and K % 4 == 0 and gy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        return mm(gy.t(), x, mode="x3")
+    nbytes = ctypes.c_size_t(0)
+    hip.check(lib.ruart_gemm_x3_plan(N, K, rows, 0, 0, None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
+    ws = _scratch(gy.device, nbytes.value // 4, "x3") if nbytes.value else None
+    out = torch.empty(N, K, dtype=torch.float32, device=gy.device)
+    rc = lib.ruart_gemm_bf16_tn(hip.ptr(gy), N, hip.ptr(x), K, hip.ptr(out), K, N, K, rows, hip.ptr(ws), nbytes.value, hip.stream_ptr())
+    if rc != 0:
+        return mm(gy.t(), x, mode="x3")
+    return out
 
 
 def linear16(x, w, b=None):

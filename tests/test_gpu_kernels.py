@@ -556,3 +556,19 @@ def test_phoc_table_matches_reference(golden_dir):
         phoc_table(["ok", "not-ok"], dev(), normalized=True)          # the reference's raw builder raises on '-'
     with pytest.raises(Exception):
         phoc_table(["a"], "cpu")
+
+
+@pytest.mark.parametrize("rows,N,K", [(43008, 768, 768), (5000, 2304, 768), (777, 256, 3072), (64, 768, 768)])
+def test_weight_gradient_bf16_tn(rows, N, K):
+    """ruart_gemm_bf16_tn: dW = dY^T . X straight from row-major dY and X, one bf16 product, fp32 accumulation, split along the
+    row dimension; against the same product of the bf16-rounded operands in float64 (tight) and of the fp32 operands (bf16-level)."""
+    from ruart_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(rows + N)
+    gy, x = torch.randn(rows, N, generator=g) * 0.01, torch.randn(rows, K, generator=g)
+    got = ops._dw_bf16(gy.to(d), x.to(d)).cpu().double()
+    ref16 = gy.bfloat16().double().t() @ x.bfloat16().double()
+    ref = gy.double().t() @ x.double()
+    scale = float(ref.abs().max())
+    assert float((got - ref16).abs().max()) < 2e-5 * scale + 1e-7 * rows ** 0.5
+    assert float((got - ref).abs().max()) < 2e-2 * scale
