@@ -240,6 +240,12 @@ int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, i
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
                   const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
                   const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
+/* ruart_gemm_x3 with ONE bf16 product (hi.hi) instead of three: the operands are rounded to bf16, the accumulation stays fp32.
+ * Same arguments, layouts, epilogue and workspace rule.  For products whose result is a gradient (dX, dW) beside a 16-bit encoder. */
+int ruart_gemm_x1(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
+                  const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
+                  const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
+
 /* Weight-gradient product in plain bf16 (one MFMA product instead of three): C (M, N) fp32 = A^T . B, where A is stored (K, M)
  * with row stride `sak_rows` and B is stored (K, N) with row stride `sbk_rows` (both row-contiguous, 16-byte aligned, strides
  * multiples of 4) - i.e. dW = dY^T . X straight from dY (rows, N_out) and X (rows, K_in), no transposed copies.  fp32 operands are

@@ -354,24 +354,12 @@ extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b
   return 0;
 }
 
-extern "C" int ruart_gemm_bf16_tn(const float* A, long long sam, const float* B, long long sbk, float* C, int ldc, int M, int N, int K,
-                                  float* ws, size_t ws_bytes, void* stream) {
-  // C (M, N) = A^T . B for A stored (K, M) with row stride sam... see the header: both operands row-contiguous, 16-byte aligned
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (sam & 3) || (sbk & 3)) return (int)hipErrorInvalidValue;
-  Plan p = make_plan(M, N, K, 1, 1);
-  if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) p.splitk = 1;
-  if (p.tm != 128) return (int)hipErrorInvalidValue;
-  launch_x3<128, 1, 1, true, true, 1>(A, 1, sam, B, sbk, 1, nullptr, C, ldc, M, N, K, p, ws, nullptr, nullptr, nullptr, 1, nullptr, 0,
-                                      RUART_ACT_NONE, (hipStream_t)stream);
-  RUART_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
-                             const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
-                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
-                             int rows_per_scale_row, void* stream) {
+namespace {
+template <int NP>
+int gemm_xn(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+            const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
+            float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
+            int rows_per_scale_row, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
   if ((residual && ldr < N) || (act != RUART_ACT_NONE && act != RUART_ACT_GELU)) return (int)hipErrorInvalidValue;
   const float* R = residual;
@@ -388,10 +376,10 @@ extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const
   hipStream_t s = (hipStream_t)stream;
 #define X3V(TM, AM, BM_)                                                                                                          \
   do {                                                                                                                            \
-    if (va && vb) launch_x3<TM, AM, BM_, true, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else if (va) launch_x3<TM, AM, BM_, true, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else if (vb) launch_x3<TM, AM, BM_, false, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else launch_x3<TM, AM, BM_, false, false>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                         \
+    if (va && vb) launch_x3<TM, AM, BM_, true, true, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else if (va) launch_x3<TM, AM, BM_, true, false, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else if (vb) launch_x3<TM, AM, BM_, false, true, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
+    else launch_x3<TM, AM, BM_, false, false, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                         \
   } while (0)
 #define X3(AM, BM_)                 \
   do {                              \
@@ -406,4 +394,28 @@ extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const
 #undef X3V
   RUART_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+                             const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
+                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
+                             int rows_per_scale_row, void* stream) {
+  return gemm_xn<3>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
+                    rows_per_scale_row, stream);
+}
+
+extern "C" int ruart_gemm_x1(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
+                             const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
+                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
+                             int rows_per_scale_row, void* stream) {
+  return gemm_xn<1>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
+                    rows_per_scale_row, stream);
+}
+
+extern "C" int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const float* B, long long sbk_rows, float* C, int ldc, int M, int N,
+                                  int K, float* ws, size_t ws_bytes, void* stream) {
+  // A stored (K, M): element (m, k) at A[k * sak_rows + m]; B stored (K, N)
+  return gemm_xn<1>(A, 1, sak_rows, B, sbk_rows, 1, nullptr, nullptr, 0, RUART_ACT_NONE, C, ldc, M, N, K, ws, ws_bytes, nullptr, nullptr,
+                    nullptr, 1, stream);
 }

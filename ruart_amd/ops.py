@@ -135,6 +135,10 @@ def whole_layer_norm(x, eps=1e-5):
 # (ruart_gemm_x3, relative error ~2^-16 per product, ~5x the fp32-MFMA rate); "fp32": torch.mm / addmm (rocBLAS, exact fp32
 # MFMA) - the validation mode (SDNet sets it when opt['bert_precision'] == 'fp32') and the fallback for tiny products.
 trunk_gemm = "x3"
+# GEMM form of the trunk's BACKWARD products (dX = dY W, dW = dY^T X, dW_hh): "x3" (three bf16 products, fp32-class) or "x1" (one
+# bf16 product with fp32 accumulation - what mixed-precision training uses for gradients).  SDNet.forward sets it from
+# opt['ruart_trunk_grad_gemm'] (default "x3").  Forward products always use trunk_gemm.
+trunk_grad_gemm = "x3"
 _X3_MIN_FLOP = 2 * 64 * 64 * 64
 
 
@@ -156,7 +160,8 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     loads / the output (each mask row is shared by ``rpm`` consecutive rows)."""
     M, K = a.shape
     N = b.shape[1]
-    use_x3 = (mode or trunk_gemm) == "x3" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and 2 * M * N * K >= _X3_MIN_FLOP
+    mode = mode or trunk_gemm
+    use_x3 = mode in ("x3", "x1") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and 2 * M * N * K >= _X3_MIN_FLOP
     if use_x3:
         a, b = _one_unit_stride(a), _one_unit_stride(b)
         if (a_scale is not None and a.stride(1) != 1) or (b_scale is not None and b.stride(1) != 1):
@@ -185,9 +190,10 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     nbytes = ctypes.c_size_t(0)
     hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
     ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
-    hip.check(lib.ruart_gemm_x3(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), None, 0, hip.ACT_NONE, hip.ptr(out), N,
-                                M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm),
-                                hip.stream_ptr()), "ruart_gemm_x3")
+    fn = lib.ruart_gemm_x1 if mode == "x1" else lib.ruart_gemm_x3
+    hip.check(fn(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), None, 0, hip.ACT_NONE, hip.ptr(out), N,
+                 M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm),
+                 hip.stream_ptr()), "ruart_gemm_x3")
     return out
 
 
@@ -202,7 +208,7 @@ class _Linear(torch.autograd.Function):
         xm = x if mask is None else (x.view(-1, rpm, x.shape[1]) * mask.unsqueeze(1)).view(x.shape)
         ctx.save_for_backward(xm, w, mask)
         ctx.has_bias = b is not None
-        ctx.mode = trunk_gemm
+        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm       # form of the two backward products
         ctx.rpm = rpm
         return mm(xm, w.t(), b)
 
@@ -329,7 +335,7 @@ class _LstmRecurrence(torch.autograd.Function):
         hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), hip.ptr(hprev), B, T, h,
                                      ndir, hip.stream_ptr()), "ruart_lstm_fwd")
         ctx.ndir, ctx.h = ndir, h
-        ctx.mode = trunk_gemm
+        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm
         ctx.save_for_backward(w_hh, gates, cells, hprev)
         ctx.shape = y.shape
         return y

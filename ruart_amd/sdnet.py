@@ -371,7 +371,11 @@ class SDNet(nn.Module):
         opt = self.opt
         dev = self.device
         # trunk projections: split-bf16 MFMA kernel, or the library's exact fp32 GEMM in the fp32 validation mode
-        ops.trunk_gemm = opt.get("ruart_trunk_gemm", "fp32" if opt.get("bert_precision", "fp16") == "fp32" else "x3")
+        prec = opt.get("bert_precision", "fp16")
+        ops.trunk_gemm = opt.get("ruart_trunk_gemm", "fp32" if prec == "fp32" else "x3")
+        # gradients of the trunk's projections: three bf16 products like the forward ("x1": one product - measured worth only
+        # 0.1-0.2 ms of a 20 ms step, these products are bound by their fp32 operand loads, so it stays an option)
+        ops.trunk_grad_gemm = opt.get("ruart_trunk_grad_gemm", "x3")
         bi = self.prepare(q_list, ocr_list, od_list)
         if self.training or self.drop_emb:
             L.mask_bank.begin_step(dev)
