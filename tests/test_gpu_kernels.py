@@ -572,3 +572,20 @@ def test_weight_gradient_bf16_tn(rows, N, K):
     scale = float(ref.abs().max())
     assert float((got - ref16).abs().max()) < 2e-5 * scale + 1e-7 * rows ** 0.5
     assert float((got - ref).abs().max()) < 2e-2 * scale
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+def test_gemm_x1_layouts(layout):
+    """ops.mm(mode='x1') -> ruart_gemm_x1: one bf16 product per term with fp32 accumulation, in all four operand layouts, against
+    the product of the bf16-rounded operands in float64."""
+    from ruart_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 700, 500, 1100
+    a = torch.randn(K, M, generator=g).t() if layout[0] == "t" else torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g).t() if layout[1] == "t" else torch.randn(K, N, generator=g)
+    got = ops.mm(a.to(d), b.to(d), mode="x1").cpu().double()
+    ref = a.bfloat16().double() @ b.bfloat16().double()
+    assert float((got - ref).abs().max()) < 3e-5 * float(ref.abs().max()) + 1e-4
+    full = ops.mm(a.to(d), b.to(d), mode="x3").cpu().double()
+    assert float((full - a.double() @ b.double()).abs().max()) < 2e-4 * float(ref.abs().max())      # the three-product form stays fp32-class
