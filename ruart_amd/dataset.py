@@ -109,6 +109,9 @@ class VQA_Dataset(Dataset):
             self.bert_tokenizer = BertTokenizer.from_pretrained(os.path.join(opt["datadir"], opt[key]))
             self._cls, self._sep = self.bert_tokenizer.vocab["[CLS]"], self.bert_tokenizer.vocab["[SEP]"]
         self._word_memo = {}
+        # the field set flatten_items would produce for the shipped conf; anything else takes the general route
+        self._direct_flat = (self.ocr_embedding == ["fasttext", "pos", "ent", "bert"] and "bert" in self.q_embedding
+                             and "bert_only" not in self.q_embedding and self.bert_tokenizer is not None)
 
     def __len__(self):
         return len(self.data)
@@ -125,6 +128,14 @@ class VQA_Dataset(Dataset):
         ocr_items = ocr_items[:self.max_ocr_num]
         od_items = od_items[:self.max_od_num]
         answers = datum.get("orign_answers")
+        if self._cache is not None and self._direct_flat:
+            # compact samples of the standard conf: the flat arrays are filled straight from the records, no per-item dicts
+            sample = {"q": q, "gt": self.get_label(ocr_items, q_id=datum["question_id"], answers=answers),
+                      "extra_info": {"q_id": datum["question_id"], "answers": answers,
+                                     "ocr_list": [t["original"] for t in ocr_items], "image_path": datum["filename"]},
+                      "_flat": {"ocr": self._flat_direct(ocr_items), "od": self._flat_direct(od_items)}}
+            self._cache[index] = sample
+            return sample
         sample = {"q": q,
                   "ocr": self.get_list_embedding(ocr_items, self.ocr_embedding),
                   "od": self.get_list_embedding(od_items, self.ocr_embedding),
@@ -141,6 +152,32 @@ class VQA_Dataset(Dataset):
             sample = {k: v for k, v in sample.items() if k not in ("ocr", "od")}
             self._cache[index] = sample
         return sample
+
+    def _flat_direct(self, items):
+        """``flatten_items(self.get_list_embedding(items, ...))`` without building the item dicts (same keys, order, dtypes)."""
+        n = len(items)
+        wid, pos, ent, bert, offs, position = [], [], [], [], [], []
+        len_w, len_b = np.empty(n, np.int64), np.empty(n, np.int64)
+        bertify = self.bertify
+        for i, item in enumerate(items):
+            w = item["object"] if "object" in item else item["word"]
+            ids = w["wordid"]
+            wid += ids
+            pos += w["pos_id"]
+            ent += w["ent_id"]
+            b, o = bertify(w["word"])
+            bert += b
+            offs += o
+            len_w[i] = len(ids)
+            len_b[i] = len(b)
+            position.append(item["pos"])
+        len_p = np.fromiter((len(it["object"]["pos_id"] if "object" in it else it["word"]["pos_id"]) for it in items), np.int64, n)
+        len_e = np.fromiter((len(it["object"]["ent_id"] if "object" in it else it["word"]["ent_id"]) for it in items), np.int64, n)
+        len_o = np.fromiter((len(it["object"]["word"] if "object" in it else it["word"]["word"]) for it in items), np.int64, n)
+        return {"fasttext": (np.array(wid, dtype=np.int64), len_w), "pos": (np.array(pos, dtype=np.int64), len_p),
+                "ent": (np.array(ent, dtype=np.int64), len_e), "bert": (np.array(bert, dtype=np.int64), len_b),
+                "bert_offsets": (np.array(offs, dtype=np.int64).reshape(-1, 2), len_o),
+                "position": np.asarray(position, dtype=np.float32).reshape(n, 8)}
 
     # -- candidate lists (VQA_Dataset.py:293-349) ---------------------------------------------------------------
     def get_list_from_datum(self, datum, name_list, od_ocr="ocr", remove_same=False):

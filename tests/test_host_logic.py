@@ -332,6 +332,14 @@ def test_collate_fast_path_equals_item_walk(golden_dir, tmp_path):
     samples = [cached[i] for i in range(len(cached))]
     assert all("_flat" in s_ and "ocr" not in s_ for s_ in samples) and cached[1] is samples[1]      # compact, and cached
     assert all("_flat" in s_ and "ocr" in s_ for s_ in full)
+    assert cached._direct_flat                                                                         # filled straight from the records
+    for c_, f_ in zip(samples, full):
+        for grp in ("ocr", "od"):
+            assert list(c_["_flat"][grp]) == list(f_["_flat"][grp])
+            for k, v in f_["_flat"][grp].items():
+                got = c_["_flat"][grp][k]
+                assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(got, v)) if isinstance(v, tuple) \
+                    else (np.array_equal(got, v) and got.dtype == v.dtype), (grp, k)
     fast = VQA_collate(opt).VQA_collate_fun(samples)                                                  # from the flat arrays alone
     mixed = VQA_collate(opt).VQA_collate_fun(full)                                                    # lists + flat arrays
     slow = VQA_collate(opt).VQA_collate_fun([{k: v for k, v in s_.items() if k != "_flat"} for s_ in full])   # the item walk
