@@ -44,6 +44,17 @@ const char* ruart_version(void);
 int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
                      int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
                      void* stream);
+/* The same projections in the "f16 + fp8 correction" precision mode (csrc/gemm_corr.hip):
+ *   C = act(A16 . W16^T + 2^-20 * A8 . W8^T + bias) [+ residual]
+ * A16 (M, K) f16 and A8 (M, 2K) e4m3 bytes with the SAME row pitch in bytes (2 * lda): A8 row = [fp8((a - f16(a)) * 2^13), K bytes |
+ * fp8(a * 2^2), K bytes]; W16 (N, K) f16 and W8 (N, 2K) likewise with [fp8(f16(w) * 2^7) | fp8((w - f16(w)) * 2^18)].  The fp8 part
+ * runs on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the f16 MFMA rate) into the same fp32 accumulators, so the product carries
+ * ~2^-16 relative operand error instead of the 2^-12 of a plain f16 product, at 2x (not 3x) the matrix time.
+ *   act NONE: C (M, N) fp32, optional fp32 residual (row stride ldr), C8 must be NULL;
+ *   act GELU: C (M, N) f16 and C8 (M, 2N) bytes (row pitch 2 * ldc) in the A8 layout - the operand of the next projection.
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0. */
+int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                      const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
 /* Tile variant of ruart_gemm_16_nt: 5 (default) = 256x256 tile, four phases per K-tile with the prefetch in flight across
@@ -70,6 +81,14 @@ int ruart_bert_embed_ln(const int* ids, const int* pos_ids, const float* word_em
 /* Models/Bert/modeling.py:164-168: TF-style layer norm (eps inside the sqrt) of fp32 rows. H % 4 == 0, H <= 1024. */
 int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
                          int out_dtype, int rows, int H, void* stream);
+/* The two row kernels above writing the "f16 + fp8 correction" triple (RUART_DT_F16C mode of the encoder): out32 (rows, H) fp32 - the
+ * residual stream / layer output -, out16 (rows, H) f16 and out8 (rows, 2H) e4m3 bytes [lo | hi] (ruart_gemm_16c_nt's A16 / A8);
+ * all three with row stride ldo elements (out8: 2 * ldo bytes). */
+int ruart_rows_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out32, void* out16,
+                               void* out8, int ldo, int rows, int H, void* stream);
+int ruart_bert_embed_ln_split(const int* ids, const int* pos_ids, const float* word_emb, const float* pos_emb, const float* type_emb,
+                              const float* gamma, const float* beta, float eps, float* out32, void* out16, void* out8, int ldo, int rows,
+                              int H, void* stream);
 /* Models/Bert/modeling.py:234-250 on a packed token stream.  qkv rows are [Q | K | V] (3H wide), Q already
  * scaled by 1/sqrt(64).  Two kinds of query blocks:
  *   short windows (n_blocks): block b covers tokens [blk_q0[b], blk_q1[b]) (<= 64, whole short sequences) and stages keys
@@ -81,6 +100,12 @@ int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype,
                          const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
                          const int* tok_hi, const float* key_bias, int n_long_blocks, const int* lblk_q0, const int* lblk_q1,
                          const int* lblk_k0, const int* lblk_k1, void* stream);
+/* ruart_bert_attention for the RUART_DT_F16C mode: fp32 [Q | K | V] rows in (the scores, the softmax and P.V stay fp32 - they are
+ * 0.1 % of the encoder's flops at item lengths of 3-8 pieces), context rows out as ctx16 (f16) + ctx8 (2H e4m3 bytes per row, [lo | hi]),
+ * both with row stride ldc elements.  Short-window blocks only (the host plans a long sequence as 64-query blocks over all its keys). */
+int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8, int ldc, int H, int n_heads, int n_blocks,
+                               const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
+                               const int* tok_hi, const float* key_bias, void* stream);
 /* Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: out[dst_row[w]] = sum_l layer_w[l] *
  * mean(layer_l[span_start[w] .. +span_len[w])).  layers = n_layers matrices [rows, H], layer_stride elements apart.
  * Rows of `out` that no word maps to are left untouched (the caller zero-fills: masked words are zeros). */
@@ -108,6 +133,12 @@ typedef struct {
   const float* const* ln2_g;  const float* const* ln2_b;
   int f32_gemm;   /* dtype == F32 only: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), 1 = fp32 operands split into bf16 hi + lo and
                      multiplied as three 16-bit MFMA products (ruart_gemm_x3: ~2^-16 per product, ~2.5x faster) */
+  int corr8;      /* dtype == F16 only: != 0 selects the "f16 + fp8 correction" mode (ruart_gemm_16c_nt): w_* are the f16 weights,
+                     w8_* the (out, 2 in) e4m3 companions; layers_out, the residual stream and the QKV rows are fp32 */
+  const void* const* w8_qkv;
+  const void* const* w8_ao;
+  const void* const* w8_ff1;
+  const void* const* w8_ff2;
 } ruart_bert_model;
 
 typedef struct {
@@ -123,7 +154,7 @@ typedef struct {
 } ruart_bert_batch;
 
 size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows);
-/* layers_out: [n_layers][n_rows][hidden] in m->dtype.  `m` and `b` are HOST structs. */
+/* layers_out: [n_layers][n_rows][hidden] in m->dtype (fp32 when m->corr8).  `m` and `b` are HOST structs. */
 int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                        size_t workspace_bytes, void* stream);
 

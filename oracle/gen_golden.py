@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_full | e2e_full_ragged | e2e_stress | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -321,6 +321,107 @@ def gen_e2e():
         else:
             arrays["cap:" + k] = v
     save("sdnet_e2e", **arrays)
+
+
+def _run_reference_step(net, L, q, ocr, od, gt, bert_eval=True):
+    """The reference's forward + loss + backward with every dropout off."""
+    L.set_dropout_prob(0.0)
+    net.train()
+    if bert_eval:
+        net.Bert.bert_model.eval()
+    net.drop_emb = False
+    scores, _ = net(q, ocr, od)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
+    loss.backward()
+    return scores, loss
+
+
+def _grad_summary(net, arrays, full_below=4096):
+    names, norms = [], []
+    for n_, p in net.named_parameters():
+        if n_.startswith("Bert."):
+            continue
+        names.append(n_)
+        norms.append(-1.0 if p.grad is None else float(p.grad.double().norm()))
+        if p.grad is not None and p.numel() <= full_below:
+            arrays["grad:" + n_] = p.grad.numpy().copy()
+    arrays["grad_names"] = np.array(names)
+    arrays["grad_norms"] = np.array(norms)
+
+
+def gen_e2e_full(which="bench"):
+    """The UNMODIFIED reference at BASELINE.json's full per-GPU size: B = 64, 30 question words, 100 OCR items, 36 objects,
+    bert-base - SDNet.forward (Models/SDNet.py:253-437) + loss (Models/SDNetTrainer.py:510-518) + backward.
+      bench  : exactly bench.py's workload (rank 0, batch 0: vocab 20000, BERT vocab 30522, weights N(0, 0.02), seed 1033,
+               batch seed 7, every sample at the maximum item counts)           -> sdnet_e2e_full.npz
+      ragged : the workload of tests/test_gpu_sdnet.py::test_full_size_properties (weights N(0, 0.05), seed 21, batch seed 31,
+               ragged item counts)                                              -> sdnet_e2e_full_ragged.npz
+    Weights are regenerated from the seed where the tests run; stored: scores (64, 101), loss, every gradient norm, the
+    gradients of the small tensors and a slice of one embedding-table gradient."""
+    import time
+    if which == "bench":
+        opt = default_opt(vocab_size=20000, max_od_num=36)
+        bert_cfg, seed, bseed, w_std, ragged, name = synth.bert_config(), 1033, 7, 0.02, False, "sdnet_e2e_full"
+    else:
+        opt = default_opt(vocab_size=2000, max_od_num=36)
+        bert_cfg, seed, bseed, w_std, ragged, name = synth.bert_config(vocab_size=3000), 21, 31, 0.05, True, "sdnet_e2e_full_ragged"
+    from Models.SDNet import SDNet
+    import Models.Layers as L
+    bw = synth.make_bert_weights(bert_cfg, seed=seed, w_std=w_std)
+    opt = dict(opt)
+    opt["BERT_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]).clone(), "fast_embedding": T(sw["fast_embed.weight"]).clone()}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing), (missing, unexpected)
+    B = 64
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, B, seed=bseed, n_q=30, n_ocr=100, n_od=36, bert_vocab=bert_cfg["vocab_size"],
+                                              ragged=ragged)
+    t0 = time.perf_counter()
+    scores, loss = _run_reference_step(net, L, q, ocr, od, gt)
+    print("%s: reference fwd+bwd at B=64 took %.1f s on %d threads; loss %.6f" % (name, time.perf_counter() - t0,
+                                                                                 torch.get_num_threads(), loss.item()))
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(bseed), B=np.array(B), vocab_size=np.array(opt["vocab_size"]),
+                  bert_vocab=np.array(bert_cfg["vocab_size"]), w_std=np.array(w_std), ragged=np.array(ragged),
+                  bert_wsum=checksum(bw), sdnet_wsum=checksum(sw), scores=scores.detach().numpy(), loss=np.array(loss.item()),
+                  ocr_num_cnt=np.array(ocr["num_cnt"]), od_num_cnt=np.array(od["num_cnt"]))
+    _grad_summary(net, arrays)
+    arrays["grad:fast_embed.weight[:64]"] = net.fast_embed.weight.grad[:64].numpy().copy()
+    save(name, **arrays)
+
+
+def gen_e2e_stress():
+    """BASELINE.json's stress shapes on the UNMODIFIED reference: bert-large (24 x 1024, 16 heads, FFN 4096; the reference
+    switches on `BERT_LARGE`, Models/Bert/Bert.py:26-33), 300 OCR items, 100 objects, B = 2 (one sample at the maximum item
+    counts, one ragged).  Stored like sdnet_e2e_full.npz -> sdnet_e2e_stress.npz."""
+    import time
+    opt = default_opt(vocab_size=800, BERT_LARGE=True, max_ocr_num=300, max_od_num=100)
+    bert_cfg = synth.bert_config(vocab_size=1200, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    seed, bseed, w_std = 1033, 41, 0.02
+    from Models.SDNet import SDNet
+    import Models.Layers as L
+    bw = synth.make_bert_weights(bert_cfg, seed=seed, w_std=w_std)
+    opt = dict(opt)
+    opt["BERT_large_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]).clone(), "fast_embedding": T(sw["fast_embed.weight"]).clone()}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing), (missing, unexpected)
+    B = 2
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, B, seed=bseed, n_q=30, n_ocr=300, n_od=100, bert_vocab=1200, ragged=True)
+    print("stress num_cnt ocr", ocr["num_cnt"], "od", od["num_cnt"])
+    t0 = time.perf_counter()
+    scores, loss = _run_reference_step(net, L, q, ocr, od, gt)
+    print("sdnet_e2e_stress: reference fwd+bwd took %.1f s; loss %.6f" % (time.perf_counter() - t0, loss.item()))
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(bseed), B=np.array(B), vocab_size=np.array(800), bert_vocab=np.array(1200),
+                  w_std=np.array(w_std), bert_wsum=checksum(bw), sdnet_wsum=checksum(sw), scores=scores.detach().numpy(),
+                  loss=np.array(loss.item()), ocr_num_cnt=np.array(ocr["num_cnt"]), od_num_cnt=np.array(od["num_cnt"]))
+    _grad_summary(net, arrays)
+    save("sdnet_e2e_stress", **arrays)
 
 
 def gen_e2e_phoc():
@@ -712,6 +813,12 @@ if __name__ == "__main__":
         gen_bert()
     if "e2e" in which:
         gen_e2e()
+    if "e2e_full" in which:
+        gen_e2e_full("bench")
+    if "e2e_full_ragged" in which:
+        gen_e2e_full("ragged")
+    if "e2e_stress" in which:
+        gen_e2e_stress()
     if "e2e_phoc" in which:
         gen_e2e_phoc()
     if "e2e_unlocked" in which:

@@ -33,14 +33,26 @@ def _np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
+def split_f16c(x, lo_shift=13, hi_shift=2):
+    """fp32 (M, K) -> (f16 (M, K), uint8 (M, 2K)): the "f16 + fp8 correction" operand form of ruart_gemm_16c_nt (csrc/common.h):
+    row of the second = [e4m3((x - f16(x)) 2^lo_shift) | e4m3(x 2^hi_shift)].  Weights use shifts (18, 7) and the halves swapped."""
+    hi = x.to(torch.float16)
+    lo = x - hi.to(torch.float32)
+    pair = torch.cat([lo * float(1 << lo_shift), x * float(1 << hi_shift)], 1).clamp_(-448.0, 448.0)
+    return hi.contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+
+
 class BertEncoderWeights:
     """Device-resident encoder weights in the layout ruart_bert_forward expects."""
 
     def __init__(self, state, cfg, device, dtype="fp16"):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
-        self.dtype = hip.PRECISION[dtype]
+        self.precision = dtype
+        self.dtype = hip.PRECISION[dtype]              # storage type of the layer outputs
         self.tdtype = hip.TORCH_DTYPE[self.dtype]
+        self.corr8 = dtype == "fp16c"                  # f16 MFMA operands + fp8 correction (csrc/gemm_corr.hip)
+        wdtype = torch.float16 if self.corr8 else self.tdtype
         H = cfg["hidden_size"]
         nh = cfg["num_attention_heads"]
         if H % nh or H // nh != 64:
@@ -51,7 +63,13 @@ class BertEncoderWeights:
             return torch.as_tensor(_np(state[pre + name]), dtype=torch.float32).to(self.device).contiguous()
 
         def gemm_w(t):
-            return t.to(self.tdtype).contiguous()
+            return t.to(wdtype).contiguous()
+
+        def gemm_w8(t):
+            """(out, 2 in) e4m3 companion of a weight matrix: [fp8(f16(w) 2^7) | fp8((w - f16(w)) 2^18)] (common.h)."""
+            hi = t.to(torch.float16).to(torch.float32)
+            pair = torch.cat([hi * float(1 << 7), (t - hi) * float(1 << 18)], 1).clamp_(-448.0, 448.0)
+            return pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
         e = "embeddings."
         self.word_emb = f32(e + "word_embeddings.weight")
@@ -60,13 +78,19 @@ class BertEncoderWeights:
         self.emb_ln_g = f32(e + "LayerNorm.gamma")
         self.emb_ln_b = f32(e + "LayerNorm.beta")
         keys = ["w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2", "ln2_g", "ln2_b"]
-        self.layers = {k: [] for k in keys}
+        keys8 = ["w8_qkv", "w8_ao", "w8_ff1", "w8_ff2"] if self.corr8 else []
+        self.layers = {k: [] for k in keys + keys8}
         scale = 1.0 / 8.0                      # 1/sqrt(head_dim = 64): a power of two, exact in fp32 and bf16
         for l in range(cfg["num_hidden_layers"]):
             p = "encoder.layer.%d." % l
             wq, wk, wv = f32(p + "attention.self.query.weight"), f32(p + "attention.self.key.weight"), f32(p + "attention.self.value.weight")
             bq, bk, bv = f32(p + "attention.self.query.bias"), f32(p + "attention.self.key.bias"), f32(p + "attention.self.value.bias")
             L = self.layers
+            if self.corr8:
+                L["w8_qkv"].append(gemm_w8(torch.cat([wq * scale, wk, wv], 0)))
+                L["w8_ao"].append(gemm_w8(f32(p + "attention.output.dense.weight")))
+                L["w8_ff1"].append(gemm_w8(f32(p + "intermediate.dense.weight")))
+                L["w8_ff2"].append(gemm_w8(f32(p + "output.dense.weight")))
             L["w_qkv"].append(gemm_w(torch.cat([wq * scale, wk, wv], 0)))
             L["b_qkv"].append(torch.cat([bq * scale, bk, bv], 0).contiguous())
             L["w_ao"].append(gemm_w(f32(p + "attention.output.dense.weight")))
@@ -83,11 +107,12 @@ class BertEncoderWeights:
         self._arrays = {}
         m = hip.BertModelC()
         m.hidden, m.n_heads, m.n_layers, m.intermediate = H, nh, nl, cfg["intermediate_size"]
-        m.dtype, m.ln_eps = self.dtype, 1e-12
+        m.dtype, m.ln_eps = (hip.DT_F16 if self.corr8 else self.dtype), 1e-12
         m.f32_gemm = 1 if dtype == "x3" else 0
+        m.corr8 = 1 if self.corr8 else 0
         for k in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"):
             setattr(m, k, getattr(self, k).data_ptr())
-        for k in keys:
+        for k in keys + keys8:
             arr = (c_void_p * nl)(*[t.data_ptr() for t in self.layers[k]])
             self._arrays[k] = arr
             setattr(m, k, ctypes.cast(arr, ctypes.POINTER(c_void_p)))

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libruart_hip.so")
-SOURCES = ["gemm.hip", "bert_kernels.hip", "bert_forward.hip", "sdnet_attention.hip", "sdnet_lstm.hip", "sdnet_gemm.hip", "sdnet_optim.hip", "phoc.hip"]
+SOURCES = ["gemm.hip", "gemm_corr.hip", "bert_kernels.hip", "bert_forward.hip", "sdnet_attention.hip", "sdnet_lstm.hip", "sdnet_gemm.hip", "sdnet_optim.hip", "phoc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INC, "-I", CSRC, "-Wno-unused-result", "-Wno-pass-failed"]
 
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INC, "ruart_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_shared.h"), os.path.join(INC, "ruart_hip.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = [s[:-4] + ".o" for s in srcs]
 

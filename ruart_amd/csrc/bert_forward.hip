@@ -23,9 +23,25 @@ struct Carve {
 };
 }  // namespace
 
+// RUART_DT_F16C ("f16 + fp8 correction", m->corr8 != 0; common.h): the residual stream, the layer outputs and the QKV rows are fp32;
+// every GEMM input exists as an f16 matrix plus a fp8 matrix of the same row pitch (two e4m3 bytes per element).
+static size_t corr_workspace_bytes(size_t R, size_t H, size_t I) {
+  size_t t = 0;
+  t += align_up(R * H * 4, 256);        // x32   embedding output (residual of layer 0)
+  t += 2 * align_up(R * H * 2, 256);    // x16, x8   current layer input as GEMM operand
+  t += align_up(R * 3 * H * 4, 256);    // qkv (fp32)
+  t += 2 * align_up(R * H * 2, 256);    // ctx16, ctx8
+  t += align_up(R * H * 4, 256);        // pre-LN rows (fp32)
+  t += align_up(R * H * 4, 256);        // mid32
+  t += 2 * align_up(R * H * 2, 256);    // mid16, mid8
+  t += 2 * align_up(R * I * 2, 256);    // ffn16, ffn8
+  return t;
+}
+
 extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows) {
   const size_t es = m->dtype == RUART_DT_F32 ? 4 : 2;
   const size_t R = (size_t)n_rows, H = (size_t)m->hidden, I = (size_t)m->intermediate;
+  if (m->corr8) return corr_workspace_bytes(R, H, I);
   size_t t = 0;
   t += align_up(R * H * es, 256);       // x0   embedding output
   t += align_up(R * 3 * H * es, 256);   // qkv
@@ -36,6 +52,54 @@ extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_ro
   return t;
 }
 
+// The encoder in the f16 + fp8-correction mode.  layers_out: [n_layers][n_rows][hidden] fp32.
+static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace, void* stream) {
+  const int H = m->hidden, I = m->intermediate, R = b->n_rows;
+  if (R % 256 || H % 256 || I % 256 || b->n_long_blocks != 0 || b->n_blocks <= 0) return (int)hipErrorInvalidValue;
+  if (!m->w8_qkv || !m->w8_ao || !m->w8_ff1 || !m->w8_ff2) return (int)hipErrorInvalidValue;
+  Carve c{(char*)workspace, 0};
+  float* x32 = (float*)c.take((size_t)R * H * 4);
+  void* x16 = c.take((size_t)R * H * 2);
+  void* x8 = c.take((size_t)R * H * 2);
+  float* qkv = (float*)c.take((size_t)R * 3 * H * 4);
+  void* ctx16 = c.take((size_t)R * H * 2);
+  void* ctx8 = c.take((size_t)R * H * 2);
+  float* pre = (float*)c.take((size_t)R * H * 4);
+  float* mid32 = (float*)c.take((size_t)R * H * 4);
+  void* mid16 = c.take((size_t)R * H * 2);
+  void* mid8 = c.take((size_t)R * H * 2);
+  void* ffn16 = c.take((size_t)R * I * 2);
+  void* ffn8 = c.take((size_t)R * I * 2);
+  int rc = ruart_bert_embed_ln_split(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, m->ln_eps, x32,
+                                     x16, x8, H, R, H, stream);
+  if (rc) return rc;
+  ruart_prof_real_rows = b->n_tokens;
+  const float* res = x32;
+  for (int l = 0; l < m->n_layers; ++l) {
+    float* out = (float*)layers_out + (size_t)l * R * H;
+    if ((rc = ruart_gemm_16c_nt(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
+                                RUART_ACT_NONE, stream)))
+      return rc;
+    if ((rc = ruart_bert_attention_split(qkv, 3 * H, ctx16, ctx8, H, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
+                                         b->tok_lo, b->tok_hi, b->key_bias, stream)))
+      return rc;
+    if ((rc = ruart_gemm_16c_nt(ctx16, ctx8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, R, H, H, RUART_ACT_NONE,
+                                stream)))
+      return rc;
+    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid32, mid16, mid8, H, R, H, stream))) return rc;
+    if ((rc = ruart_gemm_16c_nt(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, R, I, H,
+                                RUART_ACT_GELU, stream)))
+      return rc;
+    if ((rc = ruart_gemm_16c_nt(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, R, H, I,
+                                RUART_ACT_NONE, stream)))
+      return rc;
+    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, x16, x8, H, R, H, stream))) return rc;
+    res = out;
+  }
+  ruart_prof_real_rows = 0;
+  return 0;
+}
+
 extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   const int H = m->hidden, I = m->intermediate, R = b->n_rows, dt = m->dtype;
@@ -43,6 +107,10 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
   if (dt != RUART_DT_F32 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;
   if (dt != RUART_DT_F32 && dt != RUART_DT_BF16 && dt != RUART_DT_F16) return (int)hipErrorInvalidValue;
   if (workspace_bytes < ruart_bert_workspace_bytes(m, R)) return (int)hipErrorInvalidValue;
+  if (m->corr8) {
+    if (dt != RUART_DT_F16) return (int)hipErrorInvalidValue;
+    return bert_forward_corr(m, b, layers_out, workspace, stream);
+  }
   const size_t es = dt == RUART_DT_F32 ? 4 : 2;
   Carve c{(char*)workspace, 0};
   void* x0 = c.take((size_t)R * H * es);

@@ -18,9 +18,27 @@
 // ---------------------------------------------------------------------------------------------
 #define MAXG 4
 
+// where a finished row goes: one tensor in the storage type, or the "f16 + fp8 correction" triple of RUART_DT_F16C (fp32 row for
+// the residual stream and the pooling kernel, f16 row + the two e4m3 halves for the next GEMM; common.h)
 template <typename TOut>
+struct RowStorePlain {
+  TOut* out;
+  __device__ __forceinline__ void operator()(int c, f32x4_t o) const { store4(out + c, o); }
+};
+struct RowStoreSplit {
+  float* o32;
+  f16_t* o16;
+  unsigned char* o8;
+  int H;
+  __device__ __forceinline__ void operator()(int c, f32x4_t o) const {
+    store4(o32 + c, o);
+    store_split4(o16 + c, o8 + c, H, o);
+  }
+};
+
+template <typename Store>
 __device__ __forceinline__ void ln_row_finish(f32x4_t (&v)[MAXG], int H, int lane, const float* gamma, const float* beta,
-                                              float eps, TOut* out) {
+                                              float eps, const Store& out) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXG; ++i) {
@@ -50,7 +68,7 @@ __device__ __forceinline__ void ln_row_finish(f32x4_t (&v)[MAXG], int H, int lan
       f32x4_t o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = g[r] * ((v[i][r] - mean) * rstd) + b[r];
-      store4(out + c, o);
+      out(c, o);
     }
   }
 }
@@ -68,18 +86,31 @@ __global__ __launch_bounds__(256) void rows_layernorm_kernel(const float* __rest
     const int c = (i * 64 + lane) * 4;
     v[i] = (c < H) ? load4(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  ln_row_finish<TOut>(v, H, lane, gamma, beta, eps, out + (size_t)row * ldo);
+  ln_row_finish(v, H, lane, gamma, beta, eps, RowStorePlain<TOut>{out + (size_t)row * ldo});
 }
 
-template <typename TOut>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
-                                                       const float* __restrict__ word, const float* __restrict__ ptab,
-                                                       const float* __restrict__ type0, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, TOut* __restrict__ out, int ldo,
-                                                       int rows, int H) {
+__global__ __launch_bounds__(256) void rows_layernorm_split_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps, float* __restrict__ o32,
+                                                                   f16_t* __restrict__ o16, unsigned char* __restrict__ o8, int ldo,
+                                                                   int rows, int H) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  f32x4_t v[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = (c < H) ? load4(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  ln_row_finish(v, H, lane, gamma, beta, eps,
+                RowStoreSplit{o32 + (size_t)row * ldo, o16 + (size_t)row * ldo, o8 + (size_t)row * 2 * ldo, H});
+}
+
+template <typename Store>
+__device__ __forceinline__ void embed_ln_row(const int* __restrict__ ids, const int* __restrict__ pos, const float* __restrict__ word,
+                                             const float* __restrict__ ptab, const float* __restrict__ type0,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int row, int H,
+                                             int lane, const Store& out) {
   const size_t wi = (size_t)ids[row] * H, pi = (size_t)pos[row] * H;
   f32x4_t v[MAXG];
 #pragma unroll
@@ -92,7 +123,32 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
       v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  ln_row_finish<TOut>(v, H, lane, gamma, beta, eps, out + (size_t)row * ldo);
+  ln_row_finish(v, H, lane, gamma, beta, eps, out);
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
+                                                       const float* __restrict__ word, const float* __restrict__ ptab,
+                                                       const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, TOut* __restrict__ out, int ldo,
+                                                       int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  embed_ln_row(ids, pos, word, ptab, type0, gamma, beta, eps, row, H, lane, RowStorePlain<TOut>{out + (size_t)row * ldo});
+}
+
+__global__ __launch_bounds__(256) void embed_ln_split_kernel(const int* __restrict__ ids, const int* __restrict__ pos,
+                                                             const float* __restrict__ word, const float* __restrict__ ptab,
+                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ o32,
+                                                             f16_t* __restrict__ o16, unsigned char* __restrict__ o8, int ldo, int rows,
+                                                             int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  embed_ln_row(ids, pos, word, ptab, type0, gamma, beta, eps, row, H, lane,
+               RowStoreSplit{o32 + (size_t)row * ldo, o16 + (size_t)row * ldo, o8 + (size_t)row * 2 * ldo, H});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -110,12 +166,13 @@ struct KVRow {
   static constexpr int kStride = 64 * (int)sizeof(T) + 16;   // bytes
 };
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ ctx, int ldc, int H,
                                                          const int* __restrict__ bq0, const int* __restrict__ bq1,
                                                          const int* __restrict__ bk0, const int* __restrict__ bk1,
                                                          const int* __restrict__ tok_lo, const int* __restrict__ tok_hi,
-                                                         const float* __restrict__ key_bias) {
+                                                         const float* __restrict__ key_bias, f16_t* __restrict__ ctx16 = nullptr,
+                                                         unsigned char* __restrict__ ctx8 = nullptr) {
   constexpr int RS = KVRow<T>::kStride;
   __shared__ __attribute__((aligned(16))) char Ks[64 * RS];
   __shared__ __attribute__((aligned(16))) char Vs[64 * RS];
@@ -188,7 +245,10 @@ __global__ __launch_bounds__(64) void attn_varlen_kernel(const T* __restrict__ q
 #pragma unroll
     for (int d = 0; d < 64; d += 4) {
       const f32x4_t o = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
-      store4(op + d, o);
+      if (SPLIT)       // RUART_DT_F16C: the context rows only feed the attention-output GEMM (f16 row + the two e4m3 halves)
+        store_split4(ctx16 + (size_t)t * ldc + h * 64 + d, ctx8 + (size_t)t * 2 * ldc + h * 64 + d, H, o);
+      else
+        store4(op + d, o);
     }
   }
 }
@@ -588,6 +648,35 @@ extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma,
     hipLaunchKernelGGL(rows_layernorm_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (f16_t*)out, ldo, rows, H);
   else
     hipLaunchKernelGGL(rows_layernorm_kernel<float>, grid, block, 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, (float*)out, ldo, rows, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_rows_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out32,
+                                          void* out16, void* out8, int ldo, int rows, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldx & 3) || (ldo & 3) || !out32 || !out16 || !out8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(rows_layernorm_split_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, out32,
+                     (f16_t*)out16, (unsigned char*)out8, ldo, rows, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_embed_ln_split(const int* ids, const int* pos, const float* word_emb, const float* pos_emb, const float* type_emb,
+                                         const float* gamma, const float* beta, float eps, float* out32, void* out16, void* out8, int ldo,
+                                         int rows, int H, void* stream) {
+  if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldo & 3) || !out32 || !out16 || !out8) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_ln_split_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb,
+                     gamma, beta, eps, out32, (f16_t*)out16, (unsigned char*)out8, ldo, rows, H);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8, int ldc, int H, int n_heads, int n_blocks,
+                                          const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
+                                          const int* tok_hi, const float* key_bias, void* stream) {
+  if (n_heads * 64 != H || n_blocks <= 0 || !ctx16 || !ctx8 || (ldc & 3)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr, ldc,
+                     H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -105,3 +105,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
 }
+
+// ---- "f16 + fp8 correction" storage (RUART_DT_F16C): a value v travels as  hi = f16(v)  plus two e4m3 bytes
+//   lo8 = fp8((v - hi) * 2^SA_LO)   and   hi8 = fp8(v * 2^SA_HI)
+// so that a GEMM can take  v.w  as  hi.w_hi (f16 MFMA)  +  2^-20 (lo8.w_hi8 + hi8.w_lo8) (block-scaled fp8 MFMA, twice the
+// f16 rate), with w_hi8 = fp8(w_hi * 2^SW_HI), w_lo8 = fp8((w - w_hi) * 2^SW_LO) prepared once per weight matrix.
+// Exponents: SA_LO + SW_HI == SA_HI + SW_LO == RUART_C8_SHIFT.  Ranges: |v| < 112 and |w| < 3.5 stay below e4m3's 448 (larger
+// values saturate - in a correction term only); the f16 rounding residual of |v| >= 2^-8 stays a normal e4m3 number.
+#define RUART_C8_SA_LO 13
+#define RUART_C8_SA_HI 2
+#define RUART_C8_SW_HI 7
+#define RUART_C8_SW_LO 18
+#define RUART_C8_SHIFT 20
+
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4_t v, float scale) {
+  f32x4_t s;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_fmed3f(v[r] * scale, -448.0f, 448.0f);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], w, true);
+  return (unsigned)w;
+}
+// store 4 consecutive values in the split form: p16 -> f16 row, p8 -> the row's lo8 bytes, p8 + hi_off -> its hi8 bytes
+__device__ __forceinline__ void store_split4(f16_t* p16, unsigned char* p8, int hi_off, f32x4_t v) {
+  const f16x4_t h = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+  *reinterpret_cast<f16x4_t*>(p16) = h;
+  const f32x4_t lo = {v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]};
+  *reinterpret_cast<unsigned*>(p8) = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
+  *reinterpret_cast<unsigned*>(p8 + hi_off) = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
+}

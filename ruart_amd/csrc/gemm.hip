@@ -22,15 +22,13 @@
 #include "common.h"
 #include <type_traits>
 #include "ruart_hip.h"
+#include "gemm_shared.h"
 
 #define BM 128
 #define BN 128
 #define BK 64
 
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// byte offset of 16-byte chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile
-__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
 // erf for the 16-bit epilogue: Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 - far below the half-ulp of an f16/bf16
 // output (>= 2.4e-4 relative) - at a third of erff's instruction count (the GELU epilogue runs on 3072-wide rows).
@@ -46,36 +44,6 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)); }
-
-// GELU for the 16-bit epilogues:  gelu(x) = x * Phi(x) = x / (1 + exp(-x q(x^2))),  x q(x^2) = logit(Phi(x)), q = degree-4
-// polynomial in x^2 fitted (weighted minimax, tools/fit_gelu.py) on |x| <= 7.  q stays positive and grows beyond the fitted
-// range, so the logistic saturates to exactly 0 / 1 for large |x| (and through inf) without a clamp.  Max abs error 3.4e-6 in
-// fp32 evaluation - at or below the half-ulp of an f16 output wherever |gelu| > 0.01, 70x below it at |gelu| ~ 0.5.
-// The epilogue is VALU-issue bound (PMC + instruction count: ~12 lane-passes per element here vs ~19 for the A&S erf form; the
-// packed v_pk_*_f32 forms take two passes, so they save instructions, not cycles).  Coefficients carry the -log2(e) of the exp2.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t gelu_pk(f32x2_t x) {
-  const f32x2_t x2 = x * x;
-  f32x2_t p = x2 * -3.228988589e-06f + 8.823813550e-05f;
-  p = p * x2 + 3.602745419e-04f;
-  p = p * x2 + -1.052266881e-01f;
-  p = p * x2 + -2.302045345e+00f;
-  p = p * x;
-  f32x2_t d;
-  d.x = 1.0f + __builtin_amdgcn_exp2f(p.x);
-  d.y = 1.0f + __builtin_amdgcn_exp2f(p.y);
-  f32x2_t r;
-  r.x = __builtin_amdgcn_rcpf(d.x);
-  r.y = __builtin_amdgcn_rcpf(d.y);
-  return x * r;
-}
-__device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
-  const f32x2_t lo = gelu_pk((f32x2_t){v[0], v[1]}), hi = gelu_pk((f32x2_t){v[2], v[3]});
-  return (f32x4_t){lo.x, lo.y, hi.x, hi.y};
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T16, bool OUT_F32, int RES /*0 none, 1 same 16-bit type, 2 f32*/, int ACT /*0 none 1 gelu*/>
 __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A, int lda,
@@ -324,13 +292,6 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 //    prefetch issue, so each SIMD's matrix pipe alternates between its two resident waves instead of idling while both read.
 // Needs K % 128 == 0 (even number of K-tiles), M % 256 == 0, N % 256 == 0.
 // ------------------------------------------------------------------------------------------------
-#define RUART_BAR()                          \
-  do {                                       \
-    asm volatile("" ::: "memory");           \
-    __builtin_amdgcn_s_barrier();            \
-    asm volatile("" ::: "memory");           \
-  } while (0)
-
 template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
@@ -689,6 +650,19 @@ extern "C" int ruart_prof_enable(int on) {
   return 0;
 }
 
+// shared with gemm_corr.hip: bracket one launch of an encoder GEMM (NULL when profiling is off)
+void* ruart_prof_begin_(hipStream_t s, int M, int N, int K) {
+  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return nullptr;
+  ProfRec* rec = &g_prof_pool[g_prof_used++];
+  const int rows = (ruart_prof_real_rows > 0 && ruart_prof_real_rows <= M) ? ruart_prof_real_rows : M;
+  rec->flops = 2.0 * rows * (double)N * K;
+  hipEventRecord(rec->a, s);
+  return rec;
+}
+void ruart_prof_end_(void* rec, hipStream_t s) {
+  if (rec) hipEventRecord(((ProfRec*)rec)->b, s);
+}
+
 extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* flops) {
   double ms = 0.0, fl = 0.0;
   for (size_t i = 0; i < g_prof_used; ++i) {
@@ -768,19 +742,13 @@ extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, 
   if (residual && residual_dtype != RUART_DT_F32 && residual_dtype != in_dtype) return (int)hipErrorInvalidValue;
   const int res = residual ? (residual_dtype == RUART_DT_F32 ? 2 : 1) : 0;
   const bool of = out_dtype == RUART_DT_F32;
-  ProfRec* rec = nullptr;
-  if (g_prof_on && g_prof_used < g_prof_pool.size()) {
-    rec = &g_prof_pool[g_prof_used++];
-    const int rows = (ruart_prof_real_rows > 0 && ruart_prof_real_rows <= M) ? ruart_prof_real_rows : M;
-    rec->flops = 2.0 * rows * (double)N * K;
-    hipEventRecord(rec->a, (hipStream_t)stream);
-  }
+  void* rec = ruart_prof_begin_((hipStream_t)stream, M, N, K);
   int rc;
   if (in_dtype == RUART_DT_BF16)
     rc = launch_gemm16<bf16_t>(A, lda, W, ldw, bias, residual, ldr, res, C, ldc, of, M, N, K, act, (hipStream_t)stream);
   else
     rc = launch_gemm16<f16_t>(A, lda, W, ldw, bias, residual, ldr, res, C, ldc, of, M, N, K, act, (hipStream_t)stream);
-  if (rec) hipEventRecord(rec->b, (hipStream_t)stream);
+  ruart_prof_end_(rec, (hipStream_t)stream);
   return rc;
 }
 

@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libruart_hip.so")
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 TORCH_DTYPE = {DT_F32: torch.float32, DT_BF16: torch.bfloat16, DT_F16: torch.float16}
-PRECISION = {"fp32": DT_F32, "bf16": DT_BF16, "fp16": DT_F16, "x3": DT_F32}     # x3: fp32 storage, split-bf16 MFMA products
+# storage type of the encoder's layer outputs per precision mode.  x3: fp32 storage, split-bf16 MFMA products; fp16c: fp32 residual
+# stream / layer outputs, GEMM operands as f16 + two e4m3 bytes (f16 MFMA + block-scaled fp8 correction, csrc/gemm_corr.hip)
+PRECISION = {"fp32": DT_F32, "bf16": DT_BF16, "fp16": DT_F16, "x3": DT_F32, "fp16c": DT_F32}
 
 
 class BertModelC(Structure):
@@ -29,7 +31,8 @@ class BertModelC(Structure):
                 ("ln1_g", POINTER(c_void_p)), ("ln1_b", POINTER(c_void_p)),
                 ("w_ff1", POINTER(c_void_p)), ("b_ff1", POINTER(c_void_p)),
                 ("w_ff2", POINTER(c_void_p)), ("b_ff2", POINTER(c_void_p)),
-                ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p)), ("f32_gemm", c_int)]
+                ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p)), ("f32_gemm", c_int), ("corr8", c_int),
+                ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p))]
 
 
 class BertBatchC(Structure):
@@ -43,6 +46,10 @@ _P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
 _SIGNATURES = {
     "ruart_version": (c_char_p, []),
     "ruart_gemm_16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16c_nt": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_embed_ln_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_attention_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ruart_gemm_f32_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
@@ -119,8 +126,10 @@ def check(rc, what):
         raise HipError("%s failed with hipError_t %d" % (what, rc))
 
 
-def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """The current stream of ``device`` (a tensor's device), not of whichever device happens to be current: a rank whose GPU is
+    not the current device must not launch on device 0's stream with pointers into its own memory."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):

@@ -68,6 +68,72 @@ def test_gemm_16(M, N, K, mode, dt):
     assert maxerr(C.float(), ref) < tol * max(1.0, float(ref.abs().max()) / 4)
 
 
+def _w8(W):
+    hi = W.to(torch.float16).float()
+    pair = torch.cat([hi * 128.0, (W - hi) * float(1 << 18)], 1).clamp_(-448.0, 448.0)
+    return W.to(torch.float16).contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (256, 768, 3072), (256, 2304, 768)])
+@pytest.mark.parametrize("mode", ["plain", "res", "gelu"])
+def test_gemm_16c_fp8_correction(M, N, K, mode):
+    """ruart_gemm_16c_nt: f16 MFMA product + block-scaled fp8 correction of both operands' rounding residuals, against an fp64
+    product of the UNROUNDED fp32 operands.  The plain f16 kernel on the same data is measured beside it: the corrected product
+    must be >= 8x closer (it is ~2^-16 against ~2^-12 relative)."""
+    from ruart_amd.bert import split_f16c
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + len(mode))
+    A = torch.randn(M, K, generator=g) * (1.0 + 3.0 * (torch.rand(M, 1, generator=g) > 0.9))      # some rows of larger magnitude
+    if mode == "plain":
+        A[0, :8] = torch.tensor([0.0, 1e-6, -1e-4, 90.0, -111.0, 3e-3, 1.0, -1.0])                    # range edges of the fp8 halves
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A.double() @ W.double().t() + bias.double()
+    A16, A8 = split_f16c(A)
+    W16, W8 = _w8(W)
+    A16d, A8d, W16d, W8d, bd = A16.to(d), A8.to(d), W16.to(d), W8.to(d), bias.to(d)
+    res = Rd = None
+    act = hip.ACT_NONE
+    C8 = None
+    if mode == "res":
+        res = torch.randn(M, N, generator=g)
+        Rd = res.to(d)
+        ref = ref + res.double()
+    if mode == "gelu":
+        act = hip.ACT_GELU
+        ref = O.gelu_erf(ref)
+        C = torch.zeros(M, N, dtype=torch.float16, device=d)
+        C8 = torch.zeros(M, 2 * N, dtype=torch.uint8, device=d)
+    else:
+        C = torch.zeros(M, N, dtype=torch.float32, device=d)
+    rc = lib.ruart_gemm_16c_nt(hip.ptr(A16d), hip.ptr(A8d), K, hip.ptr(W16d), hip.ptr(W8d), K, hip.ptr(bd), hip.ptr(Rd), N, hip.ptr(C), N,
+                               hip.ptr(C8), M, N, K, act, hip.stream_ptr())
+    assert rc == 0
+    # the plain f16 product of the same (rounded) operands
+    P = torch.zeros(M, N, dtype=torch.float32, device=d)
+    rc = lib.ruart_gemm_16_nt(hip.ptr(A16d), K, hip.ptr(W16d), K, hip.ptr(bd), hip.ptr(Rd), N, hip.DT_F32, hip.ptr(P), N, hip.DT_F32, M, N, K,
+                              hip.ACT_NONE, hip.DT_F16, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    scale = float(ref.abs().mean())
+    if mode == "gelu":
+        lo8 = C8[:, :N].view(torch.float8_e4m3fn).float().cpu() / float(1 << 13)
+        hi8 = C8[:, N:].view(torch.float8_e4m3fn).float().cpu() / 4.0
+        got = C.float().cpu() + lo8
+        err = float((got.double() - ref).abs().max())
+        print("gelu split out: max err %.2e (mean |ref| %.2e); f16 part alone %.2e" % (err, scale, maxerr(C.float(), ref)))
+        assert err < 3e-5 * max(1.0, float(ref.abs().max()))
+        assert float((hi8.double() - ref).abs().max()) < 0.07 * float(ref.abs().max()) + 2e-3      # e4m3: 3 mantissa bits
+        return
+    err_c, err_p = maxerr(C, ref), maxerr(P, ref)
+    rms_c = float((C.double().cpu() - ref).pow(2).mean().sqrt())
+    rms_p = float((P.double().cpu() - ref).pow(2).mean().sqrt())
+    print("K=%d %s: corrected max %.2e rms %.2e | plain f16 max %.2e rms %.2e | mean |ref| %.2e" % (K, mode, err_c, rms_c, err_p, rms_p, scale))
+    assert rms_c < rms_p / 8 and err_c < err_p / 4
+    assert rms_c < 2e-5 * scale * max(1.0, (K / 768) ** 0.5)
+
+
 def test_gemm_16_rejects_bad_shapes():
     lib = hip.load()
     d = dev()
