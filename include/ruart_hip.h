@@ -235,13 +235,15 @@ int ruart_phoc_table(const unsigned char* chars, const int* offsets, int n_words
  * tensors in three launches.  `grads` / `params` / `exp_avg` / `exp_inf` are DEVICE arrays of device pointers (one per tensor);
  * the work list is cut into chunks of <= 8192 elements: chunk c covers elements [c_start[c], c_start[c] + c_count[c]) of tensor
  * c_tensor[c] (c_start multiples of 4).
- *   ruart_grad_norm_clip: partial (n_chunks floats, scratch); norm_coef[0] = total 2-norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6)).
+ *   ruart_grad_norm_clip: partial (n_chunks floats, scratch); norm_coef[0] = total 2-norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6));
+ *                         extra_sq (device float, may be NULL) is added to the sum of squares before the root - the squared norm of
+ *                         gradients the chunk list leaves out (data parallelism: the re-pinned embedding rows, which are not exchanged).
  *   ruart_adamax_step:    g' = g * norm_coef[1] (norm_coef NULL: no clipping);  m += (1 - beta1)(g' - m);  u = max(beta2 u, |g'| + eps);
  *                         p -= clr[t] * m / u  with clr[t] = lr / (1 - beta1^step_t), one DEVICE float per tensor (torch.optim.Adamax
  *                         counts the steps of every parameter separately).
  * The update's chunk list may leave out elements (embedding rows the trainer re-pins every step): they are not touched. */
 int ruart_grad_norm_clip(const float* const* grads, const int* c_tensor, const int* c_start, const int* c_count, int n_chunks,
-                         float max_norm, float* partial, float* norm_coef, void* stream);
+                         float max_norm, float* partial, float* norm_coef, const float* extra_sq, void* stream);
 int ruart_adamax_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_inf, const int* c_tensor,
                       const int* c_start, const int* c_count, int n_chunks, const float* norm_coef, const float* clr, float beta1,
                       float beta2, float eps, void* stream);

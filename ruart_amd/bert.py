@@ -134,8 +134,13 @@ class PackedTokens:
     ``pack=True`` keeps only mask==1 positions; ``pack=False`` keeps every position and turns the mask into the
     reference's additive -10000 key bias (exact reference semantics for arbitrary masks)."""
 
-    def __init__(self, groups, device=None, pack=True, mfma_long=True):
-        """Host part (numpy only; picklable, so it can run in DataLoader workers) + ``bind(device)`` when a device is given."""
+    def __init__(self, groups, device=None, pack=True, mfma_long=True, window=512, max_positions=None):
+        """Host part (numpy only; picklable, so it can run in DataLoader workers) + ``bind(device)`` when a device is given.
+        ``window``: the reference cuts a row longer than 512 word pieces into independent 512-windows, each encoded as its own
+        sequence with positions restarting at 0, and concatenates the outputs (Models/Bert/Bert.py:18, 96-99, 133-138): here
+        every (row, window) with at least one kept piece is a sequence of the packed stream; a row's pieces stay contiguous, so
+        a word whose pieces straddle a window boundary still pools over one contiguous span.  ``max_positions``: size of the
+        position table (checked, instead of reading past its end on the device)."""
         ids_l, pos_l, len_l, bias_l = [], [], [], []
         self.group_index = []            # per group: (N, L) int32 packed index of each kept position, -1 if dropped
         base = 0
@@ -143,16 +148,26 @@ class PackedTokens:
             ids = _np(ids).astype(np.int64)
             mask = _np(mask).astype(bool)
             N, L = ids.shape
+            if max_positions is not None and min(L, window) > max_positions:
+                raise ValueError("BERT input rows of %d word pieces need %d position embeddings, the checkpoint has %d"
+                                 % (L, min(L, window), max_positions))
             keep = mask if pack else np.ones_like(mask)
-            lens = keep.sum(1).astype(np.int64)
-            if (lens == 0).any():
+            if (keep.sum(1) == 0).any():
                 raise ValueError("a BERT input row has no attendable token")
+            nw = (L + window - 1) // window
+            if nw == 1:
+                lens = keep.sum(1).astype(np.int64)
+            else:                        # (row, window) sequences in row-major order, empty windows dropped
+                padded = np.zeros((N, nw * window), dtype=bool)
+                padded[:, :L] = keep
+                lens = padded.reshape(N, nw, window).sum(2).reshape(-1).astype(np.int64)
+                lens = lens[lens > 0]
             flat = keep.reshape(-1)
             idx = np.full(N * L, -1, dtype=np.int64)
             idx[flat] = base + np.arange(int(flat.sum()))
             self.group_index.append(idx.reshape(N, L))
             ids_l.append(ids.reshape(-1)[flat])
-            pos_l.append(np.broadcast_to(np.arange(L), (N, L)).reshape(-1)[flat])
+            pos_l.append(np.broadcast_to(np.arange(L) % window, (N, L)).reshape(-1)[flat])
             len_l.append(lens)
             if not pack:
                 bias_l.append(np.where(mask.reshape(-1), 0.0, -10000.0).astype(np.float32))
@@ -176,6 +191,7 @@ class PackedTokens:
         self.T, self.Tp, self.n_blocks, self.n_long_blocks = T, Tp, nb, nlb
         self.n_seq = len(lens)
         self.max_len = int(lens.max())
+        self.max_pos = int(host[Tp:Tp + T].max()) + 1 if T else 0      # position-table rows this stream reads
         self.sum_len_sq = float((lens.astype(np.float64) ** 2).sum())
         self.host = host
         self.bias_host = np.concatenate(bias_l) if not pack else None
@@ -273,6 +289,9 @@ def bert_encode(weights, packed, buffers=None):
     """Run the encoder; returns all layer outputs as one (n_layers, Tp, H) tensor in the weights' dtype.
     The tensor aliases a reusable buffer: consume it before the next call."""
     lib = hip.load()
+    if getattr(packed, "max_pos", 0) > weights.cfg["max_position_embeddings"]:
+        raise ValueError("the packed stream addresses %d position embeddings, the checkpoint has %d"
+                         % (packed.max_pos, weights.cfg["max_position_embeddings"]))
     buffers = buffers or _buffers
     layers, ws, ws_bytes = buffers.get(weights, packed.Tp)
     rc = lib.ruart_bert_forward(ctypes.byref(weights.c_model), ctypes.byref(packed.c_batch), hip.ptr(layers), hip.ptr(ws),
@@ -449,7 +468,8 @@ class Bert(nn.Module):
 
     # -- fused path used by ruart_amd.SDNet -------------------------------------------------------------
     def encode(self, groups):
-        packed = PackedTokens(groups, self._device, pack=self.pack, mfma_long=self.weights.dtype != hip.DT_F32)
+        packed = PackedTokens(groups, self._device, pack=self.pack, mfma_long=self.weights.dtype != hip.DT_F32,
+                              max_positions=self.weights.cfg["max_position_embeddings"])
         if getattr(self, "bert_model", None) is not None:
             return packed, self.bert_model(packed, training=self.training)
         return packed, bert_encode(self.weights, packed)
@@ -470,6 +490,18 @@ class Bert(nn.Module):
 
     # -- reference-compatible call: list of per-layer pooled tensors (Bert.py:56-90, 130-176) -------------
     def forward(self, x_bert, x_bert_mask, x_bert_offset, x_mask, device=None):
+        """List of ``bert_layer`` pooled tensors (N, Lw, H), as the reference returns under BERT_LINEAR_COMBINE.  Rows longer than
+        512 pieces are windowed (PackedTokens); ``opt['BERT_MAX_BatchSize']`` splits the rows into chunks that are encoded one after
+        the other and concatenated (Bert.py:65-85) - result-neutral, it only bounds the size of one pass."""
+        bs = self.opt.get("BERT_MAX_BatchSize")
+        N = x_bert.shape[0]
+        if bs and N > bs:
+            parts = []
+            for st in range(0, N, int(bs)):
+                ed = min(st + int(bs), N)
+                off = x_bert_offset[st:ed] if x_bert_offset is not None else None
+                parts.append(self.forward(x_bert[st:ed], x_bert_mask[st:ed], off, x_mask[st:ed], device=device))
+            return [torch.cat([p[i] for p in parts], 0) for i in range(len(parts[0]))]
         packed, layers = self.encode([(x_bert, x_bert_mask)])
         outs = []
         eye = torch.eye(self.weights.n_layers, device=self._device)

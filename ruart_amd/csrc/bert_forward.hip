@@ -102,6 +102,7 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
 
 extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  RUART_ENTRY();
   const int H = m->hidden, I = m->intermediate, R = b->n_rows, dt = m->dtype;
   if (R % 128 || b->n_tokens > R || b->n_tokens <= 0 || H % 64 || m->n_heads * 64 != H) return (int)hipErrorInvalidValue;
   if (dt != RUART_DT_F32 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;

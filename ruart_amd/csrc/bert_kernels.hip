@@ -640,6 +640,7 @@ __global__ void cast_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, 
 // ---------------------------------------------------------------------------------------------
 extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
                                     int out_dtype, int rows, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldx & 3) || (ldo & 3)) return (int)hipErrorInvalidValue;
   const dim3 grid(ceil_div(rows, 4)), block(256);
   if (out_dtype == RUART_DT_BF16)
@@ -654,6 +655,7 @@ extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma,
 
 extern "C" int ruart_rows_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out32,
                                           void* out16, void* out8, int ldo, int rows, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldx & 3) || (ldo & 3) || !out32 || !out16 || !out8) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(rows_layernorm_split_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, eps, out32,
                      (f16_t*)out16, (unsigned char*)out8, ldo, rows, H);
@@ -664,6 +666,7 @@ extern "C" int ruart_rows_layernorm_split(const float* x, int ldx, const float* 
 extern "C" int ruart_bert_embed_ln_split(const int* ids, const int* pos, const float* word_emb, const float* pos_emb, const float* type_emb,
                                          const float* gamma, const float* beta, float eps, float* out32, void* out16, void* out8, int ldo,
                                          int rows, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldo & 3) || !out32 || !out16 || !out8) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_ln_split_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids, pos, word_emb, pos_emb, type_emb,
                      gamma, beta, eps, out32, (f16_t*)out16, (unsigned char*)out8, ldo, rows, H);
@@ -674,6 +677,7 @@ extern "C" int ruart_bert_embed_ln_split(const int* ids, const int* pos, const f
 extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8, int ldc, int H, int n_heads, int n_blocks,
                                           const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
                                           const int* tok_hi, const float* key_bias, void* stream) {
+  RUART_ENTRY();
   if (n_heads * 64 != H || n_blocks <= 0 || !ctx16 || !ctx8 || (ldc & 3)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr, ldc,
                      H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
@@ -684,6 +688,7 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
 extern "C" int ruart_bert_embed_ln(const int* ids, const int* pos, const float* word_emb, const float* pos_emb,
                                    const float* type_emb, const float* gamma, const float* beta, float eps, void* out, int ldo,
                                    int out_dtype, int rows, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || rows <= 0 || (ldo & 3)) return (int)hipErrorInvalidValue;
   const dim3 grid(ceil_div(rows, 4)), block(256);
   if (out_dtype == RUART_DT_BF16)
@@ -700,6 +705,7 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
                                     const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1,
                                     const int* tok_lo, const int* tok_hi, const float* key_bias, int n_long_blocks,
                                     const int* lblk_q0, const int* lblk_q1, const int* lblk_k0, const int* lblk_k1, void* stream) {
+  RUART_ENTRY();
   if (n_heads * 64 != H || n_blocks < 0 || n_long_blocks < 0 || n_blocks + n_long_blocks <= 0) return (int)hipErrorInvalidValue;
   if (n_long_blocks > 0 && dtype == RUART_DT_F32) return (int)hipErrorInvalidValue;   // the MFMA kernel is 16-bit only
   hipStream_t st = (hipStream_t)stream;
@@ -734,6 +740,7 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
 extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
                                    const int* span_start, const int* span_len, const int* dst_row, const float* layer_w,
                                    float* out, int ldo, int n_words, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
   const dim3 grid(ceil_div(n_words, 4)), block(256);
   if (dtype == RUART_DT_BF16)
@@ -749,6 +756,7 @@ extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, i
 extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
                                        const int* span_start, const int* span_len, const int* dst_row, const float* grad_out,
                                        int ldg, float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream) {
+  RUART_ENTRY();
   if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
   const int nb = ceil_div(n_words, 4);
   const dim3 grid(nb), block(256);
@@ -765,6 +773,7 @@ extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_strid
 }
 
 extern "C" int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n, float scale, void* stream) {
+  RUART_ENTRY();
   if (n % 4 || (out_dtype != RUART_DT_BF16 && out_dtype != RUART_DT_F16)) return (int)hipErrorInvalidValue;
   const size_t n4 = (size_t)n / 4;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);

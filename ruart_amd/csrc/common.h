@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define RUART_DT_BF16 1
 #define RUART_DT_F16 2
 
+// hipGetLastError() is per-thread and sticky across libraries: RCCL / torch probe pointers and events in ways that leave
+// hipErrorInvalidValue behind.  Every entry point clears the slot first, so RUART_CHECK_LAUNCH reports only its own launches.
+#define RUART_ENTRY() (void)hipGetLastError()
+
 #define RUART_CHECK_LAUNCH() \
   do {                       \
     hipError_t e_ = hipGetLastError(); \

@@ -621,24 +621,28 @@ bool g_prof_on = false;
 }  // namespace
 #ifdef RUART_P8_STAMPS
 unsigned long long* g_p8_stamps = nullptr;   // diagnostic build only: 4 x s_memrealtime per workgroup
-extern "C" int ruart_gemm_set_stamps(unsigned long long* p) { g_p8_stamps = p; return 0; }
+extern "C" int ruart_gemm_set_stamps(unsigned long long* p) {
+  RUART_ENTRY(); g_p8_stamps = p; return 0; }
 #endif
 int g_tile_order = 8;            // GROUP_M of the tile walk (0 = plain row-major); tuning knob, see ruart_gemm_set_tile_order
 int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
 
 extern int g_gemm_variant;
 extern "C" int ruart_gemm_set_tile_order(int group_m) {
+  RUART_ENTRY();
   if (group_m < 0 || group_m > 64) return (int)hipErrorInvalidValue;
   g_tile_order = group_m;
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {
+  RUART_ENTRY();
   if (v != 0 && v != 3 && v != 5) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
 
 extern "C" int ruart_prof_enable(int on) {
+  RUART_ENTRY();
   if (on && g_prof_pool.empty()) {
     g_prof_pool.resize(8192);
     for (auto& r : g_prof_pool) {
@@ -664,6 +668,7 @@ void ruart_prof_end_(void* rec, hipStream_t s) {
 }
 
 extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* flops) {
+  RUART_ENTRY();
   double ms = 0.0, fl = 0.0;
   for (size_t i = 0; i < g_prof_used; ++i) {
     float t = 0.f;
@@ -735,6 +740,7 @@ static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const f
 extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
                                 int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
                                 void* stream) {
+  RUART_ENTRY();
   if (M % BM || N % BN || K % BK || (lda & 7) || (ldw & 7) || (ldc & 3)) return (int)hipErrorInvalidValue;
   if (act != RUART_ACT_NONE && act != RUART_ACT_GELU) return (int)hipErrorInvalidValue;
   if (in_dtype != RUART_DT_BF16 && in_dtype != RUART_DT_F16) return (int)hipErrorInvalidValue;
@@ -754,6 +760,7 @@ extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, 
 
 extern "C" int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,
                                  int ldr, float* C, int ldc, int M, int N, int K, int act, void* stream) {
+  RUART_ENTRY();
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ceil_div(M, FBM) * ceil_div(N, FBN)), block(256);

@@ -274,6 +274,7 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
 extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                                  const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act,
                                  void* stream) {
+  RUART_ENTRY();
   if (M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
   if (!A16 || !A8 || !W16 || !W8 || !C) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;

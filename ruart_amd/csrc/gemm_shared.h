@@ -42,3 +42,4 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     asm volatile("" ::: "memory");           \
   } while (0)
 
+

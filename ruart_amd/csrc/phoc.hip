@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void phoc_table_kernel(const unsigned char* __
 
 extern "C" int ruart_phoc_table(const unsigned char* chars, const int* offsets, int n_words, float* out, int ldo, int* status,
                                 void* stream) {
+  RUART_ENTRY();
   if (n_words <= 0 || ldo < kPhocDim || (ldo & 3)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(phoc_table_kernel, dim3(ceil_div(n_words, 4)), dim3(256), 0, (hipStream_t)stream, chars, offsets, n_words, out,
                      ldo, status);

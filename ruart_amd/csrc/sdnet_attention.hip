@@ -526,12 +526,14 @@ __global__ __launch_bounds__(256) void attn1_bwd_kernel(const float* __restrict_
 
 extern "C" int ruart_attn_fwd(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
                               int diag_len, int relu, float* out, float* probs, int B, int L1, int L2, int h, int D3, void* stream) {
+  RUART_ENTRY();
   return ruart_attn_fwd_pscale(a, k, v, mask, diag, diag_len, relu, nullptr, out, probs, B, L1, L2, h, D3, stream);
 }
 
 extern "C" int ruart_attn_fwd_pscale(const float* a, const float* k, const float* v, const unsigned char* mask, const float* diag,
                                      int diag_len, int relu, const float* prob_scale, float* out, float* probs, int B, int L1, int L2,
                                      int h, int D3, void* stream) {
+  RUART_ENTRY();
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
   if (L1 == 1 && !relu && diag_len == 0 && !prob_scale) {              // single-query fast path
@@ -551,6 +553,7 @@ extern "C" int ruart_attn_fwd_pscale(const float* a, const float* k, const float
 extern "C" int ruart_attn_bwd(const float* a, const float* k, const float* v, const float* probs, const float* grad_out,
                               const float* diag, int diag_len, int relu, float* grad_a, float* grad_k, float* grad_v,
                               float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3, void* stream) {
+  RUART_ENTRY();
   return ruart_attn_bwd_pscale(a, k, v, probs, grad_out, diag, diag_len, relu, nullptr, grad_a, grad_k, grad_v, grad_diag, ds_ws, B, L1,
                                L2, h, D3, stream);
 }
@@ -559,6 +562,7 @@ extern "C" int ruart_attn_bwd_pscale(const float* a, const float* k, const float
                                      const float* diag, int diag_len, int relu, const float* prob_scale, float* grad_a, float* grad_k,
                                      float* grad_v, float* grad_diag, float* ds_ws, int B, int L1, int L2, int h, int D3,
                                      void* stream) {
+  RUART_ENTRY();
   if (B <= 0 || L1 <= 0 || L2 <= 0 || L2 > ATTN_MAX_L2 || h <= 0 || D3 <= 0) return (int)hipErrorInvalidValue;
   if (diag_len != 0 && diag_len != 1 && diag_len != h) return (int)hipErrorInvalidValue;
   if (L1 == 1 && !relu && diag_len == 0 && !prob_scale) {              // single-query fast path (ds_ws unused)
@@ -582,6 +586,7 @@ extern "C" int ruart_attn_bwd_pscale(const float* a, const float* k, const float
 }
 
 extern "C" int ruart_whole_ln_fwd(const float* x, float* y, float* stats, float* ws, long long n, float eps, void* stream) {
+  RUART_ENTRY();
   if (n <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(wln_sum_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, x, (const float*)nullptr, n, ws);
@@ -593,6 +598,7 @@ extern "C" int ruart_whole_ln_fwd(const float* x, float* y, float* stats, float*
 
 extern "C" int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, float* grad_x, float* ws, long long n,
                                   void* stream) {
+  RUART_ENTRY();
   if (n <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(wln_sum_kernel, dim3(WLN_BLOCKS), dim3(256), 0, s, grad_y, y, n, ws);
@@ -602,6 +608,7 @@ extern "C" int ruart_whole_ln_bwd(const float* y, const float* grad_y, const flo
 }
 
 extern "C" int ruart_stream_create_cu_masked(int n_cus, void** stream_out) {
+  RUART_ENTRY();
   if (!stream_out) return -1;
   int dev = 0, total = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -2;
@@ -621,10 +628,12 @@ extern "C" int ruart_stream_create_cu_masked(int n_cus, void** stream_out) {
 }
 
 extern "C" int ruart_stream_destroy(void* stream) {
+  RUART_ENTRY();
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;
 }
 
 extern "C" int ruart_set_nan_flag(int* flag) {
+  RUART_ENTRY();
   ruart_nan_flag_ptr = flag;
   return 0;
 }

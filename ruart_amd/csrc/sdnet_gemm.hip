@@ -347,6 +347,7 @@ void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, lon
 }  // namespace
 
 extern "C" int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous, int b_k_contiguous, int* splitk, size_t* ws_bytes) {
+  RUART_ENTRY();
   if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
   const Plan p = make_plan(M, N, K, a_k_contiguous ? 0 : 1, b_k_contiguous ? 0 : 1);
   if (splitk) *splitk = p.splitk;
@@ -401,6 +402,7 @@ extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const
                              const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
                              float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
                              int rows_per_scale_row, void* stream) {
+  RUART_ENTRY();
   return gemm_xn<3>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
                     rows_per_scale_row, stream);
 }
@@ -409,12 +411,14 @@ extern "C" int ruart_gemm_x1(const float* A, long long sam, long long sak, const
                              const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
                              float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
                              int rows_per_scale_row, void* stream) {
+  RUART_ENTRY();
   return gemm_xn<1>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
                     rows_per_scale_row, stream);
 }
 
 extern "C" int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const float* B, long long sbk_rows, float* C, int ldc, int M, int N,
                                   int K, float* ws, size_t ws_bytes, void* stream) {
+  RUART_ENTRY();
   // A stored (K, M): element (m, k) at A[k * sak_rows + m]; B stored (K, N)
   return gemm_xn<1>(A, 1, sak_rows, B, sbk_rows, 1, nullptr, nullptr, 0, RUART_ACT_NONE, C, ldc, M, N, K, ws, ws_bytes, nullptr, nullptr,
                     nullptr, 1, stream);

@@ -218,6 +218,7 @@ extern int* ruart_nan_flag_ptr;
 
 extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, float* hprev, int B, int T,
                               int h, int ndir, void* stream) {
+  RUART_ENTRY();
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells, hprev, T, h, ndir,
                      ruart_nan_flag_ptr);
@@ -227,6 +228,7 @@ extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, f
 
 extern "C" int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const float* gates, const float* cells, float* grad_xproj,
                               int B, int T, int h, int ndir, void* stream) {
+  RUART_ENTRY();
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, grad_y, w_hh, gates, cells, grad_xproj, T, h,
                      ndir);
@@ -236,6 +238,7 @@ extern "C" int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const floa
 
 extern "C" int ruart_lstm_cell_fwd(const float* pre, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
                                    float* acts, int n_active, int n_rows, int h, void* stream) {
+  RUART_ENTRY();
   if (n_rows <= 0 || h <= 0 || n_active < 0 || n_active > n_rows) return (int)hipErrorInvalidValue;
   const long long total = (long long)n_rows * h;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -248,6 +251,7 @@ extern "C" int ruart_lstm_cell_fwd(const float* pre, const float* h_prev, const 
 extern "C" int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* acts, const float* c_prev,
                                    const float* c_out, float* grad_pre, float* grad_h_prev, float* grad_c_prev, int n_active,
                                    int n_rows, int h, void* stream) {
+  RUART_ENTRY();
   if (n_rows <= 0 || h <= 0 || n_active < 0 || n_active > n_rows) return (int)hipErrorInvalidValue;
   const long long total = (long long)n_rows * h;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
 
 extern "C" int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg,
                                           int D, float* grad_weight, void* stream) {
+  RUART_ENTRY();
   if (n_seg < 0 || D <= 0 || D > 4096) return (int)hipErrorInvalidValue;
   if (n_seg == 0) return 0;
   int dpad = 8;

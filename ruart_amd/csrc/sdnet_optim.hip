@@ -32,12 +32,13 @@ __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* cons
 
 // out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
 __global__ __launch_bounds__(256) void gradnorm_final_kernel(const float* __restrict__ partial, int n, float max_norm,
-                                                             float* __restrict__ out) {
+                                                             const float* __restrict__ extra_sq, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
   s = block_sum<4>(s, red);
   if (threadIdx.x == 0) {
+    if (extra_sq) s += extra_sq[0];           // squared norm of gradients that are not in the chunk list (dp.GradSync.pinned_sq)
     const float norm = sqrtf(s);
     out[0] = norm;
     out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));
@@ -85,11 +86,12 @@ __global__ __launch_bounds__(256) void adamax_update_kernel(float* const* __rest
 }
 
 extern "C" int ruart_grad_norm_clip(const float* const* grads, const int* c_tensor, const int* c_start, const int* c_count, int n_chunks,
-                                    float max_norm, float* partial, float* norm_coef, void* stream) {
+                                    float max_norm, float* partial, float* norm_coef, const float* extra_sq, void* stream) {
+  RUART_ENTRY();
   if (n_chunks <= 0 || !grads || !partial || !norm_coef) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, grads, c_tensor, c_start, c_count,
                      partial);
-  hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_chunks, max_norm, norm_coef);
+  hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_chunks, max_norm, extra_sq, norm_coef);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -97,6 +99,7 @@ extern "C" int ruart_grad_norm_clip(const float* const* grads, const int* c_tens
 extern "C" int ruart_adamax_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_inf,
                                  const int* c_tensor, const int* c_start, const int* c_count, int n_chunks, const float* norm_coef,
                                  const float* clr, float beta1, float beta2, float eps, void* stream) {
+  RUART_ENTRY();
   if (n_chunks <= 0 || !clr || !params || !grads || !exp_avg || !exp_inf) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamax_update_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_inf, c_tensor,
                      c_start, c_count, norm_coef, clr, 1.0f - beta1, beta2, eps);

@@ -6,15 +6,25 @@ asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
     norm couples samples only inside a replica, so the semantics are "N reference steps, gradients averaged");
   * only what must move moves: trainable, actually-used parameters.  The dead ``get_answer.rnn.*`` GRU (never gets a
     gradient, Models/Layers.py:395-397) is excluded.  The word-embedding rows >= tune_partial are re-pinned after every
-    step (Models/SDNetTrainer.py:369-373) so their update never survives - but their gradients DO enter the global
-    clipping norm (:366), so by default they are exchanged too (every rank must clip by the same coefficient or the
-    replicas drift).  ``opt['dp_skip_pinned_rows']`` exchanges rows < tune_partial only and zeroes the rest on every
-    rank: ~37 MB fp32 per step instead of 37 MB + 2 * (V - tune_partial) * 300 * 4, at the price of a clip norm
-    that ignores the pinned rows;
+    step (Models/SDNetTrainer.py:369-373) so their update never survives: they are NOT exchanged.  Their gradients do enter
+    the global clipping norm (:366), and every rank must clip by the same coefficient or the replicas drift - so each
+    rank adds the squared norm of its own pinned-row gradients to ONE scalar that rides along with the buckets
+    (``pinned_sq``): the clip norm becomes sqrt(|averaged trained gradients|^2 + sum_r |g_r,pinned|^2 / world^2), which is
+    the exact norm of the averaged gradient whenever the ranks' batches touch different pinned rows (the usual case: each rank's
+    64 questions hit different out-of-head words) and a bound within sqrt(world) of it otherwise.  Payload: ~37 MB
+    fp32 per step instead of 37 MB + 2 * (V - tune_partial) * 300 * 4.  The scalar path needs the fused
+    optimizer (it takes the extra term); with a torch optimizer, or ``opt['dp_exchange_pinned_rows']``, whole tables are exchanged;
+    ``opt['dp_skip_pinned_rows']`` (older switch) exchanges the head rows and zeroes the rest, dropping them from the norm;
   * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
-    win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order and each
-    bucket's all-reduce is launched asynchronously as soon as its last gradient is produced (strictly in bucket order,
-    so all ranks issue identical collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales each bucket by 1/world in one launch and points every parameter's ``.grad`` at its slice of the bucket (no copy back);
+    win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order.  The buckets
+    are allocated once; when the last gradient of a bucket has been produced, ONE multi-tensor copy moves the bucket's
+    gradients into it and its all-reduce is launched asynchronously (strictly in bucket order, so all ranks issue identical
+    collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales each bucket by 1/world in
+    one launch and points every parameter's ``.grad`` at its slice of the bucket (no copy back);
+  * stream order: the trunk runs its question / object / OCR branches on three streams, so the gradients of one bucket are
+    accumulated on different streams, and autograd joins those streams only at the END of backward.  Every hook therefore
+    notes the stream its gradient was accumulated on, and the launching hook's stream waits for all of them (an event recorded at
+    launch time covers every accumulation enqueued before the hook ran) before the copy and the collective;
   * works unchanged on the gloo backend (CPU tensors) - that is how the N>1 path is tested without GPUs.
 """
 import os
@@ -23,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 UNUSED_PREFIXES = ("get_answer.rnn.", "Bert.bert_model.pooler.")     # never reached by a gradient
+EMBED_TABLES = ("fast_embed.weight", "glove_embed.weight")
 
 
 def init_process_group(device, backend="nccl", **kw):
@@ -32,22 +43,31 @@ def init_process_group(device, backend="nccl", **kw):
     one MI355X with a world-size-1 group, 23-24 ms per step against 20.2 with the priority raised (19.9 without DP)."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
+        torch.cuda.set_device(torch.device(device))        # every later launch / stream query of this rank targets ITS device
         kw.setdefault("pg_options", dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
         kw.setdefault("device_id", torch.device(device))
     return dist.init_process_group(backend, **kw)
 
 
 class GradSync:
-    def __init__(self, network, opt, group=None, bucket_bytes=16 << 20):
+    def __init__(self, network, opt, group=None, bucket_bytes=16 << 20, pinned_scalar=False):
+        """``pinned_scalar``: the caller's optimizer takes ``pinned_sq`` (FusedAdamax.clip_and_step(extra_sq=)), so the re-pinned
+        embedding rows are represented by one scalar instead of being exchanged."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.network = network
-        tp = opt.get("tune_partial") if ("TUNE_PARTIAL" in opt and opt.get("dp_skip_pinned_rows")) else None
+        tp = None
+        self.mode = "full"
+        if "TUNE_PARTIAL" in opt and not opt.get("dp_exchange_pinned_rows"):
+            if opt.get("dp_skip_pinned_rows"):
+                tp, self.mode = int(opt["tune_partial"]), "zero"
+            elif pinned_scalar:
+                tp, self.mode = int(opt["tune_partial"]), "scalar"
         entries = []                       # (name, param, rows or None)
         for name, p in network.named_parameters():
             if not p.requires_grad or name.startswith(UNUSED_PREFIXES):
                 continue
-            rows = tp if (tp is not None and name in ("fast_embed.weight", "glove_embed.weight")) else None
+            rows = tp if (tp is not None and name in EMBED_TABLES) else None
             entries.append((name, p, rows))
         entries.reverse()                  # gradients arrive roughly in reverse registration order
         self.buckets = []
@@ -61,25 +81,41 @@ class GradSync:
             cur_bytes += 4 * n
         if cur:
             self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
+        # persistent flat buffers and, per parameter, its slice of them (shaped like the exchanged rows)
+        self._flat, self._slices = [], []
+        for b in self.buckets:
+            sizes = [(p[:r] if r is not None else p).numel() for (_, p, r) in b]
+            flat = torch.zeros(sum(sizes), dtype=b[0][1].dtype, device=b[0][1].device)
+            o, sl = 0, []
+            for (_, p, r), n in zip(b, sizes):
+                sl.append(flat[o:o + n].view_as(p[:r] if r is not None else p))
+                o += n
+            self._flat.append(flat)
+            self._slices.append(sl)
+        self._pinned = [(name, p, r) for b in self.buckets for (name, p, r) in b if r is not None]
+        self.pinned_sq = None              # device scalar: sum over ranks of |g[rows >= tune_partial]|^2 / world^2 ("scalar" mode)
+        self._sq = None
         self._work = [None] * len(self.buckets)
-        self._pending = [0] * len(self.buckets)
         self._bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for (_, p, _) in b:
                 self._bucket_of[p] = bi
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
-        self.payload_bytes = sum(4 * ((p[:r] if r is not None else p).numel()) for b in self.buckets for (_, p, r) in b)
+        self.payload_bytes = sum(f.numel() * 4 for f in self._flat) + (4 if self.mode == "scalar" else 0)
         self._reset()
 
     def _reset(self):
         self._pending = [len(b) for b in self.buckets]
+        self._streams = [set() for _ in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._sq_work = None
         self._next = 0                      # buckets are ALWAYS launched in index order: every rank issues the same
                                             # sequence of collectives even if its gradients become ready in another order
 
     def _make_hook(self, bi):
         def hook(param):
+            if param.is_cuda:               # the stream this gradient was accumulated on (see the module docstring)
+                self._streams[bi].add(torch.cuda.current_stream(param.device))
             self._pending[bi] -= 1
             self._launch_ready()
         return hook
@@ -89,7 +125,7 @@ class GradSync:
             self._launch(self._next)
             self._next += 1
 
-    def _views(self, bi):
+    def _grads(self, bi):
         out = []
         for (_, p, rows) in self.buckets[bi]:
             g = p.grad
@@ -100,10 +136,28 @@ class GradSync:
         return out
 
     def _launch(self, bi):
-        views = self._views(bi)
-        flat = torch.cat([v.reshape(-1) for v in views])
-        self._flat[bi] = flat
+        flat = self._flat[bi]
+        if flat.is_cuda:
+            cur = torch.cuda.current_stream(flat.device)
+            for s in self._streams[bi]:
+                if s != cur:
+                    cur.wait_stream(s)      # everything enqueued on s so far - the accumulations of this bucket included
+        torch._foreach_copy_(self._slices[bi], self._grads(bi))
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.mode == "scalar" and bi == len(self.buckets) - 1:
+            self._launch_pinned_scalar()
+
+    def _launch_pinned_scalar(self):
+        """One scalar for the rows that are never exchanged: this rank's sum of squares of their gradients."""
+        parts = []
+        for (_, p, rows) in self._pinned:
+            g = p.grad
+            if g is not None and g.shape[0] > rows:
+                parts.append(g[rows:].float().pow(2).sum())
+        dev = self._flat[0].device
+        sq = torch.stack(parts).sum().reshape(1) if parts else torch.zeros(1, device=dev)
+        self._sq = sq
+        self._sq_work = dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def average_gradients(self):
         """Call after ``loss.backward()``: finishes the outstanding bucket all-reduces and writes the averaged
@@ -117,16 +171,16 @@ class GradSync:
             flat = self._flat[bi]
             if self.world > 1:
                 flat.mul_(inv)                         # one launch per bucket
-            o = 0
-            for v, (_, p, rows) in zip(self._views(bi), self.buckets[bi]):
-                n = v.numel()
+            for sl, (_, p, rows) in zip(self._slices[bi], self.buckets[bi]):
                 if rows is None:
-                    p.grad = flat[o:o + n].view_as(p)      # the averaged gradient IS the bucket slice: no copy back
+                    p.grad = sl                        # the averaged gradient IS the bucket slice: no copy back
                 else:
-                    v.copy_(flat[o:o + n].view_as(v))
-                    p.grad[rows:].zero_()
-                o += n
-            self._flat[bi] = None
+                    p.grad[:rows].copy_(sl)
+                    if self.mode == "zero":
+                        p.grad[rows:].zero_()
+        if self._sq_work is not None:
+            self._sq_work.wait()
+            self.pinned_sq = self._sq.mul_(inv * inv) if self.world > 1 else self._sq
         self._reset()
 
     def broadcast_parameters(self, src=0):

@@ -70,7 +70,7 @@ _SIGNATURES = {
     "ruart_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),
-    "ruart_grad_norm_clip": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P]),
+    "ruart_grad_norm_clip": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P]),
     "ruart_adamax_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P]),
     "ruart_embedding_bwd_sorted": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "ruart_phoc_table": (_I, [_P, _P, _I, _P, _I, _P, _P]),

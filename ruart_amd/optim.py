@@ -80,9 +80,10 @@ class FusedAdamax:
         self._plan_val["gptr_np"] = [h.numpy() for h in self._plan_val["gptr_host"]]
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)
 
-    def clip_and_step(self, max_norm=None):
+    def clip_and_step(self, max_norm=None, extra_sq=None):
         """clip_grad_norm_(params, max_norm) (skipped when None) followed by step().  The total norm and the clip coefficient
-        stay on the device in ``self.norm_coef``."""
+        stay on the device in ``self.norm_coef``.  ``extra_sq`` (device float tensor): the norm runs over the UPDATED elements only
+        (the re-pinned embedding rows left out) and this squared norm is added in their place - dp.GradSync.pinned_sq."""
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return
@@ -110,9 +111,10 @@ class FusedAdamax:
         self.step_count += 1
         coef = None
         if max_norm is not None:
-            ct, cs, cc, n = pl["norm"]
+            ct, cs, cc, n = pl["norm"] if extra_sq is None else pl["upd"]
             hip.check(lib.ruart_grad_norm_clip(hip.ptr(pl["gptr"]), hip.ptr(ct), hip.ptr(cs), hip.ptr(cc), n, float(max_norm),
-                                               hip.ptr(pl["partial"]), hip.ptr(self.norm_coef), st), "ruart_grad_norm_clip")
+                                               hip.ptr(pl["partial"]), hip.ptr(self.norm_coef), hip.ptr(extra_sq), st),
+                      "ruart_grad_norm_clip")
             coef = self.norm_coef
         ct, cs, cc, n = pl["upd"]
         ptrs = pl["ptrs"]

@@ -123,6 +123,11 @@ class SDNetTrainer(BaseTrainer):
         torch.manual_seed(self.seed)
         self.batch_size = opt["batch_size"]
         self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type == "cuda":
+            # one process drives ONE GPU: make it the current device, so that every stream query, allocation and kernel launch
+            # below (the ctypes-launched HIP kernels take torch's current stream) targets this rank's device
+            torch.cuda.set_device(self.device if self.device.index is not None else torch.cuda.current_device())
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.process_group = process_group
         self.grad_sync = None
         self.fixed_answers_len = 0
@@ -170,7 +175,9 @@ class SDNetTrainer(BaseTrainer):
         if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                               and torch.distributed.get_world_size() > 1):
             from .dp import GradSync
-            self.grad_sync = GradSync(self.network, self.opt, group=self.process_group)
+            # the fused optimizer takes the re-pinned rows' share of the clip norm as one scalar: they are not exchanged
+            self.grad_sync = GradSync(self.network, self.opt, group=self.process_group,
+                                      pinned_scalar=hasattr(self.optimizer, "clip_and_step"))
             self.grad_sync.broadcast_parameters()
 
     def ToCUDA(self, batch):
@@ -224,7 +231,8 @@ class SDNetTrainer(BaseTrainer):
         if self.grad_sync is not None:
             self.grad_sync.average_gradients()
         if hasattr(self.optimizer, "clip_and_step"):       # fused: global-norm clip + Adamax in three launches
-            self.optimizer.clip_and_step(self.opt["grad_clipping"])
+            self.optimizer.clip_and_step(self.opt["grad_clipping"],
+                                         extra_sq=self.grad_sync.pinned_sq if self.grad_sync is not None else None)
         else:
             torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.opt["grad_clipping"])
             self.optimizer.step()

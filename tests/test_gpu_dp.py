@@ -74,7 +74,11 @@ def test_single_rank_nccl_step_equals_plain_step():
             assert n == "ques_merger.linear.bias" and float(gd[n].abs().max()) == 0.0, n
         l0 = [plain.update(plain.ToCUDA(batch), i) for i in range(3)]
         l1 = [dp.update(dp.ToCUDA(batch), i) for i in range(3)]
-        assert l0 == l1, (l0, l1)
+        # the re-pinned embedding rows enter the DP step's clip norm as ONE scalar (dp.GradSync.pinned_sq) instead of chunk by
+        # chunk: the same number up to fp32 summation order, so the losses agree to rounding, not bit for bit
+        assert dp.grad_sync.mode == "scalar" and dp.grad_sync.payload_bytes < 45e6
+        assert np.allclose(l0, l1, rtol=2e-6, atol=0), (l0, l1)
+        assert abs(float(plain.optimizer.norm_coef[0]) - float(dp.optimizer.norm_coef[0])) < 1e-5 * float(plain.optimizer.norm_coef[0])
         t = torch.ones(4, device="cuda:0")
         dist.all_reduce(t)
         dist.barrier()

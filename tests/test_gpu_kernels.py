@@ -250,6 +250,51 @@ def test_bert_long_sequences_and_split_groups(golden_dir, precision, tol):
                 assert err < tol, (precision, pack, gi, l, err)
 
 
+def test_bert_rows_longer_than_512_are_windowed(golden_dir):
+    """``Bert.forward`` on rows of up to 600 word pieces against the oracle's restatement of the reference's 512-windowing
+    (Models/Bert/Bert.py:133-138: independent windows, positions restart), incl. a word whose pieces straddle the boundary and
+    the ``BERT_MAX_BatchSize`` row split (:65-85)."""
+    from ruart_amd.bert import Bert
+    d = dev()
+    cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                            max_position_embeddings=512)
+    w = synth.make_bert_weights(cfg, seed=9, w_std=0.05)
+    g = np.random.default_rng(4)
+    lens = [600, 40, 513]
+    Lb = 600
+    ids = np.zeros((3, Lb), dtype=np.int64)
+    for i, l in enumerate(lens):
+        ids[i, :l] = g.integers(1, 300, size=l)
+    mask = ids != 0
+    # words: spans of 1-3 pieces; row 0 has a word over pieces [510, 514) - across the window boundary
+    offsets, Lw = [], 8
+    offsets.append([[0, 1], [1, 3], [510, 514], [514, 515], [598, 600]])
+    offsets.append([[0, 2], [2, 3], [39, 40]])
+    offsets.append([[511, 513], [0, 1]])
+    wmask = np.zeros((3, Lw), dtype=bool)
+    for i, o in enumerate(offsets):
+        wmask[i, :len(o)] = True
+    from ruart_amd.bert import BertEncoderWeights
+
+    def small_bert(**opt_extra):
+        m = Bert.__new__(Bert)                                               # (the constructor insists on bert-base / -large dims)
+        torch.nn.Module.__init__(m)
+        m._device, m.pack, m.opt = d, True, dict(opt_extra)
+        m.weights = BertEncoderWeights(w, cfg, d, "fp32")
+        return m
+
+    outs = small_bert()(T(ids), T(mask), offsets, T(wmask))
+    bw = {k: T(v) for k, v in w.items()}
+    per_window = [O.bert_forward(bw, cfg, T(ids[:, p0:p0 + 512]), T(mask[:, p0:p0 + 512])) for p0 in range(0, Lb, 512)]
+    ref_layers = [torch.cat([pw[l] for pw in per_window], 1) for l in range(cfg["num_hidden_layers"])]     # the reference's window loop
+    ref = O.pool_subwords(ref_layers, offsets, T(wmask))
+    for l in range(cfg["num_hidden_layers"]):
+        assert outs[l].shape == ref[l].shape and maxerr(outs[l], ref[l]) < 5e-5, l
+    outs2 = small_bert(BERT_MAX_BatchSize=2)(T(ids), T(mask), offsets, T(wmask))
+    for a, b in zip(outs, outs2):
+        assert maxerr(a, b) < 1e-6
+
+
 def test_pool_mix_fwd_bwd():
     from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode, Bert
     cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,

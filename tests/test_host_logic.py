@@ -177,6 +177,30 @@ def test_packed_token_plan_on_cpu():
     assert p2.T == 24 and (p2.key_bias.numpy() == np.where((ids[:3, :8] != 0).reshape(-1), 0, -10000)).all()
 
 
+def test_packed_tokens_window_rows_longer_than_512():
+    """Models/Bert/Bert.py:18, 96-99, 133-138: a row longer than 512 word pieces is encoded as independent 512-windows whose
+    positions restart at 0.  In the packed stream every (row, window) is its own sequence; the row's pieces stay contiguous."""
+    from ruart_amd.bert import PackedTokens
+    g = np.random.default_rng(2)
+    lens = [700, 5, 1100, 512, 513]
+    L = 1100
+    ids = np.zeros((len(lens), L), dtype=np.int64)
+    for i, l in enumerate(lens):
+        ids[i, :l] = g.integers(1, 99, size=l)
+    p = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu", mfma_long=False)
+    want = [512, 188, 5, 512, 512, 76, 512, 512, 1]                      # window lengths in row-major order
+    lo, hi = p.tok_lo.numpy(), p.tok_hi.numpy()
+    starts = np.unique(lo)
+    assert p.n_seq == len(want) and [int(hi[s_] - s_) for s_ in starts] == want
+    assert p.max_pos == 512 and int(p.pos.numpy()[:p.T].max()) == 511
+    # positions restart in every window; the pieces of row 0 sit at packed indices 0..699 in order
+    assert np.array_equal(p.pos.numpy()[:700], np.arange(700) % 512)
+    assert np.array_equal(p.group_index[0][0, :700], np.arange(700)) and p.group_index[0][1, 0] == 700
+    assert np.array_equal(p.ids.numpy()[:p.T], ids[ids != 0])
+    with pytest.raises(ValueError):                                          # a position table that is too small is an error,
+        PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu", max_positions=256)     # not an out-of-bounds read
+
+
 def test_word_spans_follow_reference_pooling_rules():
     from ruart_amd.bert import PackedTokens, word_spans
     ids = np.array([[5, 6, 7, 8, 9, 0, 0], [5, 6, 0, 0, 0, 0, 0]])
