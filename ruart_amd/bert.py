@@ -493,7 +493,7 @@ class Bert(nn.Module):
         """List of ``bert_layer`` pooled tensors (N, Lw, H), as the reference returns under BERT_LINEAR_COMBINE.  Rows longer than
         512 pieces are windowed (PackedTokens); ``opt['BERT_MAX_BatchSize']`` splits the rows into chunks that are encoded one after
         the other and concatenated (Bert.py:65-85) - result-neutral, it only bounds the size of one pass."""
-        bs = self.opt.get("BERT_MAX_BatchSize")
+        bs = getattr(self, "opt", {}).get("BERT_MAX_BatchSize")
         N = x_bert.shape[0]
         if bs and N > bs:
             parts = []

@@ -10,6 +10,7 @@
 //   ruart_bert_pool_mix_bwd  gradient of that mix w.r.t. the per-layer weights (alpha/gamma are trainable)
 //
 // All math is fp32; storage type T of activations is float (validation mode) or bf16.
+#include <stdlib.h>
 #include "common.h"
 #include "ruart_hip.h"
 
@@ -427,6 +428,143 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const T16* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// attn_flash_kernel for the RUART_DT_F16C mode: fp32 [Q | K | V] rows in, context rows out in the split form (f16 + two e4m3
+// halves, common.h).  Same structure - windows of whole short sequences or 64-query blocks of a long one, S^T = K . Q^T and
+// O^T += V^T . P^T on v_mfma_f32_16x16x32_f16 - but every operand is split into f16 hi + f16 lo on the way to LDS / registers
+// and every product is taken as hi.hi + hi.lo + lo.hi (22 significant bits: fp32-class scores and contexts).  Attention is
+// ~0.1 % of the encoder's flops at item lengths of 3-8 pieces, so the 3x MFMA count is free; the kernel is bound by its HBM
+// bytes (9 KB in, 3 KB out per word piece and layer).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_f16x8(const f32x4_t a, const f32x4_t b, f16x8_t& hi, f16x8_t& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (f16_t)a[i];
+    hi[4 + i] = (f16_t)b[i];
+    lo[i] = (f16_t)(a[i] - (float)hi[i]);
+    lo[4 + i] = (f16_t)(b[i] - (float)hi[4 + i]);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
+                                                                  unsigned char* __restrict__ ctx8, int ldc, int H,
+                                                                  const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                                  const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                                  const int* __restrict__ tok_lo, const float* __restrict__ key_bias) {
+  constexpr int RS = 144;
+  __shared__ __attribute__((aligned(16))) char Kh[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Kl[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vh[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vl[64 * RS];
+  __shared__ __attribute__((aligned(16))) float Bs[64];
+  __shared__ __attribute__((aligned(16))) int Ls[64];
+  typedef f16x8_t frag_t;
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
+  const int tq = q0 + wave * 16 + fr;
+  const bool qvalid = tq < q1;
+  const int lo_tok = tok_lo[qvalid ? tq : q0];
+
+  frag_t qh[2], ql[2];
+  {
+    const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split_f16x8(load4(qp + ks * 32), load4(qp + ks * 32 + 4), qh[ks], ql[ks]);
+  }
+  float m = -1e30f, l = 0.f;
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 2, sc0 = (tid & 3) * 2;       // staging: row 0..63, two 8-element chunks
+  for (int kt = k0; kt < k1; kt += 64) {
+    const int tn = min(64, k1 - kt);
+    __syncthreads();
+    {
+      frag_t kh[2], kl[2], vh[2], vl[2];
+      if (srow < tn) {
+        const float* kp = qkv + (size_t)(kt + srow) * ld + H + h * 64 + sc0 * 8;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          split_f16x8(load4(kp + c * 8), load4(kp + c * 8 + 4), kh[c], kl[c]);
+          split_f16x8(load4(kp + H + c * 8), load4(kp + H + c * 8 + 4), vh[c], vl[c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) kh[c] = kl[c] = vh[c] = vl[c] = (frag_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        *reinterpret_cast<frag_t*>(Kh + srow * RS + (sc0 + c) * 16) = kh[c];
+        *reinterpret_cast<frag_t*>(Kl + srow * RS + (sc0 + c) * 16) = kl[c];
+        *reinterpret_cast<frag_t*>(Vh + srow * RS + (sc0 + c) * 16) = vh[c];
+        *reinterpret_cast<frag_t*>(Vl + srow * RS + (sc0 + c) * 16) = vl[c];
+      }
+      if (tid < 64) {
+        const bool in = tid < tn;
+        Ls[tid] = in ? tok_lo[kt + tid] : -1;
+        Bs[tid] = (in && key_bias) ? key_bias[kt + tid] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      sacc[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (it * 16 + fr) * RS + (ks * 32 + g * 8) * 2;
+        const frag_t kfh = *reinterpret_cast<const frag_t*>(Kh + off);
+        const frag_t kfl = *reinterpret_cast<const frag_t*>(Kl + off);
+        sacc[it] = mfma_16x16x32(kfl, qh[ks], sacc[it]);        // small terms first
+        sacc[it] = mfma_16x16x32(kfh, ql[ks], sacc[it]);
+        sacc[it] = mfma_16x16x32(kfh, qh[ks], sacc[it]);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const i32x4_t lk = *reinterpret_cast<const i32x4_t*>(&Ls[it * 16 + g * 4]);
+      if (key_bias) sacc[it] += *reinterpret_cast<const f32x4_t*>(&Bs[it * 16 + g * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[it][r] = lk[r] == lo_tok ? sacc[it][r] : -1e30f;
+    }
+    frag_t ph[2];
+    flash_softmax_step<f16_t>(sacc, m, l, o, ph);             // sacc now holds the fp32 probabilities, ph their f16 roundings
+    frag_t pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pl[s2][j] = (f16_t)(sacc[2 * s2][j] - (float)ph[s2][j]);
+        pl[s2][4 + j] = (f16_t)(sacc[2 * s2 + 1][j] - (float)ph[s2][4 + j]);
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int off = (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
+        union { struct { tr16x4_t a, b; } s; frag_t f; } uh, ul;
+        uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off));
+        uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off + 16 * RS));
+        ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off));
+        ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off + 16 * RS));
+        o[dt] = mfma_16x16x32(ul.f, ph[s2], o[dt]);
+        o[dt] = mfma_16x16x32(uh.f, pl[s2], o[dt]);
+        o[dt] = mfma_16x16x32(uh.f, ph[s2], o[dt]);
+      }
+  }
+  if (qvalid) {
+    const float inv = 1.0f / l;
+    const size_t col = (size_t)h * 64 + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      store_split4(ctx16 + (size_t)tq * ldc + col + dt * 16, ctx8 + (size_t)tq * 2 * ldc + col + dt * 16, H, o[dt] * inv);
+  }
+}
+
 template <typename T16>
 __global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
                                                                  const int* __restrict__ bq0, const int* __restrict__ bq1,
@@ -653,6 +791,8 @@ extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma,
   return 0;
 }
 
+static const bool g_attn_split_valu = getenv("RUART_ATTN_SPLIT_VALU") != nullptr;
+
 extern "C" int ruart_rows_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out32,
                                           void* out16, void* out8, int ldo, int rows, int H, void* stream) {
   RUART_ENTRY();
@@ -679,8 +819,12 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
                                           const int* tok_hi, const float* key_bias, void* stream) {
   RUART_ENTRY();
   if (n_heads * 64 != H || n_blocks <= 0 || !ctx16 || !ctx8 || (ldc & 3)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr, ldc,
-                     H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
+  if (g_attn_split_valu)       // diagnostic: the fp32 VALU kernel (lane = query) instead of the split-f16 MFMA kernel
+    hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr,
+                       ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
+  else
+    hipLaunchKernelGGL(attn_flash_split_kernel, dim3(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16,
+                       (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
   RUART_CHECK_LAUNCH();
   return 0;
 }

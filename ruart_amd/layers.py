@@ -151,10 +151,9 @@ def lstm_cell_steps(xproj_steps, w_hh, n_active, h0, c0, zero_state=True):
     xproj_steps[s] is (n_active[s], 4h).  Per step: one GEMM (recurrent product, fused with the add of xproj) and one
     fused HIP cell kernel.  Returns the final (h, c) of every row."""
     h, c = h0, c0
-    wt = w_hh.t()
     for s, n in enumerate(n_active):
         # with a zero initial state there is nothing to add at step 0
-        pre = xproj_steps[s] if (s == 0 and zero_state) else torch.addmm(xproj_steps[s], h[:n], wt)
+        pre = xproj_steps[s] if (s == 0 and zero_state) else ops.addmm(xproj_steps[s], h[:n], w_hh)
         h, c = ops.lstm_cell(pre, h, c, n)
     return h, c
 
@@ -241,7 +240,7 @@ class LinearSelfAttn(nn.Module):
 
     def forward(self, x, x_mask):
         x = dropout(x, p=dropout_p, training=self.training)
-        scores = self.linear(x).squeeze(-1).masked_fill(x_mask.eq(0), float("-inf"))
+        scores = ops.linear(x, self.linear.weight, self.linear.bias).squeeze(-1).masked_fill(x_mask.eq(0), float("-inf"))
         return F.softmax(scores, dim=1)
 
     def merge(self, x, x_mask):
@@ -269,8 +268,8 @@ class BilinearSeqAttn(nn.Module):
     def forward(self, x, y, x_mask, mask_flag=True):
         x = dropout(x, p=dropout_p, training=self.training)
         y = dropout(y, p=dropout_p, training=self.training)
-        Wy = self.linear(y) if self.linear is not None else y
-        xWy = x.bmm(Wy.unsqueeze(2)).squeeze(2)
+        Wy = ops.linear(y, self.linear.weight, self.linear.bias) if self.linear is not None else y
+        xWy = (x * Wy.unsqueeze(1)).sum(2)           # x_i . (W y): a row-wise dot product, not worth a batched GEMM with N = 1
         if mask_flag:
             xWy = xWy.masked_fill(x_mask.eq(0), float("-inf"))
         return xWy
@@ -307,8 +306,8 @@ class GetFinalScores(nn.Module):
 
     def get_single_score(self, x, h, x_mask, linear, w):
         """:421-432: w . (softmax(mask(x . W h)) . x) + b - one fused-attention launch with a single query row."""
-        Wh = linear(h).unsqueeze(1)
-        return w(ops.fused_attention(Wh, x, x, x_mask)).squeeze(2)
+        Wh = ops.linear(h, linear.weight, linear.bias).unsqueeze(1)
+        return ops.linear(ops.fused_attention(Wh, x, x, x_mask), w.weight, w.bias).squeeze(2)
 
 
 class DeepAttention(nn.Module):

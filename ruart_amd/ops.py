@@ -1,7 +1,12 @@
 """autograd wrappers around the SDNet kernels of libruart_hip.so (fp32, device tensors only).
 
-Each Function's forward AND backward launch hand-written HIP kernels through the C ABI; only the plain dense
-projections around them (x W^T) go to torch.matmul (rocBLAS), as the design allows for library GEMMs.
+Each Function's forward AND backward launch hand-written HIP kernels through the C ABI - the dense projections included
+(``mm`` / ``linear`` / ``addmm`` on ruart_gemm_x3).  No library GEMM runs inside a training or inference step of the default
+modes: the vendor library's solutions for these shapes are all stream-K kernels (Tensile ``SK3``: a fixed grid of workgroups that
+exchange partial tiles through flags in memory and spin on each other), which need every workgroup of the launch resident at the
+same time; three of them launched on three streams beside the encoder's 256-workgroup GEMMs do not get that, and the device stops
+making progress (the hang of round 1).  Only the exact-fp32 validation mode (``trunk_gemm == "fp32"``) still calls
+torch.mm, and SDNet runs that mode on ONE stream.
 There is no CPU path: a CPU tensor raises ``hip.HipError``.
 """
 import ctypes
@@ -139,7 +144,6 @@ trunk_gemm = "x3"
 # bf16 product with fp32 accumulation - what mixed-precision training uses for gradients).  SDNet.forward sets it from
 # opt['ruart_trunk_grad_gemm'] (default "x3").  Forward products always use trunk_gemm.
 trunk_grad_gemm = "x3"
-_X3_MIN_FLOP = 2 * 64 * 64 * 64
 
 
 def _one_unit_stride(t):
@@ -152,20 +156,24 @@ def _one_unit_stride(t):
     return t.contiguous()
 
 
-def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale=None, rpm=1):
-    """a (M,K) . b (K,N) (+ bias (N,)) -> (M,N) fp32, on the split-bf16 MFMA kernel when the product is big enough.
-    ``mode``: 'x3' | 'fp32'; default = the module-level ``trunk_gemm`` (autograd Functions pass the mode of their forward).
-    ``out``: optional contiguous (M, N) destination.
+def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale=None, rpm=1, residual=None):
+    """a (M,K) . b (K,N) (+ bias (N,)) (+ residual (M,N)) -> (M,N) fp32 on the split-bf16 MFMA kernel - every size, down to a
+    single row: no product of a step goes to the vendor library (see the module docstring).
+    ``mode``: 'x3' | 'x1' | 'fp32' (torch.mm: the validation mode); default = the module-level ``trunk_gemm`` (autograd Functions
+    pass the mode of their forward).  ``out``: optional contiguous (M, N) destination.
     ``a_scale`` (M/rpm, K) / ``b_scale`` (K/rpm, N) / ``c_scale`` (M/rpm, N): variational-dropout masks fused into the operand
     loads / the output (each mask row is shared by ``rpm`` consecutive rows)."""
     M, K = a.shape
     N = b.shape[1]
     mode = mode or trunk_gemm
-    use_x3 = mode in ("x3", "x1") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and 2 * M * N * K >= _X3_MIN_FLOP
+    use_x3 = mode in ("x3", "x1") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
     if use_x3:
         a, b = _one_unit_stride(a), _one_unit_stride(b)
-        if (a_scale is not None and a.stride(1) != 1) or (b_scale is not None and b.stride(1) != 1):
-            use_x3 = False                                  # the fused masks follow the operand's natural orientation only
+        # the fused operand masks follow the operand's natural orientation only: otherwise multiply first
+        if a_scale is not None and a.stride(1) != 1:
+            a, a_scale = _one_unit_stride(a * a_scale.repeat_interleave(rpm, 0)), None
+        if b_scale is not None and b.stride(1) != 1:
+            b, b_scale = _one_unit_stride(b * b_scale.repeat_interleave(rpm, 0)), None
     if not use_x3:
         if a_scale is not None:
             a = a * a_scale.repeat_interleave(rpm, 0)
@@ -174,6 +182,8 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
         r = torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
         if c_scale is not None:
             r = r * c_scale.repeat_interleave(rpm, 0)
+        if residual is not None:
+            r = r + residual
         return r if out is None else out.copy_(r)
     lib = hip.load()
     if out is None:
@@ -191,7 +201,12 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
     ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
     fn = lib.ruart_gemm_x1 if mode == "x1" else lib.ruart_gemm_x3
-    hip.check(fn(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), None, 0, hip.ACT_NONE, hip.ptr(out), N,
+    ldr = 0
+    if residual is not None:
+        if not (residual.shape == (M, N) and residual.dtype == torch.float32 and residual.stride(1) == 1):
+            residual = residual.contiguous()
+        ldr = residual.stride(0)
+    hip.check(fn(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(residual), ldr, hip.ACT_NONE, hip.ptr(out), N,
                  M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm),
                  hip.stream_ptr()), "ruart_gemm_x3")
     return out
@@ -219,6 +234,32 @@ class _Linear(torch.autograd.Function):
         gw = mm(gy.t(), xm, mode=ctx.mode) if ctx.needs_input_grad[1] else None
         gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None
+
+
+class _AddMM(torch.autograd.Function):
+    """base + x W^T in one launch (the residual rides in the GEMM epilogue): the recurrent product of the wide `multi2one` LSTM
+    step added to the step's input projection (Models/SDNet.py:269-271 via nn.LSTM)."""
+
+    @staticmethod
+    def forward(ctx, base, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm
+        return mm(x, w.t(), residual=base)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = mm(gy, w, mode=ctx.mode) if ctx.needs_input_grad[1] else None
+        gw = mm(gy.t(), x, mode=ctx.mode) if ctx.needs_input_grad[2] else None
+        return (gy if ctx.needs_input_grad[0] else None), gx, gw
+
+
+def addmm(base, x, w):
+    """base (M, N) + x (M, K) . w (N, K)^T."""
+    if trunk_gemm != "x3" or not x.is_cuda:
+        return torch.addmm(base, x, w.t())
+    return _AddMM.apply(base, x.contiguous(), w)
 
 
 def linear(x, w, b=None, mask=None):

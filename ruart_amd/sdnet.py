@@ -286,6 +286,8 @@ class SDNet(nn.Module):
         """Question / object / OCR branches on three streams - with a frozen encoder.  The trainable encoder's step is 10x longer
         and gains nothing measurable from the overlap; its first version (library GEMMs of extreme shape running on the three
         streams at once) also stopped completing steps at B = 64 - DESIGN.md section 5 - so that mode stays on one stream."""
+        if ops.trunk_gemm != "x3":          # exact-fp32 validation mode: its projections are library GEMMs (stream-K solutions that
+            return False                     # need all their workgroups resident) - never beside other streams' kernels
         return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or getattr(self.Bert, "bert_model", None) is None)
 
     def _layer_weights(self):
