@@ -112,7 +112,7 @@ int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8
 int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
                         const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H,
                         void* stream);
-/* d(loss)/d(layer_w[l]) for the op above; partial_ws holds ceil(n_words/4) * n_layers floats. Deterministic. */
+/* d(loss)/d(layer_w[l]) for the op above; partial_ws holds n_words * n_layers floats. Deterministic.  (Both: H % 4 == 0, H <= 1024.) */
 int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
                             const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial_ws,
                             float* grad_layer_w, int n_words, int H, void* stream);
@@ -290,7 +290,8 @@ int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const float* B, long 
 /* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
  * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for
  * the trunk's short kernels.  Off by default - it did not pay on MI355X.  n_cus <= 0 or >= the device's CU count creates an
- * ordinary stream.  Destroy with ruart_stream_destroy before the process exits. */
+ * ordinary stream.  ruart_stream_destroy drops it early; never call that from an atexit hook (teardown order
+ * of the runtime / profiler is not under the caller's control) - process exit releases the stream. */
 int ruart_stream_create_cu_masked(int n_cus, void** stream_out);
 int ruart_stream_destroy(void* stream);
 

@@ -312,7 +312,7 @@ class BatchIndex:
                 spans.append((s, l, d, rows))
             self._spans_host = (np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32),
                                 [(len(t[0]), t[3]) for t in spans])
-            if "LOCK_BERT" in opt:
+            if "LOCK_BERT" in opt and not opt.get("bert_frozen_dropout"):
                 self.packed.group_index = None         # (N, L) maps were only needed for the spans: keep the pickle small
                                                        # (the trainable encoder pads its attention per group from them)
         # sort of every embedding lookup's ids (word / POS / entity tables), for ops.embedding's backward

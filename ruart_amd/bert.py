@@ -328,7 +328,7 @@ class _PoolMix(torch.autograd.Function):
         g = torch.zeros(NL, dtype=torch.float32, device=layers.device)
         if W > 0:
             grad_out = grad_out.contiguous()
-            partial = torch.empty(((W + 3) // 4) * NL, dtype=torch.float32, device=layers.device)
+            partial = torch.empty(W * NL, dtype=torch.float32, device=layers.device)
             rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_len),
                                              hip.ptr(dst_row), hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H,
                                              hip.stream_ptr())
@@ -405,7 +405,24 @@ class Bert(nn.Module):
         self._source = None
 
     def lock(self):
+        """Frozen encoder (``LOCK_BERT``, Models/SDNet.py:91-94).  With ``opt['bert_frozen_dropout']`` the training-mode passes
+        reproduce what the reference really trains with: ``SDNetTrainer.update`` calls ``network.train()``
+        (Models/SDNetTrainer.py:332), which switches the dropout(0.1) layers INSIDE the frozen BERT back on
+        (Models/Bert/modeling.py:198, 244, 263, 302) although ``Bert.__init__`` had put it in eval mode.  Off by default: the
+        deterministic encoder is what that eval call intended, and it is what lets the pass run one step ahead.  When on, training
+        passes go through the fp32 module of bert_train.py (the dropouts sit exactly where the reference has them) without
+        gradients; evaluation passes stay on the fast frozen path."""
+        if self.opt.get("bert_frozen_dropout"):
+            from .bert_train import BertModelTrainable
+            state, cfg = self._source
+            model = BertModelTrainable(state, cfg, self._device, gemm="x3")
+            for p in model.parameters():
+                p.requires_grad_(False)
+            self.__dict__["_dropout_model"] = model        # not a registered child: the state dict keeps the reference's keys
         self._source = None
+
+    def _frozen_dropout_active(self):
+        return self.training and self.__dict__.get("_dropout_model") is not None
 
     # -- encoder pipelining across steps ---------------------------------------------------------------------
     # BERT is frozen, so the encoder pass of batch t+1 depends on nothing step t produces.  ``prefetch`` launches it on a
@@ -424,8 +441,8 @@ class Bert(nn.Module):
         """Encode ``packed`` asynchronously into the buffer set the current step does NOT use; ``layers_for`` returns the
         result.  ``after_stream``: the stream whose already enqueued work (the previous consumers of that set) must finish
         first.  Call it after ``layers_for`` of the current batch."""
-        if getattr(packed, "_layers", None) is not None or getattr(self, "bert_model", None) is not None:
-            return                           # (a trainable encoder changes every step: nothing to run ahead)
+        if getattr(packed, "_layers", None) is not None or getattr(self, "bert_model", None) is not None or self._frozen_dropout_active():
+            return                           # (a trainable encoder changes every step, a dropout pass is drawn per step: nothing to run ahead)
         dev = self._device
         if self._pf_stream is None or self._pf_stream.device != dev:
             # an ordinary stream by default; a CU-masked one (ruart_stream_create_cu_masked) only on request - measured on
@@ -452,6 +469,9 @@ class Bert(nn.Module):
         """All-layer encoder output of ``packed``: the prefetched one (the current stream waits for it) or computed now."""
         if getattr(self, "bert_model", None) is not None:
             return self.bert_model(packed, training=self.training)
+        if self._frozen_dropout_active():
+            with torch.no_grad():
+                return self.__dict__["_dropout_model"](packed, training=True)
         layers = getattr(packed, "_layers", None)
         if layers is not None:
             torch.cuda.current_stream(self._device).wait_event(packed._event)
@@ -484,7 +504,7 @@ class Bert(nn.Module):
             from .bert_train import pool_mix
             out = pool_mix(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows)
         else:
-            out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, self.weights.dtype)
+            out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, hip.dtype_code(layers))
         N, Lw = word_mask.shape
         return out.view(N, Lw, self.weights.hidden)
 

@@ -674,97 +674,144 @@ __global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sub-word pooling fused with the layer mix.  One wave per word.
+// Sub-word pooling fused with the layer mix.
 //   out[dst_row[w]][:] = sum_l wl[l] * mean_{p in [start, start+len)} layer_l[p][:]
+// One workgroup per word, its four waves share the layers (wave v takes layers v*ceil(NL/4) ...), every wave issues the
+// loads of up to three layers x two pieces x H/256 column groups (18 x 16 B per lane at bert-base) BEFORE it touches any of
+// them, and the four partial rows meet in LDS.  A word is 12-24 rows of 1.5-4 KB scattered over as many layer matrices, so
+// the kernel lives on bytes in flight: the first version (one wave per word, one layer per loop trip, three 8-byte loads
+// outstanding) ran at 1.4-1.6 TB/s.  All loads are unconditional (an out-of-range layer / piece re-reads a valid row with
+// weight 0): hipcc turns a per-load runtime condition into a branch plus s_waitcnt vmcnt(0) per load.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+#define POOL_MAX_LAYERS 32
+#define POOL_LPB 3
+template <typename T, int NG>
 __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
                                                        const int* __restrict__ span_start, const int* __restrict__ span_len,
                                                        const int* __restrict__ dst_row, const float* __restrict__ wl,
                                                        float* __restrict__ out, int ldo, int W, int H) {
-  const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= W) return;
+  __shared__ __attribute__((aligned(16))) float red[3][NG * 256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x;
   const int st = span_start[w], n = span_len[w];
-  f32x4_t acc[MAXG];
+  const float inv = 1.0f / (float)n;
+  const int per = (NL + 3) >> 2;
+  const int l0 = wv * per, l1 = min(NL, l0 + per);
+  f32x4_t acc[NG];
+  int col[NG];                                          // a lane past the row's end (H not a multiple of 256) re-reads the last group
 #pragma unroll
-  for (int i = 0; i < MAXG; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const float fn = (float)n;
-  for (int l = 0; l < NL; ++l) {
-    const float wgt = wl[l];
-    const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+  for (int i = 0; i < NG; ++i) {
+    acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    col[i] = min((i * 64 + lane) * 4, H - 4);
+  }
+  for (int lb = l0; lb < l1; lb += POOL_LPB) {
+    f32x4_t v[POOL_LPB][2][NG];
+    float wgt[POOL_LPB];
 #pragma unroll
-    for (int i = 0; i < MAXG; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < H) {
-        f32x4_t s = load4(base + c);
-        for (int p = 1; p < n; ++p) s += load4(base + (size_t)p * ldl + c);
-        if (n > 1) s = s / fn;
-        acc[i] += s * wgt;
+    for (int j = 0; j < POOL_LPB; ++j) {
+      const int l = min(lb + j, l1 - 1);
+      wgt[j] = (lb + j < l1) ? wl[l] * inv : 0.f;
+      const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+      const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        v[j][0][i] = load4(base + col[i]);
+        v[j][1][i] = load4(base1 + col[i]);
+      }
+    }
+    const float two = n > 1 ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < POOL_LPB; ++j)
+#pragma unroll
+      for (int i = 0; i < NG; ++i) acc[i] += (v[j][0][i] + v[j][1][i] * two) * wgt[j];
+    if (n > 2) {                                        // rare: words of three or more pieces
+      for (int j = 0; j < POOL_LPB && lb + j < l1; ++j) {
+        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)st * ldl;
+        for (int p = 2; p < n; ++p)
+#pragma unroll
+          for (int i = 0; i < NG; ++i) acc[i] += load4(base + (size_t)p * ldl + col[i]) * wgt[j];
       }
     }
   }
-  float* o = out + (size_t)dst_row[w] * ldo;
+  if (wv > 0) {
 #pragma unroll
-  for (int i = 0; i < MAXG; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < H) store4(o + c, acc[i]);
+    for (int i = 0; i < NG; ++i) *reinterpret_cast<f32x4_t*>(&red[wv - 1][(i * 64 + lane) * 4]) = acc[i];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* o = out + (size_t)dst_row[w] * ldo;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      f32x4_t r = acc[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r += *reinterpret_cast<const f32x4_t*>(&red[k][c]);
+      if (c < H) store4(o + c, r);
+    }
   }
 }
 
-#define POOL_MAX_LAYERS 32
-template <typename T>
+// d(loss)/d(wl[l]) partial of one word: <grad_out[dst_row[w]], mean of the word's rows of layer l>; partial[w * NL + l].
+template <typename T, int NG>
 __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
                                                            const int* __restrict__ span_start, const int* __restrict__ span_len,
                                                            const int* __restrict__ dst_row, const float* __restrict__ gout, int ldg,
                                                            float* __restrict__ partial, int W, int H) {
-  __shared__ float red[4][POOL_MAX_LAYERS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int w = blockIdx.x * 4 + wv;
-  float mine[POOL_MAX_LAYERS];
+  const int w = blockIdx.x;
+  const int st = span_start[w], n = span_len[w];
+  const float inv = 1.0f / (float)n;
+  const int per = (NL + 3) >> 2;
+  const int l0 = wv * per, l1 = min(NL, l0 + per);
+  f32x4_t gv[NG];
+  int col[NG];
+  const float* g = gout + (size_t)dst_row[w] * ldg;
 #pragma unroll
-  for (int l = 0; l < POOL_MAX_LAYERS; ++l) mine[l] = 0.f;
-  if (w < W) {
-    const int st = span_start[w], n = span_len[w];
-    const float fn = (float)n;
-    const float* g = gout + (size_t)dst_row[w] * ldg;
+  for (int i = 0; i < NG; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    col[i] = min(c, H - 4);
+    gv[i] = load4(g + col[i]);
+    if (c >= H) gv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // lanes past the row's end contribute nothing
+  }
+  for (int lb = l0; lb < l1; lb += POOL_LPB) {
+    f32x4_t v[POOL_LPB][2][NG];
 #pragma unroll
-    for (int i = 0; i < MAXG; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < H) {
-        const f32x4_t gv = load4(g + c);
+    for (int j = 0; j < POOL_LPB; ++j) {
+      const int l = min(lb + j, l1 - 1);
+      const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+      const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
 #pragma unroll
-        for (int l = 0; l < POOL_MAX_LAYERS; ++l) {
-          if (l < NL) {
-            const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
-            f32x4_t s = load4(base + c);
-            for (int p = 1; p < n; ++p) s += load4(base + (size_t)p * ldl + c);
-            if (n > 1) s = s / fn;
-            mine[l] += s[0] * gv[0] + s[1] * gv[1] + s[2] * gv[2] + s[3] * gv[3];
-          }
-        }
+      for (int i = 0; i < NG; ++i) {
+        v[j][0][i] = load4(base + col[i]);
+        v[j][1][i] = load4(base1 + col[i]);
       }
     }
-  }
+    const float two = n > 1 ? 1.f : 0.f;
 #pragma unroll
-  for (int l = 0; l < POOL_MAX_LAYERS; ++l) {
-    if (l < NL) {
-      const float s = wave_sum(mine[l]);
-      if (lane == 0) red[wv][l] = s;
+    for (int j = 0; j < POOL_LPB; ++j) {
+      f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NG; ++i) s4 += (v[j][0][i] + v[j][1][i] * two) * gv[i];
+      if (n > 2 && lb + j < l1) {
+        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)st * ldl;
+        for (int p = 2; p < n; ++p)
+#pragma unroll
+          for (int i = 0; i < NG; ++i) s4 += load4(base + (size_t)p * ldl + col[i]) * gv[i];
+      }
+      const float d = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) * inv;
+      if (lane == 0 && lb + j < l1) partial[(size_t)w * NL + lb + j] = d;
     }
   }
-  __syncthreads();
-  if (threadIdx.x < NL) partial[(size_t)blockIdx.x * NL + threadIdx.x] =
-      red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int NL, float* __restrict__ out) {
-  // one wave per layer weight; fixed summation order => bitwise reproducible
-  const int l = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nrows, int NL, float* __restrict__ out) {
+  // one workgroup per layer weight; fixed summation order => bitwise reproducible
+  __shared__ float red[4];
+  const int l = blockIdx.x;
   float s = 0.f;
-  for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * NL + l];
-  s = wave_sum(s);
-  if (lane == 0) out[l] = s;
+  for (int b = threadIdx.x; b < nrows; b += 256) s += partial[(size_t)b * NL + l];
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) out[l] = s;
 }
 
 template <typename TIn, typename TOut>
@@ -881,18 +928,34 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
   return 0;
 }
 
+template <typename T>
+static void launch_pool(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_len,
+                        const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H, hipStream_t st) {
+  const dim3 grid(n_words), block(256);
+#define POOL(NG) hipLaunchKernelGGL((pool_mix_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H)
+  switch ((H + 255) / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
+#undef POOL
+}
+template <typename T>
+static void launch_pool_bwd(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_len,
+                            const int* dst_row, const float* grad_out, int ldg, float* partial, int n_words, int H, hipStream_t st) {
+  const dim3 grid(n_words), block(256);
+#define POOL(NG) hipLaunchKernelGGL((pool_mix_bwd_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial, n_words, H)
+  switch ((H + 255) / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
+#undef POOL
+}
+
 extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
                                    const int* span_start, const int* span_len, const int* dst_row, const float* layer_w,
                                    float* out, int ldo, int n_words, int H, void* stream) {
   RUART_ENTRY();
-  if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
-  const dim3 grid(ceil_div(n_words, 4)), block(256);
+  if (H % 4 || H < 4 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0) return (int)hipErrorInvalidValue;
   if (dtype == RUART_DT_BF16)
-    hipLaunchKernelGGL(pool_mix_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+    launch_pool<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   else if (dtype == RUART_DT_F16)
-    hipLaunchKernelGGL(pool_mix_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+    launch_pool<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL(pool_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H);
+    launch_pool<float>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -901,17 +964,15 @@ extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_strid
                                        const int* span_start, const int* span_len, const int* dst_row, const float* grad_out,
                                        int ldg, float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream) {
   RUART_ENTRY();
-  if (H % 4 || H > 256 * MAXG || n_words <= 0 || n_layers > POOL_MAX_LAYERS) return (int)hipErrorInvalidValue;
-  const int nb = ceil_div(n_words, 4);
-  const dim3 grid(nb), block(256);
+  if (H % 4 || H < 4 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0) return (int)hipErrorInvalidValue;
   if (dtype == RUART_DT_BF16)
-    hipLaunchKernelGGL(pool_mix_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+    launch_pool_bwd<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   else if (dtype == RUART_DT_F16)
-    hipLaunchKernelGGL(pool_mix_bwd_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+    launch_pool_bwd<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL(pool_mix_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H);
+    launch_pool_bwd<float>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(64), 0, (hipStream_t)stream, partial_ws, nb, n_layers, grad_layer_w);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, partial_ws, n_words, n_layers, grad_layer_w);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -132,6 +132,14 @@ def stream_ptr(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_DTYPE_CODE = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}
+
+
+def dtype_code(t):
+    """RUART_DT_* of a tensor's storage type."""
+    return _DTYPE_CODE[t.dtype]
+
+
 def ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
@@ -153,13 +161,8 @@ def cu_masked_stream(n_cus, device):
     out = ctypes.c_void_p()
     with torch.cuda.device(device):
         check(lib.ruart_stream_create_cu_masked(int(n_cus), ctypes.byref(out)), "ruart_stream_create_cu_masked")
-    import atexit
-
-    def _destroy(handle=out.value):
-        try:
-            torch.cuda.synchronize(device)
-            lib.ruart_stream_destroy(handle)
-        except Exception:
-            pass
-    atexit.register(_destroy)
+    # No atexit destroy: at interpreter exit the HIP runtime, RCCL and - under rocprofv3 - the profiler's tool library are torn
+    # down in an order this module does not control; destroying the stream from an atexit hook after the profiler had finalised
+    # is what ended a round-1 profiling run with SIGSEGV in __cxa_finalize (gpurun_out/pftrace.log: the masked stream was the
+    # default prefetch stream then).  The process exit releases the stream; call ruart_stream_destroy yourself to drop one earlier.
     return torch.cuda.ExternalStream(out.value, device=device)

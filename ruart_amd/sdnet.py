@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import hip
 from . import layers as L
 from . import ops
 from .batch import BatchIndex
@@ -405,7 +406,7 @@ class SDNet(nn.Module):
             s_, l_, dst, rows = bi.spans[g]
             if trainable:
                 return bert_train.pool_words(mixed, s_, l_, dst, rows)
-            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, self.Bert.weights.dtype)
+            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers))
 
         def front(items, idx, mix):
             words, raw = self._embed_items(items, idx, mix)

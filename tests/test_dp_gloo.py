@@ -86,3 +86,73 @@ def test_gradsync_two_ranks(tmp_path, skip_pinned):
     # replicas stay bit-identical after two optimizer steps
     for name in r[0]["params"]:
         assert torch.equal(r[0]["params"][name], r[1]["params"][name]), name
+
+
+# ---- the REAL SDNet parameter list (no forward: gradients filled by hand) -------------------------------------------------------
+class _StubBert(nn.Module):
+    """Stands in for ruart_amd.bert.Bert: the frozen encoder holds no nn.Parameter, so the DP logic never sees it."""
+
+    def __init__(self, opt, device=None):
+        super().__init__()
+
+    def lock(self):
+        pass
+
+
+def _real_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from ruart_amd import sdnet as sdnet_mod, synth
+    from ruart_amd.arguments import default_opt
+    from ruart_amd.dp import GradSync
+    sdnet_mod.Bert = _StubBert
+    opt = default_opt(vocab_size=1500, device="cpu")
+    sw = synth.make_sdnet_weights(opt, seed=7)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    net = sdnet_mod.SDNet(opt, {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+    gs = GradSync(net, opt, pinned_scalar=True)                   # what the trainer passes with the fused optimizer
+    g = torch.Generator().manual_seed(1000 + rank)
+    local = {}
+    for name, p in net.named_parameters():
+        if p.requires_grad and not name.startswith("get_answer.rnn."):
+            p.grad = torch.randn(p.shape, generator=g)
+            local[name] = p.grad.clone()
+    gs.average_gradients()                                        # no hook fired: every bucket is launched here, in order
+    res = {"names": [n for b in gs.buckets for (n, _, _) in b], "rows": [r for b in gs.buckets for (_, _, r) in b],
+           "payload": gs.payload_bytes, "mode": gs.mode, "n_buckets": len(gs.buckets), "local": local,
+           "avg": {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+           "pinned_sq": float(gs.pinned_sq), "tp": int(opt["tune_partial"]),
+           "numel": {n: p.numel() for n, p in net.named_parameters() if p.requires_grad}}
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+def test_gradsync_on_the_real_sdnet_parameter_list(tmp_path):
+    """Bucket layout of the actual model: identical order on both ranks, the dead GRU left out, the re-pinned embedding rows
+    represented by one scalar, payload = the ~37 MB class of SURVEY section 8e (scaled to this vocabulary)."""
+    world = 2
+    out = str(tmp_path / "real%d.pt")
+    mp.spawn(_real_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(out % i) for i in range(world)]
+    assert r[0]["names"] == r[1]["names"] and r[0]["rows"] == r[1]["rows"] and r[0]["n_buckets"] == r[1]["n_buckets"] >= 2
+    names = r[0]["names"]
+    assert r[0]["mode"] == "scalar" and not any(n.startswith("get_answer.rnn.") for n in names)
+    assert "alphaBERT" in names and "multi2one.rnns.0.weight_ih_l0" in names and "get_answer.attn.linear.weight" in names
+    tp = r[0]["tp"]
+    want = 0
+    for n in names:
+        want += tp * 300 if n in ("fast_embed.weight", "glove_embed.weight") else r[0]["numel"][n]
+    assert r[0]["payload"] == 4 * want + 4                        # fp32 elements + the scalar
+    assert set(names) == {n for n in r[0]["numel"] if not n.startswith("get_answer.rnn.")}
+    sq = 0.0
+    for n in names:
+        l0, l1 = r[0]["local"][n], r[1]["local"][n]
+        a0, a1 = r[0]["avg"][n], r[1]["avg"][n]
+        if n in ("fast_embed.weight", "glove_embed.weight"):
+            assert torch.allclose(a0[:tp], (l0[:tp] + l1[:tp]) / 2, atol=1e-6) and torch.equal(a0[:tp], a1[:tp]), n
+            assert torch.equal(a0[tp:], l0[tp:]) and torch.equal(a1[tp:], l1[tp:]), n      # never exchanged: still local
+            sq += float(l0[tp:].double().pow(2).sum() + l1[tp:].double().pow(2).sum())
+        else:
+            assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6) and torch.equal(a0, a1), n
+    assert abs(r[0]["pinned_sq"] - sq / 4) < 1e-4 * sq / 4 and r[0]["pinned_sq"] == r[1]["pinned_sq"]

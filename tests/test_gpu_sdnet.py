@@ -205,6 +205,32 @@ def test_variational_dropout_contract():
     assert torch.equal(L.dropout(x, p=0.4, training=False), x)
 
 
+def test_frozen_bert_dropout_is_opt_in(golden):
+    """``opt['bert_frozen_dropout']`` reproduces the reference's actual training-mode behaviour (Models/SDNetTrainer.py:332 flips the
+    dropout(0.1) layers inside the frozen BERT back on, Models/Bert/modeling.py:198, 244, 263, 302): training passes become random,
+    evaluation passes stay the deterministic ones; without the option nothing changes."""
+    import ruart_amd.layers as L
+    z = golden
+    net, opt = build(z, "x3", bert_frozen_dropout=True)
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=30, n_ocr=100, n_od=30, bert_vocab=2000, ragged=True)
+    L.set_dropout_prob(0.0)
+    net.drop_emb = False
+    assert not any(k.startswith("Bert.") for k in net.state_dict())           # the fp32 copy is not part of the checkpoint
+    net.eval()
+    with torch.no_grad():
+        e = net(q, ocr, od)[0].cpu().numpy()
+    assert np.abs(e - z["scores"]).max() < 2e-4                                # evaluation: the deterministic encoder
+    net.train()
+    with torch.no_grad():
+        a = net(q, ocr, od)[0].cpu().numpy()
+        b = net(q, ocr, od)[0].cpu().numpy()
+    assert np.abs(a - b).max() > 1e-5                                          # two training passes draw different masks
+    assert np.abs(a - z["scores"]).max() < 0.5 and np.allclose(a.sum(1), 1.0, atol=1e-5)
+    scores, _ = net(q, ocr, od)
+    torch.nn.functional.binary_cross_entropy_with_logits(scores, gt.to(scores.device)).backward()
+    assert net.alphaBERT.grad is not None and torch.isfinite(net.alphaBERT.grad).all()
+
+
 def test_no_cpu_fallback():
     from ruart_amd import hip, ops
     with pytest.raises(hip.HipError):
