@@ -429,6 +429,9 @@ def main():
     if dp:
         dist.barrier()
         dist.destroy_process_group()
+    torch.cuda.synchronize()
+    if getattr(tr.network, "Bert", None) is not None:
+        tr.network.Bert.close()                 # the CU-masked run-ahead stream must not outlive the interpreter (hip.destroy_stream)
 
 
 if __name__ == "__main__":

@@ -391,7 +391,10 @@ class Bert(nn.Module):
         self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
         self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path
         self.pack = not opt.get("bert_no_pack", False)
-        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 0))
+        # CUs the run-ahead encoder pass may occupy.  In the fp16c mode the pass (19 ms) outlasts the trunk's step (15 ms), and a trunk
+        # kernel otherwise waits for a GEMM workgroup (which owns a whole CU's registers and LDS for ~45 us) to retire: keeping 16
+        # CUs out of the encoder's reach took the step from 26.7 to 25.8 ms.  The plain 16-bit modes gain nothing (round 1).
+        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 240 if opt.get("bert_precision", "fp16") == "fp16c" else 0))
         self._init_pipeline()
 
     def unlock(self):
@@ -464,6 +467,15 @@ class Bert(nn.Module):
             packed._set = self._in_use ^ 1
             packed._layers = bert_encode(self.weights, packed, self._bufsets[packed._set])
             packed._event = st.record_event()
+
+    def close(self):
+        """Release the CU-masked run-ahead stream (see hip.destroy_stream); a later prefetch creates a new one."""
+        st, self._pf_stream = getattr(self, "_pf_stream", None), None
+        if st is not None:
+            if self._pending is not None:
+                self._pending._layers = None
+                self._pending = None
+            hip.destroy_stream(st)
 
     def layers_for(self, packed):
         """All-layer encoder output of ``packed``: the prefetched one (the current stream waits for it) or computed now."""

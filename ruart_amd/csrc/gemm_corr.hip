@@ -27,6 +27,12 @@
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 
+// operand format code of the scaled MFMA: 0 = e4m3 (production).  Diagnostic builds (tools/build_variant.sh fp6 -DRUART_C8_FMT=2)
+// make the instruction read the same registers as e2m3 fp6 - wrong numbers, but the 4x-rate timing of an fp6 correction phase.
+#ifndef RUART_C8_FMT
+#define RUART_C8_FMT 0
+#endif
+
 #define CBM 256
 #define CBN 256
 #define CBKB 128   // bytes of one row of one K-tile (64 f16 or 128 fp8)
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[hc * 2 + i][hr * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], af[j], acc[hc * 2 + i][hr * 4 + j], 0, 0, 0,
-                                                                                         scale_w, 0, scale_a);
+          acc[hc * 2 + i][hr * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], af[j], acc[hc * 2 + i][hr * 4 + j], RUART_C8_FMT,
+                                                                                         RUART_C8_FMT, 0, scale_w, 0, scale_a);
     } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)

@@ -165,4 +165,19 @@ def cu_masked_stream(n_cus, device):
     # down in an order this module does not control; destroying the stream from an atexit hook after the profiler had finalised
     # is what ended a round-1 profiling run with SIGSEGV in __cxa_finalize (gpurun_out/pftrace.log: the masked stream was the
     # default prefetch stream then).  The process exit releases the stream; call ruart_stream_destroy yourself to drop one earlier.
-    return torch.cuda.ExternalStream(out.value, device=device)
+    st = torch.cuda.ExternalStream(out.value, device=device)
+    st._ruart_handle = out.value            # for destroy_stream()
+    return st
+
+
+def destroy_stream(st):
+    """Destroy a stream made by ``cu_masked_stream`` (after synchronising it).  Call it before the process ends when a profiler is
+    attached: on ROCm 7.2 a CU-masked queue that is still alive when the runtime's static destructors run takes rocprofv3's
+    teardown down with SIGSEGV in __cxa_finalize (after the tool has written its output) - seen in round 1 and again in round 2
+    with no atexit hook of ours involved."""
+    handle = getattr(st, "_ruart_handle", None)
+    if handle is None:
+        return
+    st.synchronize()
+    load().ruart_stream_destroy(handle)
+    st._ruart_handle = None
