@@ -210,7 +210,7 @@ def bert512_measure(a, device, lib, precision, batch=64, steps=None, warmup=None
     return {"flops": flops, "dt": dt, "dt1": dt1, "gemm_ms": ms.value, "gemm_n": n.value, "gemm_flops": fl.value, "steps": steps, "L": L}
 
 
-def bert512(a, device, lib):
+def bert512(a, device, lib, out_stream=sys.stdout):
     note("bert512: building weights")
     r = bert512_measure(a, device, lib, a.precision, batch=a.batch)
     flops, dt, dt1, L = r["flops"], r["dt"], r["dt1"], r["L"]
@@ -225,11 +225,21 @@ def bert512(a, device, lib):
                                      "frac": round(flops / dt1 / 1e12 / PEAK_TFLOPS, 4),
                                      "gemm_only_tflops": round(r["gemm_flops"] / (r["gemm_ms"] * 1e-3) / 1e12, 1) if r["gemm_n"] else None,
                                      "gemm_share": round(r["gemm_ms"] / r["steps"] / (dt1 * 1e3), 3) if r["gemm_n"] else None}}}
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=out_stream, flush=True)
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner at its first collective):
+    keep the real stdout for the line and send everything else that is written to fd 1 to stderr."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
 
 
 def main():
     a = parse()
+    out_stream = _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +267,7 @@ def main():
     from ruart_amd.arguments import default_opt
     lib = hip.load()
     if a.mode == "bert512":
-        return bert512(a, device, lib)
+        return bert512(a, device, lib, out_stream)
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
     if a.graph_trunk is not None:
         opt["ruart_graph_trunk"] = bool(a.graph_trunk)
@@ -425,7 +435,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle) ...")
             out["cpu_baseline"] = cpu_baseline(opt, cfg, a.cpu_samples)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=out_stream, flush=True)
     if dp:
         dist.barrier()
         dist.destroy_process_group()
