@@ -55,6 +55,11 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
  * M % 256 == 0, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                       const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, void* stream);
+/* Split-K form for weight gradients (dW = dY^T . X with both operands given K-contiguous, i.e. transposed: ruart_transpose16):
+ * part[z] (M x N fp32, row stride ldc; slabs M * ldc floats apart) = A[:, z kchunk ...] . W[:, z kchunk ...]^T, z < ceil(K / kchunk);
+ * sum the slabs with ruart_splitk_reduce.  M, N % 256 == 0, K % 128 == 0, kchunk % 128 == 0. */
+int ruart_gemm_16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* part, int ldc, int M, int N, int K, int kchunk,
+                            int in_dtype, void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
 /* Tile variant of ruart_gemm_16_nt: 5 (default) = 256x256 tile, four phases per K-tile with the prefetch in flight across
@@ -117,6 +122,44 @@ int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl,
                             const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial_ws,
                             float* grad_layer_w, int n_words, int H, void* stream);
 int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n, float scale, void* stream);
+
+/* ---- kernels of the TRAINABLE encoder's 16-bit path (conf without LOCK_BERT, opt['bert_train_gemm'] = '16'; csrc/bert_train_*.hip).
+ * Activations f16, GEMM-bound gradients bf16, residual-stream gradient fp32.  Dropout masks are regenerated from (seed, element index)
+ * by a counter-based hash: the same seed in the forward and the backward call gives the same mask. ------------------------------- */
+/* Models/Bert/modeling.py:260-264 / 299-303: y = LN(dropout(x) + res) with x fp32 (dense output incl. bias) and res f16 (post = 0), or
+ * :196-199: y = dropout(LN(x)) (post = 1, res ignored).  Saves pre16 = f16(LayerNorm input) and stats[row] = (mean, rstd). */
+int ruart_ln_train_fwd(const float* x, int ldx, const void* res16, int ldr, const float* gamma, const float* beta, float eps, float p,
+                       unsigned seed, int post, void* y16, void* pre16, float* stats, int ld16, int rows, int H, void* stream);
+/* backward: dy fp32 (+ add_scale[0] * add when add != NULL) -> d_res fp32 (gradient at the LayerNorm input: the residual path) and, post = 0,
+ * d_gemm bf16 (the same times the dropout multiplier: gradient at the dense output); d_gamma / d_beta (H) written or accumulated.
+ * ws: ruart_ln_train_bwd_ws_floats(H) floats. */
+size_t ruart_ln_train_bwd_ws_floats(int H);
+int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, const float* add_scale, const void* pre16, int ld16, const float* stats,
+                       const float* gamma, float p, unsigned seed, int post, float* d_res, int ldd, void* d_gemm_bf16, int ldg,
+                       float* d_gamma, float* d_beta, int accumulate, float* ws, int rows, int H, void* stream);
+/* Models/Bert/modeling.py:52-57: g = gelu(h) (f16 -> f16) and d_h = d_g * gelu'(h) (bf16, f16 -> bf16); n elements, n % 4 == 0 */
+int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* stream);
+int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, long long n, void* stream);
+/* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */
+int ruart_colsum_bf16(const void* x_bf16, int ld, int rows, int cols, float* out, int accumulate, float* ws, void* stream);
+/* out (cols x rows, row stride ldo) = in^T for a 16-bit matrix (rows x cols, row stride ldi); f16_to_bf16 != 0 converts f16 elements
+ * to bf16 on the way (activations as the bf16 operand of a weight-gradient product) */
+int ruart_transpose16(const void* in, int ldi, void* out, int ldo, int rows, int cols, int f16_to_bf16, void* stream);
+/* C (n floats) = scale * sum_z part[z] (+ C when accumulate), slabs slab_floats apart, z in order (deterministic) */
+int ruart_splitk_reduce(const float* part, long long slab_floats, int nz, float* C, long long n, float scale, int accumulate, void* stream);
+/* Models/SDNet.py:573-581 on the token stream: out[r] = sum_l w[l] * layers[l][r] (f16 layers, fp32 out) and d w[l] = sum_r <g[r],
+ * layers[l][r]> (ws: 512 * n_layers floats) */
+int ruart_mix_rows(const void* layers16, long long layer_stride, int ld, int n_layers, const float* w, float* out, int ldo, int rows, int H,
+                   void* stream);
+int ruart_mix_rows_bwd(const void* layers16, long long layer_stride, int ld, int n_layers, const float* g, int ldg, float* d_w, float* ws,
+                       int rows, int H, void* stream);
+/* Models/Bert/modeling.py:224-250 for training: windows of whole sequences (<= 64 word pieces per block [blk_q0, blk_q1), keys = the same
+ * tokens), f16 [Q | K | V] rows in (Q pre-scaled), f16 context rows out, attention-probability dropout p_drop from `seed`; the backward
+ * takes the context gradient (bf16) and writes [dQ | dK | dV] rows (bf16), recomputing the probabilities. */
+int ruart_attn_train_fwd(const void* qkv16, int ld, void* ctx16, int ldc, int H, int n_heads, int n_blocks, const int* blk_q0,
+                         const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, void* stream);
+int ruart_attn_train_bwd(const void* qkv16, int ld, const void* dctx_bf16, int ldc, void* dqkv_bf16, int ldd, int H, int n_heads, int n_blocks,
+                         const int* blk_q0, const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, void* stream);
 
 /* ---- whole BERT encoder (Models/Bert/modeling.py:585-614, all layer outputs kept as Bert.py:137 needs) ---- */
 typedef struct {

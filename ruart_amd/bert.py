@@ -404,7 +404,15 @@ class Bert(nn.Module):
         if not self.pack:
             raise NotImplementedError("the trainable encoder runs on the packed token stream (bert_no_pack is for the frozen path)")
         state, cfg = self._source
-        self.bert_model = BertModelTrainable(state, cfg, self._device, gemm=str(self.opt.get("bert_train_gemm", "x3")))
+        mode = str(self.opt.get("bert_train_gemm", "x3"))
+        if mode == "16" and cfg["hidden_size"] % 256 == 0 and cfg["intermediate_size"] % 256 == 0:
+            # the whole encoder, forward and backward, as one autograd Function over 16-bit kernels (bert_train16.py)
+            from .bert_train16 import BertModelTrainable16
+            self.bert_model = BertModelTrainable16(state, cfg, self._device)
+        else:
+            # "x3": fp32-class graph (pins parity); "16gemm": the same graph with the two row-parallel products of every projection on
+            # the frozen path's 16-bit MFMA GEMM
+            self.bert_model = BertModelTrainable(state, cfg, self._device, gemm="16" if mode in ("16", "16gemm") else "x3")
         self._source = None
 
     def lock(self):

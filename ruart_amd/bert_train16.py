@@ -1,0 +1,290 @@
+"""Trainable BERT encoder, 16-bit path (``opt['bert_train_gemm'] = '16'`` in a conf without ``LOCK_BERT``).
+
+Same parameters, names and dropout semantics as ``bert_train.BertModelTrainable`` (the fp32-class path that pins parity), but the
+whole encoder - forward and backward - is ONE ``torch.autograd.Function`` over hand-written kernels instead of an autograd graph of
+torch row-wise ops:
+
+  forward   embeddings (torch gathers) -> ``ruart_ln_train_fwd`` (LayerNorm, then dropout: modeling.py:196-199); per layer
+            QKV / attention-output / intermediate / output projections on ``ruart_gemm_16_nt`` (f16 operands, the frozen path's MFMA
+            kernel), ``ruart_attn_train_fwd`` (MFMA flash attention with hash-generated probability dropout),
+            ``ruart_ln_train_fwd`` for dense -> dropout -> + input -> LayerNorm (:260-264, :299-303), ``ruart_gelu16_fwd``;
+            the layer mix of ``SDNet.linear_sum`` (Models/SDNet.py:573-581) is taken inside (``ruart_mix_rows``), so what
+            leaves is ONE (T, H) fp32 stream instead of twelve layer outputs
+  saved     per layer, f16: layer input, QKV rows, context rows, both LayerNorm inputs (+ mean / rstd), the intermediate
+            pre-activations: 0.8 GB per layer at the bench shape (9.3 GB for bert-base) - the GELU output and every dropout mask are
+            recomputed
+  backward  ``ruart_ln_train_bwd`` (residual-stream gradient in fp32, GEMM-bound gradient in bf16 with the dropout multiplier
+            regenerated from the seed; the layer-mix gradient joins the stream there), dX = dY . W on the same MFMA kernel with
+            bf16 operands (weights transposed once per step), dW = dY^T . X as split-K products of transposed bf16 copies
+            (``ruart_transpose16`` + ``ruart_gemm_16_nt_splitk`` + ``ruart_splitk_reduce``), ``ruart_attn_train_bwd``,
+            ``ruart_gelu16_bwd``, ``ruart_colsum_bf16`` for the biases.
+
+Accuracy class: mixed-precision training - f16 activations, bf16 gradients, fp32 accumulation, master weights and residual-stream
+gradient (tests hold every parameter-gradient norm of the reference's backward to 3 %).  Sequences longer than 64 word pieces are
+outside the attention kernels' window: such a batch falls back to the fp32-class path of bert_train.py.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .bert_train import BertModelTrainable
+
+_LAYER_TENSORS = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight", "attention.self.key.bias",
+                  "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight",
+                  "attention.output.dense.bias", "attention.output.LayerNorm.gamma", "attention.output.LayerNorm.beta",
+                  "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
+                  "output.LayerNorm.gamma", "output.LayerNorm.beta")
+_EMB_TENSORS = ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight",
+                "embeddings.LayerNorm.gamma", "embeddings.LayerNorm.beta")
+
+
+def _chk(rc, what):
+    hip.check(rc, what)
+
+
+class _Run:
+    """One forward / backward pass: buffers, launches and the saved activations."""
+
+    def __init__(self, model, packed, training, params):
+        self.m, self.packed, self.training = model, packed, training
+        self.P = dict(zip(model._order, params))
+        self.lib = hip.load()
+        self.dev = packed.ids.device
+        self.T, self.Tp = packed.T, packed.Tp
+        self.H, self.NL, self.nh = model.hidden, model.n_layers, model.n_heads
+        self.I = int(model.cfg["intermediate_size"])
+        self.p_h = model.p_hidden if training else 0.0
+        self.p_a = model.p_attn if training else 0.0
+        # one 31-bit stream id per pass (CPU generator: no device sync); every dropout site adds its own offset
+        self.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.p_h > 0 or self.p_a > 0) else 0
+
+    # -- small launch helpers ----------------------------------------------------------------------------------------------
+    def _new(self, rows, cols, dtype, zero=False):
+        f = torch.zeros if zero else torch.empty
+        return f(rows, cols, dtype=dtype, device=self.dev)
+
+    def _gemm(self, A, W, bias, out, in_dt, act=hip.ACT_NONE, res=None, res_dt=hip.DT_F32):
+        """out (Tp, N) = act(A (Tp, K) . W (N, K)^T + bias) + res"""
+        M, K = A.shape
+        N = W.shape[0]
+        out_dt = hip.DT_F32 if out.dtype == torch.float32 else in_dt
+        _chk(self.lib.ruart_gemm_16_nt(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(bias), hip.ptr(res), N, res_dt, hip.ptr(out), N, out_dt, M, N, K, act,
+                                       in_dt, hip.stream_ptr()), "ruart_gemm_16_nt")
+        return out
+
+    def _seed(self, layer, site):
+        return (self.seed + 7919 * (4 * layer + site + 1)) & 0x7FFFFFFF
+
+    def _ln_fwd(self, x32, res16, g, b, p, seed, post=0):
+        Tp, H = self.Tp, self.H
+        y, pre, st = self._new(Tp, H, torch.float16), self._new(Tp, H, torch.float16), self._new(Tp, 2, torch.float32)
+        _chk(self.lib.ruart_ln_train_fwd(hip.ptr(x32), H, hip.ptr(res16), H, hip.ptr(g), hip.ptr(b), 1e-12, float(p), int(seed), post, hip.ptr(y),
+                                         hip.ptr(pre), hip.ptr(st), H, Tp, H, hip.stream_ptr()), "ruart_ln_train_fwd")
+        return y, pre, st
+
+    def _attention_ok(self):
+        return self.packed.n_long_blocks == 0 and self.packed.max_len <= 64 and self.packed.key_bias is None
+
+    # -- forward -------------------------------------------------------------------------------------------------------------
+    def forward(self, layer_w):
+        P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
+        pk = self.packed
+        st = hip.stream_ptr
+        scale = 1.0 / float(np.sqrt(H // self.nh))
+        ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
+        e = torch.zeros(Tp, H, dtype=torch.float32, device=self.dev)
+        e[:T] = (F.embedding(ids, P["embeddings.word_embeddings.weight"]) + F.embedding(pos, P["embeddings.position_embeddings.weight"])) \
+            + P["embeddings.token_type_embeddings.weight"][0]
+        x16, self.pre_e, self.st_e = self._ln_fwd(e, None, P["embeddings.LayerNorm.gamma"], P["embeddings.LayerNorm.beta"], self.p_h,
+                                                  self._seed(-1, 0), post=1)
+        del e
+        self.x_in = x16                                               # input of layer 0
+        self.layers = torch.empty(NL, Tp, H, dtype=torch.float16, device=self.dev)
+        self.saved = []
+        self.w16 = []
+        blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
+        for l in range(NL):
+            pre = "encoder.layer.%d." % l
+            a = pre + "attention.self."
+            w_qkv = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0)
+            b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0).contiguous()
+            wq16 = w_qkv.to(torch.float16)
+            wo16 = P[pre + "attention.output.dense.weight"].to(torch.float16)
+            w1_16 = P[pre + "intermediate.dense.weight"].to(torch.float16)
+            w2_16 = P[pre + "output.dense.weight"].to(torch.float16)
+            qkv = self._gemm(x16, wq16, b_qkv, self._new(Tp, 3 * H, torch.float16), hip.DT_F16)
+            ctx = self._new(Tp, H, torch.float16, zero=True)
+            _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0), hip.ptr(blk_q1),
+                                          hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_fwd")
+            ao = self._gemm(ctx, wo16, P[pre + "attention.output.dense.bias"], self._new(Tp, H, torch.float32), hip.DT_F16)
+            mid, pre1, st1 = self._ln_fwd(ao, x16, P[pre + "attention.output.LayerNorm.gamma"], P[pre + "attention.output.LayerNorm.beta"],
+                                          self.p_h, self._seed(l, 1))
+            h16 = self._gemm(mid, w1_16, P[pre + "intermediate.dense.bias"], self._new(Tp, I, torch.float16), hip.DT_F16)
+            g16 = self._new(Tp, I, torch.float16)
+            _chk(lib.ruart_gelu16_fwd(hip.ptr(h16), hip.ptr(g16), Tp * I, st()), "ruart_gelu16_fwd")
+            ff = self._gemm(g16, w2_16, P[pre + "output.dense.bias"], ao, hip.DT_F16)           # reuses the fp32 buffer
+            del g16
+            out, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
+                                          self._seed(l, 2))
+            self.layers[l].copy_(out)
+            self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
+            x16 = self.layers[l]
+        self.lw = layer_w.detach().to(torch.float32).contiguous()
+        mixed = torch.empty(Tp, H, dtype=torch.float32, device=self.dev)
+        _chk(lib.ruart_mix_rows(hip.ptr(self.layers), Tp * H, H, NL, hip.ptr(self.lw), hip.ptr(mixed), H, Tp, H, st()), "ruart_mix_rows")
+        return mixed[:T]
+
+    # -- backward ------------------------------------------------------------------------------------------------------------
+    def _dw(self, dY_bf16, X16, x_is_f16, scale=1.0):
+        """(N_out, K_in) fp32 = dY^T . X over the token rows: transposed bf16 copies, split-K MFMA product, ordered slab sum."""
+        lib, Tp = self.lib, self.Tp
+        M, N = dY_bf16.shape[1], X16.shape[1]
+        tA, tB = self.tA[:M * Tp].view(M, Tp), self.tB[:N * Tp].view(N, Tp)
+        _chk(lib.ruart_transpose16(hip.ptr(dY_bf16), M, hip.ptr(tA), Tp, Tp, M, 0, hip.stream_ptr()), "ruart_transpose16")
+        _chk(lib.ruart_transpose16(hip.ptr(X16), N, hip.ptr(tB), Tp, Tp, N, 1 if x_is_f16 else 0, hip.stream_ptr()), "ruart_transpose16")
+        tiles = (M // 256) * (N // 256)
+        nz = max(1, min(256 // tiles, Tp // 128))
+        kchunk = ((Tp + nz - 1) // nz + 127) // 128 * 128
+        nz = (Tp + kchunk - 1) // kchunk
+        part = self.part[:nz * M * N]
+        _chk(lib.ruart_gemm_16_nt_splitk(hip.ptr(tA), Tp, hip.ptr(tB), Tp, hip.ptr(part), N, M, N, Tp, kchunk, hip.DT_BF16, hip.stream_ptr()),
+             "ruart_gemm_16_nt_splitk")
+        dW = torch.empty(M, N, dtype=torch.float32, device=self.dev)
+        _chk(lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, float(scale), 0, hip.stream_ptr()), "ruart_splitk_reduce")
+        return dW
+
+    def _colsum(self, d_bf16):
+        n = d_bf16.shape[1]
+        out = torch.empty(n, dtype=torch.float32, device=self.dev)
+        _chk(self.lib.ruart_colsum_bf16(hip.ptr(d_bf16), n, self.Tp, n, hip.ptr(out), 0, hip.ptr(self.cs_ws), hip.stream_ptr()), "ruart_colsum_bf16")
+        return out
+
+    def _ln_bwd(self, dy, add, add_scale, pre16, stats, gamma, p, seed, post=0):
+        Tp, H = self.Tp, self.H
+        d_res = self._new(Tp, H, torch.float32, zero=True)
+        d_gemm = self._new(Tp, H, torch.bfloat16, zero=True) if not post else None
+        dg, db = torch.empty(H, device=self.dev), torch.empty(H, device=self.dev)
+        _chk(self.lib.ruart_ln_train_bwd(hip.ptr(dy), H, hip.ptr(add), hip.ptr(add_scale), hip.ptr(pre16), H, hip.ptr(stats), hip.ptr(gamma), float(p),
+                                         int(seed), post, hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), 0, hip.ptr(self.ln_ws),
+                                         self.T, H, hip.stream_ptr()), "ruart_ln_train_bwd")
+        return d_res, d_gemm, dg, db
+
+    def backward(self, g_mixed):
+        P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
+        pk = self.packed
+        st = hip.stream_ptr
+        dev = self.dev
+        scale = 1.0 / float(np.sqrt(H // self.nh))
+        grads = {}
+        G = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
+        G[:T] = g_mixed
+        d_lw = torch.empty(NL, dtype=torch.float32, device=dev)
+        ws = torch.empty(512 * NL, dtype=torch.float32, device=dev)
+        _chk(lib.ruart_mix_rows_bwd(hip.ptr(self.layers), Tp * H, H, NL, hip.ptr(G), H, hip.ptr(d_lw), hip.ptr(ws), Tp, H, st()), "ruart_mix_rows_bwd")
+        wmax = max(3 * H, I)
+        self.tA = torch.empty(wmax * Tp, dtype=torch.bfloat16, device=dev)
+        self.tB = torch.empty(wmax * Tp, dtype=torch.bfloat16, device=dev)
+        self.part = torch.empty(max(256, Tp // 128) * 256 * 256 + 4 * wmax * H, dtype=torch.float32, device=dev)
+        self.cs_ws = torch.empty(((Tp + 255) // 256) * wmax, dtype=torch.float32, device=dev)
+        self.ln_ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), dtype=torch.float32, device=dev)
+        dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
+        dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
+        blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
+        for l in range(NL - 1, -1, -1):
+            pre = "encoder.layer.%d." % l
+            a = pre + "attention.self."
+            qkv, ctx, pre1, st1, mid, h16, pre2, st2 = self.saved[l]
+            x16 = self.layers[l - 1] if l > 0 else self.x_in
+            # ---- output LayerNorm (+ the layer-mix gradient of this layer's output) and the FFN
+            d_res2, d_g2, dg2, db2 = self._ln_bwd(dX, G, self.lw[l:l + 1], pre2, st2, P[pre + "output.LayerNorm.gamma"], self.p_h, self._seed(l, 2))
+            grads[pre + "output.LayerNorm.gamma"], grads[pre + "output.LayerNorm.beta"] = dg2, db2
+            grads[pre + "output.dense.bias"] = self._colsum(d_g2)
+            g16 = self._new(Tp, I, torch.float16)
+            _chk(lib.ruart_gelu16_fwd(hip.ptr(h16), hip.ptr(g16), Tp * I, st()), "ruart_gelu16_fwd")
+            grads[pre + "output.dense.weight"] = self._dw(d_g2, g16, True)
+            del g16
+            w2t = P[pre + "output.dense.weight"].t().contiguous().to(torch.bfloat16)            # (I, H): dX = dY . W as an NT product
+            d_g = self._gemm(d_g2, w2t, None, self._new(Tp, I, torch.bfloat16), hip.DT_BF16)
+            d_h = self._new(Tp, I, torch.bfloat16)
+            _chk(lib.ruart_gelu16_bwd(hip.ptr(d_g), hip.ptr(h16), hip.ptr(d_h), Tp * I, st()), "ruart_gelu16_bwd")
+            del d_g
+            grads[pre + "intermediate.dense.bias"] = self._colsum(d_h)
+            grads[pre + "intermediate.dense.weight"] = self._dw(d_h, mid, True)
+            w1t = P[pre + "intermediate.dense.weight"].t().contiguous().to(torch.bfloat16)      # (H, I)
+            d_mid = self._gemm(d_h, w1t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res2)
+            del d_h, d_res2
+            # ---- attention-output LayerNorm, output projection, attention, QKV projection
+            d_res1, d_g1, dg1, db1 = self._ln_bwd(d_mid, None, None, pre1, st1, P[pre + "attention.output.LayerNorm.gamma"], self.p_h, self._seed(l, 1))
+            grads[pre + "attention.output.LayerNorm.gamma"], grads[pre + "attention.output.LayerNorm.beta"] = dg1, db1
+            grads[pre + "attention.output.dense.bias"] = self._colsum(d_g1)
+            grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, ctx, True)
+            wot = P[pre + "attention.output.dense.weight"].t().contiguous().to(torch.bfloat16)
+            d_ctx = self._gemm(d_g1, wot, None, self._new(Tp, H, torch.bfloat16), hip.DT_BF16)
+            _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0),
+                                          hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_bwd")
+            db = self._colsum(dqkv)
+            # the key bias shifts every score of a query row by the same q . b_k, which the softmax ignores: its gradient is
+            # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise), so it is
+            # not summed up out of rounded dK rows
+            grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[H:2 * H]), db[2 * H:]
+            dW = self._dw(dqkv, x16, True)
+            grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = dW[:H] * scale, dW[H:2 * H], dW[2 * H:]
+            w_qkv_t = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0).t().contiguous().to(torch.bfloat16)
+            dX = self._gemm(dqkv, w_qkv_t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res1)
+            self.saved[l] = None                                                          # release this layer's activations
+        # ---- embeddings: dropout(LayerNorm(word + position + type))
+        d_e, _, dge, dbe = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
+        grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe
+        d_e = d_e[:T]
+        ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
+        grads["embeddings.word_embeddings.weight"] = torch.zeros_like(P["embeddings.word_embeddings.weight"]).index_add_(0, ids, d_e)
+        grads["embeddings.position_embeddings.weight"] = torch.zeros_like(P["embeddings.position_embeddings.weight"]).index_add_(0, pos, d_e)
+        gt = torch.zeros_like(P["embeddings.token_type_embeddings.weight"])
+        gt[0] = d_e.sum(0)
+        grads["embeddings.token_type_embeddings.weight"] = gt
+        self.tA = self.tB = self.part = None
+        return d_lw, grads
+
+
+class _Encoder16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, packed, training, layer_w, *params):
+        run = _Run(model, packed, training, params)
+        ctx.run = run
+        ctx.lw_dtype = layer_w.dtype
+        return run.forward(layer_w)
+
+    @staticmethod
+    def backward(ctx, g_mixed):
+        run = ctx.run
+        d_lw, grads = run.backward(g_mixed.contiguous().to(torch.float32))
+        ctx.run = None
+        return (None, None, None, d_lw.to(ctx.lw_dtype)) + tuple(grads.get(n) for n in run.m._order)
+
+
+class BertModelTrainable16(BertModelTrainable):
+    """``forward_mixed(packed, layer_w, training)`` -> (T, H) fp32 = sum_l layer_w[l] * layer_l, differentiable w.r.t. ``layer_w`` and
+    every encoder parameter; ``forward`` (all layer outputs, the fp32-class graph of the parent) stays available."""
+
+    fused_mix = True
+
+    def __init__(self, state, cfg, device):
+        super().__init__(state, cfg, device, gemm="x3")
+        if self.hidden % 256 or int(cfg["intermediate_size"]) % 256:
+            raise ValueError("the 16-bit trainable encoder takes hidden / intermediate sizes that are multiples of 256")
+        self._order = [n for n in _EMB_TENSORS] + ["encoder.layer.%d.%s" % (l, t) for l in range(self.n_layers) for t in _LAYER_TENSORS]
+        missing = [n for n in self._order if n not in self._p]
+        if missing:
+            raise ValueError("checkpoint lacks encoder tensors: %s" % missing[:3])
+
+    def supports(self, packed):
+        return packed.n_long_blocks == 0 and packed.max_len <= 64 and packed.bias_host is None and packed.Tp % 256 == 0
+
+    def forward_mixed(self, packed, layer_w, training=False):
+        if not self.supports(packed):
+            from .bert_train import mix_layers
+            return mix_layers(layer_w, self.forward(packed, training=training))
+        return _Encoder16.apply(self, packed, training, layer_w, *[self._p[n] for n in self._order])

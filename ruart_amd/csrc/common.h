@@ -139,3 +139,19 @@ __device__ __forceinline__ void store_split4(f16_t* p16, unsigned char* p8, int 
   *reinterpret_cast<unsigned*>(p8) = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
   *reinterpret_cast<unsigned*>(p8 + hi_off) = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
 }
+
+// ---- dropout without stored masks: a counter-based hash of (stream seed, element index) decides every element, so the backward
+// pass regenerates the forward's mask (training kernels of the encoder, bert_train_*.hip)
+__device__ __forceinline__ unsigned hash32(unsigned x) {       // "lowbias32": a well-mixed 32-bit integer hash
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// multiplier of element `idx` under dropout(p) with stream `seed`: 0 or keep_inv = 1/(1-p)
+__device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, float p, float keep_inv) {
+  const float u = (float)(hash32(idx * 0x9E3779B9u + seed) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? keep_inv : 0.f;
+}

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk
 #ifdef RUART_P8_STAMPS
                                                            , unsigned long long* __restrict__ stamps
 #endif
@@ -306,6 +306,15 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
 #define P8_STAMP(i)
 #endif
   P8_STAMP(0);
+  if (kchunk > 0) {
+    // split-K form (weight gradients: small output, K = all token rows): slice blockIdx.y multiplies columns [z * kchunk, ...) of
+    // both operands and writes its own fp32 slab z of C; ruart_splitk_reduce adds the slabs in slice order
+    const int z = blockIdx.y;
+    A += (size_t)z * kchunk;
+    W += (size_t)z * kchunk;
+    K = min(kchunk, K - z * kchunk);
+    C = reinterpret_cast<float*>(C) + (size_t)z * M * ldc;
+  }
   constexpr int kHalf = 128 * BK * 2;            // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -699,10 +708,10 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     (void)done;
 #ifdef RUART_P8_STAMPS
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, g_p8_stamps);
+                       g_tile_order, 0, g_p8_stamps);
 #else
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order);
+                       g_tile_order, 0);
 #endif
   } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
@@ -756,6 +765,39 @@ extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, 
     rc = launch_gemm16<f16_t>(A, lda, W, ldw, bias, residual, ldr, res, C, ldc, of, M, N, K, act, (hipStream_t)stream);
   ruart_prof_end_(rec, (hipStream_t)stream);
   return rc;
+}
+
+// Split-K form of the 16-bit NT product: part[z] (M x N fp32, row stride ldc, slabs M * ldc floats apart) = A[:, z*kchunk : ...] .
+// W[:, z*kchunk : ...]^T for z < ceil(K / kchunk).  For the encoder's weight gradients dW = dY^T . X (M, N = layer widths, K = token
+// rows): a 768 x 768 output is 9 tiles, so the reduction is cut into ~28 slices to fill the 256 CUs.
+template <typename T16>
+static void launch_splitk(const void* A, int lda, const void* W, int ldw, float* part, int ldc, int M, int N, int K, int kchunk, hipStream_t s) {
+  constexpr int lds = 2 * 2 * BM4 * BK * 2;
+  auto kern = gemm_16_nt_256p8<T16, true, 0, 0>;
+  static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)done;
+  const int nz = (K + kchunk - 1) / kchunk;
+#ifdef RUART_P8_STAMPS
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (unsigned long long*)nullptr);
+#else
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk);
+#endif
+}
+
+extern "C" int ruart_gemm_16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* part, int ldc, int M, int N, int K, int kchunk,
+                                       int in_dtype, void* stream) {
+  RUART_ENTRY();
+  if (M % BM4 || N % BN4 || K % 128 || kchunk <= 0 || kchunk % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || !part) return (int)hipErrorInvalidValue;
+  if (in_dtype == RUART_DT_BF16)
+    launch_splitk<bf16_t>(A, lda, W, ldw, part, ldc, M, N, K, kchunk, (hipStream_t)stream);
+  else if (in_dtype == RUART_DT_F16)
+    launch_splitk<f16_t>(A, lda, W, ldw, part, ldc, M, N, K, kchunk, (hipStream_t)stream);
+  else
+    return (int)hipErrorInvalidValue;
+  RUART_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual,

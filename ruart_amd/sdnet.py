@@ -384,9 +384,15 @@ class SDNet(nn.Module):
             L.mask_bank.begin_step(dev)
 
         # ---- BERT: one packed pass, then pooled + mixed per group --------------------------------------------
-        layers = self.Bert.layers_for(bi.packed)
-        self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
         lw = self._layer_weights()
+        trainable = getattr(self.Bert, "bert_model", None) is not None
+        fused_mix = trainable and getattr(self.Bert.bert_model, "fused_mix", False)
+        if fused_mix:                        # 16-bit trainable encoder: the layer mix happens inside its autograd Function
+            layers = None
+            mixed = self.Bert.bert_model.forward_mixed(bi.packed, lw, training=self.training)
+        else:
+            layers = self.Bert.layers_for(bi.packed)
+        self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
         H = self.Bert.weights.hidden
         Bq, Q = q_list[opt["q_emb_initial"]].shape
         q_mask = q_list[opt["q_emb_initial"] + "_mask"].to(dev).to(torch.uint8)    # once: the attention kernels take uint8
@@ -399,8 +405,10 @@ class SDNet(nn.Module):
         use_streams = self._use_streams()
         s_q, s_od = self._side_streams(dev) if use_streams else (main, main)
 
-        trainable = getattr(self.Bert, "bert_model", None) is not None
-        mixed = bert_train.mix_layers(lw, layers) if trainable else None     # once for the three groups
+        if trainable and not fused_mix:
+            mixed = bert_train.mix_layers(lw, layers)                         # once for the three groups
+        elif not trainable:
+            mixed = None
 
         def pooled(g):
             s_, l_, dst, rows = bi.spans[g]

@@ -480,7 +480,7 @@ def _unlocked(z, precision, **extra):
     return net.to("cuda:0"), opt
 
 
-@pytest.mark.parametrize("precision,tol_p,tol_g", [("fp32", 5e-5, 2e-3), ("x3", 2e-4, 3e-2), ("x3+16", 3e-3, 1.5e-1)])
+@pytest.mark.parametrize("precision,tol_p,tol_g", [("fp32", 5e-5, 2e-3), ("x3", 2e-4, 3e-2), ("x3+16gemm", 3e-3, 1.5e-1), ("x3+16", 3e-3, 3e-2)])
 def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_g):
     """Conf without LOCK_BERT: the trainable encoder (bert_train.py) under the reference's parameter names; scores, loss and the
     gradient norm of every parameter - 197 BERT tensors included - against the reference's backward, plus gradient slices.
@@ -490,8 +490,9 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
     element-wise, identical with a locked encoder: tools-level check in DESIGN.md section 2), so only norms are held, at 3 %."""
     import ruart_amd.layers as L
     z = np.load(os.path.join(golden_dir, "sdnet_e2e_unlocked.npz"))
-    # "x3+16": the encoder's x W^T in f16 and dY W in bf16 on the MFMA GEMM of the frozen path (opt['bert_train_gemm'] = '16')
-    net, opt = _unlocked(z, precision.split("+")[0], **({"bert_train_gemm": "16"} if precision.endswith("+16") else {}))
+    # "x3+16": the 16-bit trainable encoder (bert_train16.py: one autograd Function over f16 / bf16 kernels, opt['bert_train_gemm'] =
+    # '16'), held to the 3 % of the round-1 verdict; "x3+16gemm": the fp32-class graph with 16-bit MFMA products for x W^T and dY W
+    net, opt = _unlocked(z, precision.split("+")[0], **({"bert_train_gemm": precision.split("+")[1]} if "+" in precision else {}))
     names = dict(net.named_parameters())
     assert set(z["grad_names"].tolist()) == set(names), set(z["grad_names"].tolist()) ^ set(names)   # same state-dict surface
     q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=12, n_ocr=16, n_od=6, bert_vocab=2000,

@@ -1,0 +1,255 @@
+"""Kernels of the trainable encoder's 16-bit path (csrc/bert_train_kernels.hip, bert_train_attn.hip, the split-K form of the
+encoder GEMM) through the C ABI against plain torch fp32 / autograd references of the same ops (Models/Bert/modeling.py:155-168
+LayerNorm, :52-57 GELU, :224-250 self-attention, :260-264 / :299-303 dense -> dropout -> residual -> LayerNorm).
+
+Tolerances: activations travel in f16 (11 significant bits) and GEMM-bound gradients in bf16 (8 bits); every comparison states its
+bound next to the assertion."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ruart_amd import hip                      # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _st():
+    return hip.stream_ptr()
+
+
+def _ln_fwd(lib, x, res, gamma, beta, p, seed, post):
+    R, H = x.shape
+    y = torch.empty(R, H, dtype=torch.float16, device=DEV)
+    pre = torch.empty(R, H, dtype=torch.float16, device=DEV)
+    stats = torch.empty(R, 2, dtype=torch.float32, device=DEV)
+    rc = lib.ruart_ln_train_fwd(hip.ptr(x), H, hip.ptr(res), H, hip.ptr(gamma), hip.ptr(beta), 1e-12, float(p), int(seed), int(post),
+                                hip.ptr(y), hip.ptr(pre), hip.ptr(stats), H, R, H, _st())
+    assert rc == 0
+    return y, pre, stats
+
+
+def _ln_bwd(lib, dy, pre, stats, gamma, p, seed, post, add=None, add_scale=None):
+    R, H = dy.shape
+    d_res = torch.empty(R, H, dtype=torch.float32, device=DEV)
+    d_gemm = torch.empty(R, H, dtype=torch.bfloat16, device=DEV)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), device=DEV)
+    rc = lib.ruart_ln_train_bwd(hip.ptr(dy), H, hip.ptr(add), hip.ptr(add_scale), hip.ptr(pre), H, hip.ptr(stats), hip.ptr(gamma), float(p),
+                                int(seed), int(post), hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), R, H, _st())
+    assert rc == 0
+    return d_res, d_gemm, dg, db
+
+
+@pytest.mark.parametrize("R,H", [(37, 768), (1030, 1024), (5, 128)])
+def test_ln_train_fwd_bwd_vs_autograd(R, H):
+    lib = hip.load()
+    g = torch.Generator().manual_seed(R + H)
+    x = torch.randn(R, H, generator=g).to(DEV)
+    res = torch.randn(R, H, generator=g).half().to(DEV)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV)
+    dy = torch.randn(R, H, generator=g).to(DEV)
+    add = torch.randn(R, H, generator=g).to(DEV)
+    a = torch.tensor([0.37], device=DEV)
+    y, pre, stats = _ln_fwd(lib, x, res, gamma, beta, 0.0, 1, 0)
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr + res.float(), (H,), gr, br, 1e-12)
+    assert float((y.float() - ref).abs().max()) < 4e-3                          # f16 output of O(1) values
+    ref.backward(dy + 0.37 * add)
+    d_res, d_gemm, dg, db = _ln_bwd(lib, dy, pre, stats, gamma, 0.0, 1, 0, add=add, add_scale=a)
+    scale = float(xr.grad.abs().max())
+    assert float((d_res - xr.grad).abs().max()) < 3e-3 * scale                  # the LayerNorm input is re-read from its f16 copy
+    assert float((d_gemm.float() - xr.grad).abs().max()) < 1e-2 * scale         # bf16 copy
+    assert float((dg - gr.grad).abs().max()) < 3e-3 * float(gr.grad.abs().max()) + 1e-3
+    assert float((db - br.grad).abs().max()) < 1e-4 * float(br.grad.abs().max()) + 1e-4
+
+
+def test_ln_train_dropout_masks_regenerate():
+    """pre-LN dropout (post = 0) and the embeddings' post-LN dropout (post = 1): the backward regenerates the forward's mask from the
+    seed; a different seed gives a different mask; the kept fraction is 1 - p."""
+    lib = hip.load()
+    R, H, p = 300, 768, 0.1
+    gamma, beta = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    x = torch.full((R, H), 2.0, device=DEV)
+    _, pre, stats = _ln_fwd(lib, x, None, gamma, beta, p, 77, 0)
+    mask = pre.float() / 2.0                                                     # 0 or 1 / (1 - p)
+    kept = float((mask > 0).float().mean())
+    assert abs(kept - (1 - p)) < 0.01 and float((mask[mask > 0] - 1 / (1 - p)).abs().max()) < 2e-3
+    x2 = torch.randn(R, H, device=DEV)
+    _, pre2, stats2 = _ln_fwd(lib, x2, None, gamma, beta, p, 77, 0)
+    dy = torch.randn(R, H, device=DEV)
+    d_res, d_gemm, _, _ = _ln_bwd(lib, dy, pre2, stats2, gamma, p, 77, 0)
+    assert float((d_gemm.float() - d_res * mask).abs().max()) < 1e-2 * float(d_res.abs().max()) * 1.2     # same mask, bf16 rounding
+    _, pre3, _ = _ln_fwd(lib, x, None, gamma, beta, p, 78, 0)
+    assert float(((pre3 > 0) != (pre > 0)).float().mean()) > 0.1                # another stream
+    # post = 1: y = dropout(LN(x)); with gamma = 1, beta = 0 the kept entries equal the normalised input * 1/(1-p)
+    y, pre4, stats4 = _ln_fwd(lib, x2, None, gamma, beta, p, 5, 1)
+    ln = torch.nn.functional.layer_norm(x2, (H,), None, None, 1e-12)
+    m = (y != 0)
+    assert abs(float(m.float().mean()) - (1 - p)) < 0.01
+    assert float((y.float()[m] - ln[m] / (1 - p)).abs().max()) < 5e-3
+    d_in, _, _, _ = _ln_bwd(lib, dy, pre4, stats4, gamma, p, 5, 1)
+    xr = x2.clone().requires_grad_()
+    (torch.nn.functional.layer_norm(xr, (H,), None, None, 1e-12) * m.float() / (1 - p) * dy).sum().backward()
+    assert float((d_in - xr.grad).abs().max()) < 3e-3 * float(xr.grad.abs().max())
+
+
+def test_gelu16_colsum_transpose_mix():
+    lib = hip.load()
+    g = torch.Generator().manual_seed(3)
+    R, N = 1000, 3072
+    h = (2 * torch.randn(R, N, generator=g)).half().to(DEV)
+    out = torch.empty_like(h)
+    assert lib.ruart_gelu16_fwd(hip.ptr(h), hip.ptr(out), R * N, _st()) == 0
+    hr = h.float().requires_grad_()
+    ref = torch.nn.functional.gelu(hr)
+    assert float((out.float() - ref).abs().max()) < 4e-3
+    dg = torch.randn(R, N, generator=g).bfloat16().to(DEV)
+    dh = torch.empty_like(dg)
+    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh), R * N, _st()) == 0
+    ref.backward(dg.float())
+    assert float((dh.float() - hr.grad).abs().max()) < 2e-2 * float(hr.grad.abs().max())      # bf16 in, bf16 out
+    # column sums (bias gradients)
+    ws = torch.empty(((R + 255) // 256) * N, device=DEV)
+    cs = torch.zeros(N, device=DEV)
+    assert lib.ruart_colsum_bf16(hip.ptr(dg), N, R, N, hip.ptr(cs), 0, hip.ptr(ws), _st()) == 0
+    assert float((cs - dg.float().sum(0)).abs().max()) < 1e-3 * float(dg.float().sum(0).abs().max()) + 1e-3
+    assert lib.ruart_colsum_bf16(hip.ptr(dg), N, R, N, hip.ptr(cs), 1, hip.ptr(ws), _st()) == 0
+    assert float((cs - 2 * dg.float().sum(0)).abs().max()) < 2e-3 * float(dg.float().sum(0).abs().max()) + 2e-3
+    # transpose
+    t = torch.empty(N, 1024, dtype=torch.float16, device=DEV).zero_()
+    assert lib.ruart_transpose16(hip.ptr(h), N, hip.ptr(t), 1024, R, N, 0, _st()) == 0
+    assert torch.equal(t[:, :R], h.t()) and float(t[:, R:].abs().max()) == 0.0
+    tb = torch.empty(N, 1024, dtype=torch.bfloat16, device=DEV).zero_()
+    assert lib.ruart_transpose16(hip.ptr(h), N, hip.ptr(tb), 1024, R, N, 1, _st()) == 0         # f16 -> bf16 on the way
+    assert torch.equal(tb[:, :R], h.float().bfloat16().t())
+    # layer mix and its weight gradient
+    NL, H = 12, 768
+    layers = torch.randn(NL, R, H, generator=g).half().to(DEV)
+    w = torch.randn(NL, generator=g).to(DEV)
+    mixed = torch.empty(R, H, device=DEV)
+    assert lib.ruart_mix_rows(hip.ptr(layers), R * H, H, NL, hip.ptr(w), hip.ptr(mixed), H, R, H, _st()) == 0
+    ref = (layers.float() * w.view(-1, 1, 1)).sum(0)
+    assert float((mixed - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    gm = torch.randn(R, H, generator=g).to(DEV)
+    dw = torch.empty(NL, device=DEV)
+    ws2 = torch.empty(512 * NL, device=DEV)
+    assert lib.ruart_mix_rows_bwd(hip.ptr(layers), R * H, H, NL, hip.ptr(gm), H, hip.ptr(dw), hip.ptr(ws2), R, H, _st()) == 0
+    refw = (layers.float() * gm.unsqueeze(0)).sum((1, 2))
+    assert float((dw - refw).abs().max()) < 1e-4 * float(refw.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,kchunk", [(768, 768, 43008, 1536), (2304, 768, 5120, 2048), (256, 3072, 1280, 512)])
+def test_weight_gradient_splitk(M, N, K, kchunk):
+    """dW = dY^T . X as a split-K NT product of the transposed 16-bit operands, slabs summed by ruart_splitk_reduce."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(M + K)
+    rows = K - 100                                                                # K = token rows padded to 256; the pad rows are zero
+    dY = torch.zeros(K, M).bfloat16()
+    X = torch.zeros(K, N).bfloat16()
+    dY[:rows] = (torch.randn(rows, M, generator=g) * 1e-3).bfloat16()
+    X[:rows] = torch.randn(rows, N, generator=g).bfloat16()
+    dYd, Xd = dY.to(DEV), X.to(DEV)
+    dYt = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    Xt = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+    assert lib.ruart_transpose16(hip.ptr(dYd), M, hip.ptr(dYt), K, K, M, 0, _st()) == 0
+    assert lib.ruart_transpose16(hip.ptr(Xd), N, hip.ptr(Xt), K, K, N, 0, _st()) == 0
+    nz = (K + kchunk - 1) // kchunk
+    part = torch.empty(nz, M, N, device=DEV)
+    assert lib.ruart_gemm_16_nt_splitk(hip.ptr(dYt), K, hip.ptr(Xt), K, hip.ptr(part), N, M, N, K, kchunk, hip.DT_BF16, _st()) == 0
+    dW = torch.full((M, N), 7.0, device=DEV)
+    assert lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, 0.5, 0, _st()) == 0
+    ref = 0.5 * (dY.double().t() @ X.double())
+    assert float((dW.double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-7       # exact bf16 operands, fp32 sums
+    assert lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, 0.5, 1, _st()) == 0  # accumulate form
+    assert float((dW.double().cpu() - 2 * ref).abs().max()) < 4e-5 * float(ref.abs().max()) + 1e-7
+
+
+def _attn_case(g, lens, heads):
+    """packed tokens of the given sequence lengths, windows of whole sequences (<= 64 tokens)"""
+    H = heads * 64
+    T = sum(lens)
+    qkv = torch.randn(T, 3 * H, generator=g)
+    qkv[:, :H] *= 0.125 * 3                                                        # queries arrive pre-scaled; *3: peaked rows too
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    q0, q1, s = [], [], 0
+    while s < len(lens):
+        e = s
+        while e < len(lens) and cu[e + 1] - cu[s] <= 64:
+            e += 1
+        q0.append(cu[s]); q1.append(cu[e]); s = e
+    tok_lo = np.repeat(cu[:-1], lens)
+    return qkv, torch.tensor(q0, dtype=torch.int32), torch.tensor(q1, dtype=torch.int32), torch.tensor(tok_lo, dtype=torch.int32), cu
+
+
+def _attn_ref(qkv, cu, heads):
+    H = heads * 64
+    T = qkv.shape[0]
+    out = torch.zeros(T, H, dtype=qkv.dtype)
+    for a, b in zip(cu[:-1], cu[1:]):
+        q, k, v = [qkv[a:b, i * H:(i + 1) * H].view(b - a, heads, 64).transpose(0, 1) for i in range(3)]
+        p = torch.softmax(q @ k.transpose(1, 2), -1)
+        out[a:b] = (p @ v).transpose(0, 1).reshape(b - a, H)
+    return out
+
+
+def test_attention_train_fwd_bwd_vs_autograd():
+    lib = hip.load()
+    g = torch.Generator().manual_seed(11)
+    heads = 3
+    H = heads * 64
+    lens = [5, 1, 64, 3, 8, 30, 30, 7, 50, 2, 2, 2, 63]
+    qkv, q0, q1, tok_lo, cu = _attn_case(g, lens, heads)
+    T = qkv.shape[0]
+    q16 = qkv.half()
+    qd, q0d, q1d, lod = q16.to(DEV), q0.to(DEV), q1.to(DEV), tok_lo.to(DEV)
+    ctx = torch.zeros(T, H, dtype=torch.float16, device=DEV)
+    assert lib.ruart_attn_train_fwd(hip.ptr(qd), 3 * H, hip.ptr(ctx), H, H, heads, len(q0), hip.ptr(q0d), hip.ptr(q1d), hip.ptr(lod), 0.0, 0, _st()) == 0
+    xr = q16.double().requires_grad_()
+    ref = _attn_ref(xr, cu, heads)
+    assert float((ctx.double().cpu() - ref).abs().max()) < 4e-3                    # f16 operands / output, O(1) values
+    dO = torch.randn(T, H, generator=g) * 1e-3
+    dOb = dO.bfloat16()
+    ref.backward(dOb.double())
+    dqkv = torch.zeros(T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dOb.to(DEV)), H, hip.ptr(dqkv), 3 * H, H, heads, len(q0), hip.ptr(q0d), hip.ptr(q1d),
+                                    hip.ptr(lod), 0.0, 0, _st()) == 0
+    got, want = dqkv.double().cpu(), xr.grad
+    for name, sl in (("dQ", slice(0, H)), ("dK", slice(H, 2 * H)), ("dV", slice(2 * H, 3 * H))):
+        e = float((got[:, sl] - want[:, sl]).abs().max()) / float(want[:, sl].abs().max())
+        rel = float((got[:, sl] - want[:, sl]).norm() / want[:, sl].norm())
+        assert e < 4e-2 and rel < 1.5e-2, (name, e, rel)                           # bf16 operands: 8 significant bits
+
+
+def test_attention_train_dropout_is_consistent():
+    """With probability dropout the output is linear in V for a fixed mask: <dO, O> == <dV, V> holds exactly when the backward
+    regenerates the forward's mask; the share of dropped probabilities is p."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(12)
+    heads, p = 2, 0.1
+    H = heads * 64
+    qkv, q0, q1, tok_lo, cu = _attn_case(g, [40, 24, 64, 9, 33, 31], heads)
+    T = qkv.shape[0]
+    # values that are exact in bf16 and f16, so that the two kernels see the same V
+    qkv[:, 2 * H:] = torch.randint(-4, 5, (T, H), generator=g).float() / 4
+    qd, q0d, q1d, lod = qkv.half().to(DEV), q0.to(DEV), q1.to(DEV), tok_lo.to(DEV)
+    ctx = torch.zeros(T, H, dtype=torch.float16, device=DEV)
+    ctx0 = torch.zeros(T, H, dtype=torch.float16, device=DEV)
+    args = (H, heads, len(q0), hip.ptr(q0d), hip.ptr(q1d), hip.ptr(lod))
+    assert lib.ruart_attn_train_fwd(hip.ptr(qd), 3 * H, hip.ptr(ctx), H, *args, p, 1234, _st()) == 0
+    assert lib.ruart_attn_train_fwd(hip.ptr(qd), 3 * H, hip.ptr(ctx0), H, *args, 0.0, 1234, _st()) == 0
+    assert float((ctx.float() - ctx0.float()).abs().max()) > 1e-2                 # the mask does something
+    dO = (torch.randint(-4, 5, (T, H), generator=g).float() / 64).bfloat16()
+    dqkv = torch.zeros(T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv), 3 * H, *args, p, 1234, _st()) == 0
+    lhs = float((dO.double() * ctx.double().cpu()).sum())
+    rhs = float((dqkv[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
+    assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), 1e-3), (lhs, rhs)                 # same mask on both sides (f16 / bf16 rounding only)
+    dqkv2 = torch.zeros_like(dqkv)
+    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv2), 3 * H, *args, p, 99, _st()) == 0
+    rhs2 = float((dqkv2[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
+    assert abs(lhs - rhs2) > 5 * abs(lhs - rhs)                                    # another seed: another mask
