@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on one GPU: a world-size-1 RCCL process group, so the gradient hooks, the bucketed all-reduce and "
                          "the barriers of the N > 1 path all run")
-    ap.add_argument("--train-gemm", default="x3", choices=["x3", "16"], help="with --unlock-bert: GEMM form of the trainable encoder")
+    ap.add_argument("--train-gemm", default="16", choices=["x3", "16", "16gemm"], help="with --unlock-bert: GEMM form of the trainable encoder")
     ap.add_argument("--unlock-bert", action="store_true",
                     help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
     ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
@@ -423,7 +423,8 @@ def main():
                "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
-               "dtype": "f32 storage, split-bf16 MFMA" if a.unlock_bert and a.precision != "fp32" else DTYPE[a.precision],
+               "dtype": ("f16 activations / bf16 gradients, fp32 accumulate and master weights" if a.train_gemm == "16"
+                         else "f32 storage, split-bf16 MFMA") if a.unlock_bert and a.precision != "fp32" else DTYPE[a.precision],
                "data": "synthetic",
                "config": {"workload": "RUArt training step, synthetic ST-VQA-shaped batch: B=%d/GPU, q=30 words, %d OCR items, "
                                       "%d objects, %s %s, SDNet trunk fwd+bwd, Adamax"
@@ -431,7 +432,8 @@ def main():
                                          "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
                           "parallelism": "dp%d" % world, "mode": a.mode},
-               "roofline": roof, "parity": parity, "bert512": b512}
+               "roofline": roof, "parity": parity, "bert512": b512,
+               "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle) ...")
             out["cpu_baseline"] = cpu_baseline(opt, cfg, a.cpu_samples)

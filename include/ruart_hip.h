@@ -55,10 +55,20 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
  * M % 256 == 0, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                       const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, void* stream);
+/* Training forward of the intermediate dense (Models/Bert/modeling.py:287-288): G16 = gelu(A . W^T + bias) and the pre-activation H16, both
+ * (M x N) in the operands' 16-bit type, row stride ldc.  M, N % 256 == 0, K % 128 == 0. */
+int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* H16, void* G16, int ldc, int M, int N, int K,
+                           int in_dtype, void* stream);
 /* Split-K form for weight gradients (dW = dY^T . X with both operands given K-contiguous, i.e. transposed: ruart_transpose16):
  * part[z] (M x N fp32, row stride ldc; slabs M * ldc floats apart) = A[:, z kchunk ...] . W[:, z kchunk ...]^T, z < ceil(K / kchunk);
  * sum the slabs with ruart_splitk_reduce.  M, N % 256 == 0, K % 128 == 0, kchunk % 128 == 0. */
 int ruart_gemm_16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* part, int ldc, int M, int N, int K, int kchunk,
+                            int in_dtype, void* stream);
+/* The same product straight from the layouts the backward pass holds - no transposes: part[z] (M x N fp32) = P[zT..][:, :M]^T . Q[zT..][:, :N]
+ * over token rows z * tchunk .. of P (T x M, row stride ldp) and Q (T x N, row stride ldq), both bf16 or both f16
+ * (autograd's grad_output.t().mm(input) of the nn.Linear sites, Models/Bert/modeling.py:225-227, :261, :287, :300).
+ * M, N % 256 == 0, T % 128 == 0, tchunk % 128 == 0; rows past the real tokens must be zero in at least one operand and finite in both. */
+int ruart_gemm_16_tn_splitk(const void* P, int ldp, const void* Q, int ldq, float* part, int ldc, int M, int N, int T, int tchunk,
                             int in_dtype, void* stream);
 /* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
 int ruart_gemm_set_tile_order(int group_m);
@@ -131,15 +141,22 @@ int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n,
 int ruart_ln_train_fwd(const float* x, int ldx, const void* res16, int ldr, const float* gamma, const float* beta, float eps, float p,
                        unsigned seed, int post, void* y16, void* pre16, float* stats, int ld16, int rows, int H, void* stream);
 /* backward: dy fp32 (+ add_scale[0] * add when add != NULL) -> d_res fp32 (gradient at the LayerNorm input: the residual path) and, post = 0,
- * d_gemm bf16 (the same times the dropout multiplier: gradient at the dense output); d_gamma / d_beta (H) written or accumulated.
+ * d_gemm bf16 (the same times the dropout multiplier: gradient at the dense output); d_gamma / d_beta (H) and, when not NULL and post = 0,
+ * d_bias (H: column sums of the unrounded d_gemm = bias gradient of the dense layer in front) written or accumulated.
  * ws: ruart_ln_train_bwd_ws_floats(H) floats. */
 size_t ruart_ln_train_bwd_ws_floats(int H);
 int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, const float* add_scale, const void* pre16, int ld16, const float* stats,
                        const float* gamma, float p, unsigned seed, int post, float* d_res, int ldd, void* d_gemm_bf16, int ldg,
-                       float* d_gamma, float* d_beta, int accumulate, float* ws, int rows, int H, void* stream);
-/* Models/Bert/modeling.py:52-57: g = gelu(h) (f16 -> f16) and d_h = d_g * gelu'(h) (bf16, f16 -> bf16); n elements, n % 4 == 0 */
+                       float* d_gamma, float* d_beta, float* d_bias, int accumulate, float* ws, int rows, int H, void* stream);
+/* Models/Bert/modeling.py:52-57: g = gelu(h) (f16 -> f16; n elements, n % 4 == 0) */
 int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* stream);
-int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, long long n, void* stream);
+/* ... and its backward over the (rows x cols) intermediate in one pass: dh (bf16) = dg (bf16) * gelu'(h); g_bf16 (optional) = gelu(h) again
+ * as the bf16 operand of the next weight gradient; d_bias (optional, cols) = column sums of the unrounded dh.
+ * ws: ruart_gelu16_bwd_ws_floats(rows, cols) floats when d_bias is given. */
+size_t ruart_gelu16_bwd_ws_floats(int rows, int cols);
+int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, void* g_bf16, float* d_bias, float* ws, int rows, int cols, void* stream);
+/* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
+int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */
 int ruart_colsum_bf16(const void* x_bf16, int ld, int rows, int cols, float* out, int accumulate, float* ws, void* stream);
 /* out (cols x rows, row stride ldo) = in^T for a 16-bit matrix (rows x cols, row stride ldi); f16_to_bf16 != 0 converts f16 elements

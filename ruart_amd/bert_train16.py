@@ -63,8 +63,11 @@ class _Run:
 
     # -- small launch helpers ----------------------------------------------------------------------------------------------
     def _new(self, rows, cols, dtype, zero=False):
-        f = torch.zeros if zero else torch.empty
-        return f(rows, cols, dtype=dtype, device=self.dev)
+        """(rows, cols) buffer; ``zero``: the pad rows past the last real token are cleared (the kernels behind it write the real ones)"""
+        b = torch.empty(rows, cols, dtype=dtype, device=self.dev)
+        if zero and rows > self.T:
+            b[self.T:].zero_()
+        return b
 
     def _gemm(self, A, W, bias, out, in_dt, act=hip.ACT_NONE, res=None, res_dt=hip.DT_F32):
         """out (Tp, N) = act(A (Tp, K) . W (N, K)^T + bias) + res"""
@@ -122,9 +125,9 @@ class _Run:
             ao = self._gemm(ctx, wo16, P[pre + "attention.output.dense.bias"], self._new(Tp, H, torch.float32), hip.DT_F16)
             mid, pre1, st1 = self._ln_fwd(ao, x16, P[pre + "attention.output.LayerNorm.gamma"], P[pre + "attention.output.LayerNorm.beta"],
                                           self.p_h, self._seed(l, 1))
-            h16 = self._gemm(mid, w1_16, P[pre + "intermediate.dense.bias"], self._new(Tp, I, torch.float16), hip.DT_F16)
-            g16 = self._new(Tp, I, torch.float16)
-            _chk(lib.ruart_gelu16_fwd(hip.ptr(h16), hip.ptr(g16), Tp * I, st()), "ruart_gelu16_fwd")
+            h16, g16 = self._new(Tp, I, torch.float16), self._new(Tp, I, torch.float16)
+            _chk(lib.ruart_gemm_16_nt_gelu2(hip.ptr(mid), H, hip.ptr(w1_16), H, hip.ptr(P[pre + "intermediate.dense.bias"]), hip.ptr(h16), hip.ptr(g16),
+                                            I, Tp, I, H, hip.DT_F16, st()), "ruart_gemm_16_nt_gelu2")
             ff = self._gemm(g16, w2_16, P[pre + "output.dense.bias"], ao, hip.DT_F16)           # reuses the fp32 buffer
             del g16
             out, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
@@ -138,22 +141,26 @@ class _Run:
         return mixed[:T]
 
     # -- backward ------------------------------------------------------------------------------------------------------------
-    def _dw(self, dY_bf16, X16, x_is_f16, scale=1.0):
-        """(N_out, K_in) fp32 = dY^T . X over the token rows: transposed bf16 copies, split-K MFMA product, ordered slab sum."""
+    def _bf16(self, x16):
+        """bf16 copy of a saved f16 activation (the X operand of a weight-gradient product; transient)"""
+        out = self.xb[:x16.numel()].view(x16.shape)
+        _chk(self.lib.ruart_f16_to_bf16(hip.ptr(x16), hip.ptr(out), x16.numel(), hip.stream_ptr()), "ruart_f16_to_bf16")
+        return out
+
+    def _dw(self, dY_bf16, X_bf16):
+        """(N_out, K_in) fp32 = dY^T . X over the token rows, straight from the row-major operands: split over the token rows to fill
+        the chip (a 768 x 768 output is 9 tiles), slabs summed in slice order."""
         lib, Tp = self.lib, self.Tp
-        M, N = dY_bf16.shape[1], X16.shape[1]
-        tA, tB = self.tA[:M * Tp].view(M, Tp), self.tB[:N * Tp].view(N, Tp)
-        _chk(lib.ruart_transpose16(hip.ptr(dY_bf16), M, hip.ptr(tA), Tp, Tp, M, 0, hip.stream_ptr()), "ruart_transpose16")
-        _chk(lib.ruart_transpose16(hip.ptr(X16), N, hip.ptr(tB), Tp, Tp, N, 1 if x_is_f16 else 0, hip.stream_ptr()), "ruart_transpose16")
+        M, N = dY_bf16.shape[1], X_bf16.shape[1]
         tiles = (M // 256) * (N // 256)
         nz = max(1, min(256 // tiles, Tp // 128))
-        kchunk = ((Tp + nz - 1) // nz + 127) // 128 * 128
-        nz = (Tp + kchunk - 1) // kchunk
+        tchunk = ((Tp + nz - 1) // nz + 127) // 128 * 128
+        nz = (Tp + tchunk - 1) // tchunk
         part = self.part[:nz * M * N]
-        _chk(lib.ruart_gemm_16_nt_splitk(hip.ptr(tA), Tp, hip.ptr(tB), Tp, hip.ptr(part), N, M, N, Tp, kchunk, hip.DT_BF16, hip.stream_ptr()),
-             "ruart_gemm_16_nt_splitk")
+        _chk(lib.ruart_gemm_16_tn_splitk(hip.ptr(dY_bf16), M, hip.ptr(X_bf16), N, hip.ptr(part), N, M, N, Tp, tchunk, hip.DT_BF16, hip.stream_ptr()),
+             "ruart_gemm_16_tn_splitk")
         dW = torch.empty(M, N, dtype=torch.float32, device=self.dev)
-        _chk(lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, float(scale), 0, hip.stream_ptr()), "ruart_splitk_reduce")
+        _chk(lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, 1.0, 0, hip.stream_ptr()), "ruart_splitk_reduce")
         return dW
 
     def _colsum(self, d_bf16):
@@ -167,10 +174,11 @@ class _Run:
         d_res = self._new(Tp, H, torch.float32, zero=True)
         d_gemm = self._new(Tp, H, torch.bfloat16, zero=True) if not post else None
         dg, db = torch.empty(H, device=self.dev), torch.empty(H, device=self.dev)
+        dbias = torch.empty(H, device=self.dev) if not post else None
         _chk(self.lib.ruart_ln_train_bwd(hip.ptr(dy), H, hip.ptr(add), hip.ptr(add_scale), hip.ptr(pre16), H, hip.ptr(stats), hip.ptr(gamma), float(p),
-                                         int(seed), post, hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), 0, hip.ptr(self.ln_ws),
-                                         self.T, H, hip.stream_ptr()), "ruart_ln_train_bwd")
-        return d_res, d_gemm, dg, db
+                                         int(seed), post, hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), hip.ptr(dbias), 0,
+                                         hip.ptr(self.ln_ws), self.T, H, hip.stream_ptr()), "ruart_ln_train_bwd")
+        return d_res, d_gemm, dg, db, dbias
 
     def backward(self, g_mixed):
         P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
@@ -185,10 +193,9 @@ class _Run:
         ws = torch.empty(512 * NL, dtype=torch.float32, device=dev)
         _chk(lib.ruart_mix_rows_bwd(hip.ptr(self.layers), Tp * H, H, NL, hip.ptr(G), H, hip.ptr(d_lw), hip.ptr(ws), Tp, H, st()), "ruart_mix_rows_bwd")
         wmax = max(3 * H, I)
-        self.tA = torch.empty(wmax * Tp, dtype=torch.bfloat16, device=dev)
-        self.tB = torch.empty(wmax * Tp, dtype=torch.bfloat16, device=dev)
+        self.xb = torch.empty(Tp * H, dtype=torch.bfloat16, device=dev)
         self.part = torch.empty(max(256, Tp // 128) * 256 * 256 + 4 * wmax * H, dtype=torch.float32, device=dev)
-        self.cs_ws = torch.empty(((Tp + 255) // 256) * wmax, dtype=torch.float32, device=dev)
+        self.cs_ws = torch.empty(max(((Tp + 255) // 256) * wmax, int(lib.ruart_gelu16_bwd_ws_floats(Tp, I))), dtype=torch.float32, device=dev)
         self.ln_ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), dtype=torch.float32, device=dev)
         dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
         dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
@@ -199,28 +206,30 @@ class _Run:
             qkv, ctx, pre1, st1, mid, h16, pre2, st2 = self.saved[l]
             x16 = self.layers[l - 1] if l > 0 else self.x_in
             # ---- output LayerNorm (+ the layer-mix gradient of this layer's output) and the FFN
-            d_res2, d_g2, dg2, db2 = self._ln_bwd(dX, G, self.lw[l:l + 1], pre2, st2, P[pre + "output.LayerNorm.gamma"], self.p_h, self._seed(l, 2))
+            d_res2, d_g2, dg2, db2, dbias2 = self._ln_bwd(dX, G, self.lw[l:l + 1], pre2, st2, P[pre + "output.LayerNorm.gamma"], self.p_h,
+                                                          self._seed(l, 2))
             grads[pre + "output.LayerNorm.gamma"], grads[pre + "output.LayerNorm.beta"] = dg2, db2
-            grads[pre + "output.dense.bias"] = self._colsum(d_g2)
-            g16 = self._new(Tp, I, torch.float16)
-            _chk(lib.ruart_gelu16_fwd(hip.ptr(h16), hip.ptr(g16), Tp * I, st()), "ruart_gelu16_fwd")
-            grads[pre + "output.dense.weight"] = self._dw(d_g2, g16, True)
-            del g16
+            grads[pre + "output.dense.bias"] = dbias2
             w2t = P[pre + "output.dense.weight"].t().contiguous().to(torch.bfloat16)            # (I, H): dX = dY . W as an NT product
             d_g = self._gemm(d_g2, w2t, None, self._new(Tp, I, torch.bfloat16), hip.DT_BF16)
-            d_h = self._new(Tp, I, torch.bfloat16)
-            _chk(lib.ruart_gelu16_bwd(hip.ptr(d_g), hip.ptr(h16), hip.ptr(d_h), Tp * I, st()), "ruart_gelu16_bwd")
+            d_h, g_b = self._new(Tp, I, torch.bfloat16), self._new(Tp, I, torch.bfloat16)
+            db1_ff = torch.empty(I, dtype=torch.float32, device=dev)
+            _chk(lib.ruart_gelu16_bwd(hip.ptr(d_g), hip.ptr(h16), hip.ptr(d_h), hip.ptr(g_b), hip.ptr(db1_ff), hip.ptr(self.cs_ws), Tp, I, st()),
+                 "ruart_gelu16_bwd")
             del d_g
-            grads[pre + "intermediate.dense.bias"] = self._colsum(d_h)
-            grads[pre + "intermediate.dense.weight"] = self._dw(d_h, mid, True)
+            grads[pre + "output.dense.weight"] = self._dw(d_g2, g_b)
+            del g_b
+            grads[pre + "intermediate.dense.bias"] = db1_ff
+            grads[pre + "intermediate.dense.weight"] = self._dw(d_h, self._bf16(mid))
             w1t = P[pre + "intermediate.dense.weight"].t().contiguous().to(torch.bfloat16)      # (H, I)
             d_mid = self._gemm(d_h, w1t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res2)
             del d_h, d_res2
             # ---- attention-output LayerNorm, output projection, attention, QKV projection
-            d_res1, d_g1, dg1, db1 = self._ln_bwd(d_mid, None, None, pre1, st1, P[pre + "attention.output.LayerNorm.gamma"], self.p_h, self._seed(l, 1))
+            d_res1, d_g1, dg1, db1, dbias1 = self._ln_bwd(d_mid, None, None, pre1, st1, P[pre + "attention.output.LayerNorm.gamma"], self.p_h,
+                                                          self._seed(l, 1))
             grads[pre + "attention.output.LayerNorm.gamma"], grads[pre + "attention.output.LayerNorm.beta"] = dg1, db1
-            grads[pre + "attention.output.dense.bias"] = self._colsum(d_g1)
-            grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, ctx, True)
+            grads[pre + "attention.output.dense.bias"] = dbias1
+            grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, self._bf16(ctx))
             wot = P[pre + "attention.output.dense.weight"].t().contiguous().to(torch.bfloat16)
             d_ctx = self._gemm(d_g1, wot, None, self._new(Tp, H, torch.bfloat16), hip.DT_BF16)
             _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0),
@@ -230,13 +239,13 @@ class _Run:
             # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise), so it is
             # not summed up out of rounded dK rows
             grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[H:2 * H]), db[2 * H:]
-            dW = self._dw(dqkv, x16, True)
+            dW = self._dw(dqkv, self._bf16(x16))
             grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = dW[:H] * scale, dW[H:2 * H], dW[2 * H:]
             w_qkv_t = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0).t().contiguous().to(torch.bfloat16)
             dX = self._gemm(dqkv, w_qkv_t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res1)
             self.saved[l] = None                                                          # release this layer's activations
         # ---- embeddings: dropout(LayerNorm(word + position + type))
-        d_e, _, dge, dbe = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
+        d_e, _, dge, dbe, _ = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
         grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe
         d_e = d_e[:T]
         ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
@@ -245,7 +254,7 @@ class _Run:
         gt = torch.zeros_like(P["embeddings.token_type_embeddings.weight"])
         gt[0] = d_e.sum(0)
         grads["embeddings.token_type_embeddings.weight"] = gt
-        self.tA = self.tB = self.part = None
+        self.xb = self.part = None
         return d_lw, grads
 
 

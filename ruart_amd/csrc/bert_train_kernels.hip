@@ -83,21 +83,22 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
 //   post == 0: d_res (fp32) = gradient w.r.t. the LayerNorm's input (what flows on through the residual connection),
 //              d_gemm (bf16) = the same times the dropout multiplier (gradient w.r.t. the dense output);
 //   post == 1: dy is first multiplied by the dropout multiplier; only d_res is written (gradient w.r.t. the embedding sum).
-// Partial column sums of d(gamma), d(beta) go to part[(block, 0/1, H)]; ruart_ln_train_bwd reduces them in block order.
+// Partial column sums of d(gamma), d(beta) and (post == 0) of the unrounded d_gemm - the bias gradient of the dense layer in front - go
+// to part[(block, 0/1/2, H)]; ruart_ln_train_bwd reduces them in block order.
 __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ add,
                                                            const float* __restrict__ add_scale, const f16_t* __restrict__ pre16, int ld16,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma, float p,
                                                            unsigned seed, int post, float* __restrict__ d_res, int ldd,
                                                            bf16_t* __restrict__ d_gemm, int ldg, float* __restrict__ part, int rows, int H) {
-  __shared__ float red[3][2 * 256 * TMAXG];
+  __shared__ float red[3][3 * 256 * TMAXG];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float keep_inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   const float a = add ? add_scale[0] : 0.f;
-  f32x4_t dgam[TMAXG], dbet[TMAXG], gam[TMAXG];
+  f32x4_t dgam[TMAXG], dbet[TMAXG], dbia[TMAXG], gam[TMAXG];
 #pragma unroll
   for (int i = 0; i < TMAXG; ++i) {
     const int c = (i * 64 + lane) * 4;
-    dgam[i] = dbet[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dgam[i] = dbet[i] = dbia[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     gam[i] = c < H ? load4(gamma + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
   for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) dx[r] *= drop_scale(seed, (unsigned)(row * H + c + r), p, keep_inv);
           }
+          dbia[i] += dx;
           store4(d_gemm + (size_t)row * ldg + c, dx);
         }
       }
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
     for (int i = 0; i < TMAXG; ++i) {
       *reinterpret_cast<f32x4_t*>(&red[wv - 1][(i * 64 + lane) * 4]) = dgam[i];
       *reinterpret_cast<f32x4_t*>(&red[wv - 1][256 * TMAXG + (i * 64 + lane) * 4]) = dbet[i];
+      *reinterpret_cast<f32x4_t*>(&red[wv - 1][2 * 256 * TMAXG + (i * 64 + lane) * 4]) = dbia[i];
     }
   }
   __syncthreads();
@@ -160,35 +163,48 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
     for (int i = 0; i < TMAXG; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
-        f32x4_t sg = dgam[i], sb = dbet[i];
+        f32x4_t sg = dgam[i], sb = dbet[i], sx = dbia[i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           sg += *reinterpret_cast<const f32x4_t*>(&red[k][c]);
           sb += *reinterpret_cast<const f32x4_t*>(&red[k][256 * TMAXG + c]);
+          sx += *reinterpret_cast<const f32x4_t*>(&red[k][2 * 256 * TMAXG + c]);
         }
-        store4(part + ((size_t)blockIdx.x * 2) * H + c, sg);
-        store4(part + ((size_t)blockIdx.x * 2 + 1) * H + c, sb);
+        store4(part + ((size_t)blockIdx.x * 3) * H + c, sg);
+        store4(part + ((size_t)blockIdx.x * 3 + 1) * H + c, sb);
+        store4(part + ((size_t)blockIdx.x * 3 + 2) * H + c, sx);
       }
     }
   }
 }
 
-// out[j] (+)= sum over `n` rows of part[row * stride + j], rows in index order
+// out[j] (+)= sum over `n` rows of part[row * stride + j]: 32 columns per block, eight row groups (rows g, g + 8, ...) summed in a fixed
+// order - the same bits every run
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int n, size_t stride, float* __restrict__ out,
                                                         int cols, int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= cols) return;
-  float s = 0.f;
-  for (int r = 0; r < n; ++r) s += part[(size_t)r * stride + j];
-  out[j] = accumulate ? out[j] + s : s;
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < cols) {
+    int r = g;
+    for (; r + 8 < n; r += 16) {
+      s0 += part[(size_t)r * stride + j];
+      s1 += part[(size_t)(r + 8) * stride + j];
+    }
+    if (r < n) s0 += part[(size_t)r * stride + j];
+  }
+  red[g][cx] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < cols) {
+    float s = red[0][cx];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][cx];
+    out[j] = accumulate ? out[j] + s : s;
+  }
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-
 __global__ void gelu16_fwd_kernel(const f16_t* __restrict__ h, f16_t* __restrict__ g, size_t n4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4_t v = load4(h + i * 4);
@@ -197,14 +213,34 @@ __global__ void gelu16_fwd_kernel(const f16_t* __restrict__ h, f16_t* __restrict
     store4(g + i * 4, v);
   }
 }
-__global__ void gelu16_bwd_kernel(const bf16_t* __restrict__ dg, const f16_t* __restrict__ h, bf16_t* __restrict__ dh, size_t n4) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const f32x4_t x = load4(h + i * 4);
-    f32x4_t d = load4(dg + i * 4);
+// Backward of the GELU between the two feed-forward products, one pass over the (rows x cols) intermediate:
+//   dh (bf16) = dg * gelu'(h)          gradient w.r.t. the intermediate dense output
+//   g  (bf16) = gelu(h)                 the activation again - the X operand of the output dense's weight gradient (not kept by the forward)
+//   part[row block][col]                column sums of the unrounded dh over the block's GELU_RB rows (the intermediate bias gradient)
+// Block = 256 threads x 4 columns (1024 columns) x GELU_RB rows.
+#define GELU_RB 128
+__global__ __launch_bounds__(256) void gelu16_bwd_kernel(const bf16_t* __restrict__ dg, const f16_t* __restrict__ h, bf16_t* __restrict__ dh,
+                                                         bf16_t* __restrict__ g, float* __restrict__ part, int rows, int cols) {
+  const int c = blockIdx.x * 1024 + threadIdx.x * 4;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * GELU_RB, r1 = min(rows, r0 + GELU_RB);
+  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int r = r0; r < r1; ++r) {
+    const size_t o = (size_t)r * cols + c;
+    const f32x4_t x = load4(h + o);
+    f32x4_t d = load4(dg + o), a;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] *= gelu_grad(x[r]);
-    store4(dh + i * 4, d);
+    for (int k = 0; k < 4; ++k) {
+      const float cdf = 0.5f * (1.0f + erff(x[k] * 0.70710678118654752440f));
+      a[k] = x[k] * cdf;
+      d[k] *= cdf + x[k] * 0.3989422804014327f * __expf(-0.5f * x[k] * x[k]);
+    }
+    sum += d;
+    store4(dh + o, d);
+    if (g) store4(g + o, a);
   }
+  if (part) store4(part + (size_t)blockIdx.y * cols + c, sum);
 }
 
 // column sums of a bf16 matrix in two deterministic stages: block (chunk of 256 rows, 256 columns) -> part[chunk][cols]
@@ -338,19 +374,22 @@ extern "C" int ruart_ln_train_fwd(const float* x, int ldx, const void* res16, in
   return 0;
 }
 
-extern "C" size_t ruart_ln_train_bwd_ws_floats(int H) { return (size_t)LN_BWD_BLOCKS * 2 * H; }
+extern "C" size_t ruart_ln_train_bwd_ws_floats(int H) { return (size_t)LN_BWD_BLOCKS * 3 * H; }
 
 extern "C" int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, const float* add_scale, const void* pre16, int ld16,
                                   const float* stats, const float* gamma, float p, unsigned seed, int post, float* d_res, int ldd,
-                                  void* d_gemm_bf16, int ldg, float* d_gamma, float* d_beta, int accumulate, float* ws, int rows, int H,
-                                  void* stream) {
+                                  void* d_gemm_bf16, int ldg, float* d_gamma, float* d_beta, float* d_bias, int accumulate, float* ws, int rows,
+                                  int H, void* stream) {
   RUART_ENTRY();
   if (H % 4 || H > 256 * TMAXG || rows <= 0 || !d_res || (!post && !d_gemm_bf16) || !ws || !d_gamma || !d_beta) return (int)hipErrorInvalidValue;
   const int blocks = min(LN_BWD_BLOCKS, ceil_div(rows, 4));
   hipLaunchKernelGGL(ln_train_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, add, add_scale, (const f16_t*)pre16, ld16,
                      stats, gamma, p, seed, post, d_res, ldd, (bf16_t*)d_gemm_bf16, ldg, ws, rows, H);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)2 * H, d_gamma, H, accumulate);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream, ws + H, blocks, (size_t)2 * H, d_beta, H, accumulate);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)3 * H, d_gamma, H, accumulate);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws + H, blocks, (size_t)3 * H, d_beta, H, accumulate);
+  if (d_bias && !post)
+    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws + 2 * H, blocks, (size_t)3 * H, d_bias, H,
+                       accumulate);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -364,12 +403,30 @@ extern "C" int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* s
   RUART_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, long long n, void* stream) {
+__global__ void f16_to_bf16_kernel(const f16_t* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) store4(out + i * 4, load4(in + i * 4));
+}
+extern "C" int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream) {
   RUART_ENTRY();
-  if (n <= 0 || n % 4) return (int)hipErrorInvalidValue;
+  if (n <= 0 || n % 4 || !in16 || !out_bf16) return (int)hipErrorInvalidValue;
   const size_t n4 = (size_t)n / 4;
-  hipLaunchKernelGGL(gelu16_bwd_kernel, dim3((unsigned)min((size_t)4096, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dg_bf16, (const f16_t*)h16, (bf16_t*)dh_bf16, n4);
+  hipLaunchKernelGGL(f16_to_bf16_kernel, dim3((unsigned)min((size_t)4096, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)in16,
+                     (bf16_t*)out_bf16, n4);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t ruart_gelu16_bwd_ws_floats(int rows, int cols) { return (size_t)ceil_div(rows, GELU_RB) * cols; }
+
+extern "C" int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, void* g_bf16, float* d_bias, float* ws, int rows, int cols,
+                                void* stream) {
+  RUART_ENTRY();
+  if (rows <= 0 || cols <= 0 || cols % 4 || !dg_bf16 || !h16 || !dh_bf16 || (d_bias && !ws)) return (int)hipErrorInvalidValue;
+  const int rb = ceil_div(rows, GELU_RB);
+  hipLaunchKernelGGL(gelu16_bwd_kernel, dim3(ceil_div(cols, 1024), rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg_bf16,
+                     (const f16_t*)h16, (bf16_t*)dh_bf16, (bf16_t*)g_bf16, d_bias ? ws : nullptr, rows, cols);
+  if (d_bias)
+    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, (hipStream_t)stream, ws, rb, (size_t)cols, d_bias, cols, 0);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -381,7 +438,7 @@ extern "C" int ruart_colsum_bf16(const void* x_bf16, int ld, int rows, int cols,
   const int chunks = ceil_div(rows, 256);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ld, rows,
                      cols, ws);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)stream, ws, chunks, (size_t)cols, out, cols, accumulate);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, (hipStream_t)stream, ws, chunks, (size_t)cols, out, cols, accumulate);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -428,7 +485,7 @@ extern "C" int ruart_mix_rows_bwd(const void* layers16, long long layer_stride, 
   const int blocks = min(512, ceil_div(rows, 4));
   hipLaunchKernelGGL(mix_rows_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)layers16, (size_t)layer_stride, ld, n_layers,
                      g, ldg, ws, rows, H);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)n_layers, d_w, n_layers, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(n_layers, 32)), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)n_layers, d_w, n_layers, 0);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
-                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk,
+                                                           void* __restrict__ C2
 #ifdef RUART_P8_STAMPS
                                                            , unsigned long long* __restrict__ stamps
 #endif
@@ -345,9 +346,9 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   const int m0 = tm * BM4, n0 = tn * BN4;
 
   // staging: wave w fills local rows 16w .. 16w+15 of a half-tile (two 1 KB pieces of 8 rows x 128 B, lane-linear)
-  // Addresses = uniform 64-bit base (SGPR pair) + ONE 32-bit per-lane offset per operand (global_load_lds saddr form).
+  // Addresses = uniform 64-bit base (SGPR pair) + ONE 32-bit per-lane byte offset per operand (dma16: the saddr form of global_load_lds).
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const unsigned a_lane = (unsigned)(srow * lda + schunk * 8), w_lane = (unsigned)(srow * ldw + schunk * 8);
+  const unsigned a_lane = (unsigned)(srow * lda + schunk * 8) * 2, w_lane = (unsigned)(srow * ldw + schunk * 8) * 2;      // bytes
   const T16* a_src = A + (size_t)(m0 + (wave >> 2) * 128 + (wave & 3) * 16) * lda;
   const T16* w_src = W + (size_t)(n0 + (wave >> 1) * 64 + (wave & 1) * 16) * ldw;
   const size_t a8 = (size_t)8 * lda, w8 = (size_t)8 * ldw, a_h = (size_t)64 * lda, w_h = (size_t)32 * ldw;
@@ -355,14 +356,14 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   auto stage_a = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + h * kHalf;
     const T16* src = a_src + h * a_h + kt * BK;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + a_lane), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + a8 + a_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+    dma16(src, a_lane, dst);
+    dma16(src + a8, a_lane, dst + 1024);
   };
   auto stage_w = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + kOper + h * kHalf;
     const T16* src = w_src + h * w_h + kt * BK;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + w_lane), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + w8 + w_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+    dma16(src, w_lane, dst);
+    dma16(src + w8, w_lane, dst + 1024);
   };
 
   f32x4_t acc[4][8];
@@ -407,6 +408,65 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   };
   auto nothing = [] {};
   // one K-tile = four phases.  D: LDS buffer of this tile; N1: K-tile t+1 exists; N2: K-tile t+2 exists.
+  // RUART_P8_BALANCED=1 (diagnostic builds): the read balancing that gemm_tn.hip ships.  Here it measures neutral (layer average 728 us
+  // against 724 us over three interleaved runs of tools/gemm_corr_bench.py), so the plain schedule below stays the product.
+#ifndef RUART_P8_BALANCED
+#define RUART_P8_BALANCED 0
+#endif
+#if RUART_P8_BALANCED
+  // Fragment reads per phase 8 / 4 / 8 / 4 (ds_read_b128) instead of 12 / 4 / 8 / 0: phase 3, which has nothing of its own to fetch,
+  // reads the NEXT K-tile's W-h0 fragments into the register set that held this tile's W-h1 (dead after phase 2) - the two sets swap
+  // roles with the LDS buffer, no register is added - so the longest read segment of the loop is a third shorter.  K-tile t+1's W-h0 must then have landed for BOTH wave groups one barrier
+  // earlier than the rest of that tile: the counted wait at the end of phase 2 (the five half-tiles issued after it may still be in
+  // flight) stands before the barrier the other group pairs with.  Same products in the same order: bitwise the old kernel.
+  auto tile = [&](auto dtag, auto n1tag, auto n2tag, int t) {
+    constexpr int D = decltype(dtag)::value;
+    constexpr bool N1 = decltype(n1tag)::value, N2 = decltype(n2tag)::value;
+    constexpr bool S1 = N1 && !(ab & 1), S2 = N2 && !(ab & 1);
+    const bool rd = !(ab & 2) || t == 0;
+    auto run = [&](frag_t (&wc)[2][2], frag_t (&wn)[2][2]) {
+      // phase 0: quadrant (rows h0, cols h0), W-h0 fragments already in wc; prefetch (t+1, A-h1)
+      if (rd) read_a(D, 0);
+      if (S1) stage_a(D ^ 1, 1, t + 1);
+      RUART_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      quad(0, 0, wc, nothing);
+      RUART_BAR();
+      // phase 1: (rows h0, cols h1); prefetch (t+2, W-h0)
+      if (rd) read_w(D, 1, wn);
+      if (S2) stage_w(D, 0, t + 2);
+      RUART_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      quad(1, 0, wn, nothing);
+      RUART_BAR();
+      // phase 2: (rows h1, cols h1); prefetch (t+2, A-h0)
+      if (rd) read_a(D, 1);
+      if (S2) stage_a(D, 0, t + 2);
+      RUART_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      quad(1, 1, wn, nothing);
+      if (N2) {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // (t+1, W-h0) has landed; the five half-tiles issued after it may be in flight
+      } else if (N1) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // tail: only (t+1, A-h1) is younger
+      }
+      RUART_BAR();
+      // phase 3: (rows h1, cols h0) - operands in registers; prefetch (t+2, W-h1); read (t+1, W-h0) for the next tile's phase 0
+      if (N2) {
+        if (S2) stage_w(D, 1, t + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile t+1 complete; the 3 youngest half-tiles stay in flight
+      } else if (N1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // last prefetch: (t+1, A-h1) from phase 0
+      }
+      RUART_BAR();
+      if (N1 && rd) read_w(D ^ 1, 0, wn);
+      quad(0, 1, wc, nothing);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (free: issued 16 MFMAs ago) the W-h0 slot is restaged two barriers on
+      RUART_BAR();
+    };
+    if constexpr (D == 0) run(wf0, wf1); else run(wf1, wf0);
+  };
+#else
   auto tile = [&](auto dtag, auto n1tag, auto n2tag, int t) {
     constexpr int D = decltype(dtag)::value;
     constexpr bool N1 = decltype(n1tag)::value, N2 = decltype(n2tag)::value;
@@ -451,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     if (S2) quad(0, 1, wf0, [&] { stage_w(D, 1, t + 2); }); else quad(0, 1, wf0, nothing);
     RUART_BAR();
   };
+#endif
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using Tt = std::true_type;
@@ -467,6 +528,9 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile 0 landed (this wave's share)
   RUART_BAR();
   P8_STAMP(1);
+#if RUART_P8_BALANCED
+  read_w(0, 0, wf0);
+#endif
   if (wave >= 4 && !(ab & 4)) RUART_BAR();   // stagger: waves 4-7 run one barrier behind
   int t = 0;
   for (; t + 2 < nt; t += 2) {
@@ -505,7 +569,11 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
-    if (ACT == 1) {
+    if (ACT == 2) {                                          // training forward: the pre-activation is kept for the backward pass
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+    }
+    if (ACT != 0) {
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
     }
@@ -708,10 +776,10 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     (void)done;
 #ifdef RUART_P8_STAMPS
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0, g_p8_stamps);
+                       g_tile_order, 0, (void*)nullptr, g_p8_stamps);
 #else
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0);
+                       g_tile_order, 0, (void*)nullptr);
 #endif
   } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
@@ -767,6 +835,41 @@ extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, 
   return rc;
 }
 
+// Training forward of the intermediate dense (Models/Bert/modeling.py:287-288): G = gelu(A . W^T + bias) AND the pre-activation H, both in
+// the operands' 16-bit type with row stride ldc - the backward pass needs H, the next product needs G, and a separate GELU pass would
+// read H back (1.4 ms of the unlocked step).
+template <typename T16>
+static void launch_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* Hout, void* G, int ldc, int M, int N, int K,
+                         hipStream_t s) {
+  constexpr int lds = 2 * 2 * BM4 * BK * 2;
+  auto kern = gemm_16_nt_256p8<T16, false, 0, 2>;
+  static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)done;
+#ifdef RUART_P8_STAMPS
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
+                     ldc, M, N, K, g_tile_order, 0, Hout, (unsigned long long*)nullptr);
+#else
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
+                     ldc, M, N, K, g_tile_order, 0, Hout);
+#endif
+}
+
+extern "C" int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* H16, void* G16, int ldc, int M,
+                                      int N, int K, int in_dtype, void* stream) {
+  RUART_ENTRY();
+  if (M <= 0 || M % BM4 || N % BN4 || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || !H16 || !G16 || !A || !W) return (int)hipErrorInvalidValue;
+  void* rec = ruart_prof_begin_((hipStream_t)stream, M, N, K);
+  if (in_dtype == RUART_DT_BF16)
+    launch_gelu2<bf16_t>(A, lda, W, ldw, bias, H16, G16, ldc, M, N, K, (hipStream_t)stream);
+  else if (in_dtype == RUART_DT_F16)
+    launch_gelu2<f16_t>(A, lda, W, ldw, bias, H16, G16, ldc, M, N, K, (hipStream_t)stream);
+  else
+    return (int)hipErrorInvalidValue;
+  ruart_prof_end_(rec, (hipStream_t)stream);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
 // Split-K form of the 16-bit NT product: part[z] (M x N fp32, row stride ldc, slabs M * ldc floats apart) = A[:, z*kchunk : ...] .
 // W[:, z*kchunk : ...]^T for z < ceil(K / kchunk).  For the encoder's weight gradients dW = dY^T . X (M, N = layer widths, K = token
 // rows): a 768 x 768 output is 9 tiles, so the reduction is cut into ~28 slices to fill the 256 CUs.
@@ -779,10 +882,10 @@ static void launch_splitk(const void* A, int lda, const void* W, int ldw, float*
   const int nz = (K + kchunk - 1) / kchunk;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (unsigned long long*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr);
 #endif
 }
 

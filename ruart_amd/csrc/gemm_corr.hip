@@ -99,14 +99,14 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
   auto stage_a = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + h * kHalf;
     const char* src = (kt < nt ? A16 + (size_t)kt * CBKB : A8 + (size_t)(kt - nt) * CBKB) + a_row0 + h * a_h;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + a_lane), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + a8r + a_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+    dma16(src, a_lane, dst);
+    dma16(src + a8r, a_lane, dst + 1024);
   };
   auto stage_w = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + kOper + h * kHalf;
     const char* src = (kt < nt ? W16 + (size_t)kt * CBKB : W8 + (size_t)(kt - nt) * CBKB) + w_row0 + h * w_h;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + w_lane), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + w8r + w_lane), (lptr_t)(dst + 1024), 16, 0, 0);
+    dma16(src, w_lane, dst);
+    dma16(src + w8r, w_lane, dst + 1024);
   };
 
   f32x4_t acc[4][8];

@@ -35,6 +35,24 @@ __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA of 16 bytes per lane in the instruction's saddr form: global address = wave-uniform 64-bit base (an SGPR pair) + this lane's
+// 32-bit BYTE offset; LDS address = wave-uniform byte address (through M0) + lane * 16.  The builtin takes one 64-bit pointer per lane
+// and hipcc then keeps every staged address as a VGPR pair plus two v_lshl_add_u64 per load in the K loop (12+ VGPRs and ~16 64-bit
+// VALU adds per K-tile in gemm_16_nt_256p8); this form needs one VGPR per operand piece and scalar pointer arithmetic.
+// Not tracked by the compiler's own s_waitcnt insertion: every kernel that uses it counts vmcnt by hand (they already do).
+// RUART_DMA_BUILTIN=1 (diagnostic builds) goes back to the builtin.
+#ifndef RUART_DMA_BUILTIN
+#define RUART_DMA_BUILTIN 0
+#endif
+__device__ __forceinline__ void dma16(const void* base_uniform, unsigned lane_byte_off, char* lds_dst_uniform) {
+#if RUART_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(base_uniform) + lane_byte_off), (lptr_t)lds_dst_uniform, 16, 0, 0);
+#else
+  const unsigned lds_addr = (unsigned)(size_t)(lptr_t)lds_dst_uniform;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_byte_off), "s"(base_uniform) : "memory");
+#endif
+}
+
 #define RUART_BAR()                          \
   do {                                       \
     asm volatile("" ::: "memory");           \

@@ -480,8 +480,9 @@ def _unlocked(z, precision, **extra):
     return net.to("cuda:0"), opt
 
 
-@pytest.mark.parametrize("precision,tol_p,tol_g", [("fp32", 5e-5, 2e-3), ("x3", 2e-4, 3e-2), ("x3+16gemm", 3e-3, 1.5e-1), ("x3+16", 3e-3, 3e-2)])
-def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_g):
+@pytest.mark.parametrize("precision,tol_p,tol_g,tol_trunk", [("fp32", 5e-5, 2e-3, 2e-3), ("x3", 2e-4, 3e-2, 3e-2), ("x3+16gemm", 3e-3, 1.5e-1, 1.5e-1),
+                                                             ("x3+16", 3e-3, 3e-2, 6e-2)])
+def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_g, tol_trunk):
     """Conf without LOCK_BERT: the trainable encoder (bert_train.py) under the reference's parameter names; scores, loss and the
     gradient norm of every parameter - 197 BERT tensors included - against the reference's backward, plus gradient slices.
     The exact-fp32 mode pins parity (norms to 3e-5 here).  In the split-bf16 mode (2^-16 per product) this small batch is
@@ -491,7 +492,12 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
     import ruart_amd.layers as L
     z = np.load(os.path.join(golden_dir, "sdnet_e2e_unlocked.npz"))
     # "x3+16": the 16-bit trainable encoder (bert_train16.py: one autograd Function over f16 / bf16 kernels, opt['bert_train_gemm'] =
-    # '16'), held to the 3 % of the round-1 verdict; "x3+16gemm": the fp32-class graph with 16-bit MFMA products for x W^T and dY W
+    # '16').  Its 197 BERT tensors are held to the 3 % of the round-1 verdict (measured: 0.7 % worst, 0.14 % median).  The trunk runs the
+    # same fp32-class kernels as in "x3", but on an encoder output computed from f16 operands: the answer probabilities move by up to
+    # 1.7e-3 (bound 3e-3), and the gradient of the no-answer branch (get_answer.noanswer_*, norm 1e-4) is proportional to
+    # p(no answer) - y with p(no answer) ~ 0.04, i.e. it moves by dp / p ~ 4 %.  That is the forward tolerance seen through a small
+    # probability, not a backward error, so trunk tensors get their own bound (6 %; every other trunk tensor is within 1.7 %).
+    # "x3+16gemm": the fp32-class graph with 16-bit MFMA products for x W^T and dY W
     net, opt = _unlocked(z, precision.split("+")[0], **({"bert_train_gemm": precision.split("+")[1]} if "+" in precision else {}))
     names = dict(net.named_parameters())
     assert set(z["grad_names"].tolist()) == set(names), set(z["grad_names"].tolist()) ^ set(names)   # same state-dict surface
@@ -508,7 +514,7 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
     loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
     assert abs(loss.item() - float(z["loss"])) < 50 * tol_p
     loss.backward()
-    worst = (0.0, "")
+    worst, worst_trunk = (0.0, ""), (0.0, "")
     for name, ref_norm in zip(z["grad_names"].tolist(), z["grad_norms"].tolist()):
         g = names[name].grad
         if ref_norm < 0:
@@ -518,21 +524,28 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
             assert name == "ques_merger.linear.bias" and ref_norm < 1e-6, (name, ref_norm)
             continue
         rel = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, 1e-4)
-        worst = max(worst, (rel, name))
+        if name.startswith("Bert."):
+            worst = max(worst, (rel, name))
+        else:
+            worst_trunk = max(worst_trunk, (rel, name))
         if "grad:" + name in z.files and precision == "fp32":
             ref = z["grad:" + name]
             got = g[tuple(slice(0, n) for n in ref.shape)].detach().cpu().numpy()
             assert np.abs(got - ref).max() <= 2 * tol_g * max(np.abs(ref).max(), 1e-6), name
-    print("unlocked %s: max |dp| %.2e, worst grad-norm rel err %.2e (%s)" % (precision, err, worst[0], worst[1]))
+    print("unlocked %s: max |dp| %.2e, worst grad-norm rel err: BERT %.2e (%s), trunk %.2e (%s)"
+          % (precision, err, worst[0], worst[1], worst_trunk[0], worst_trunk[1]))
     assert worst[0] < tol_g, worst
+    assert worst_trunk[0] < tol_trunk, worst_trunk
 
 
-def test_unlocked_bert_trains_with_the_fused_optimizer():
+@pytest.mark.parametrize("train_gemm", ["x3", "16"])
+def test_unlocked_bert_trains_with_the_fused_optimizer(train_gemm):
     """The trainer path without LOCK_BERT: BERT's parameters sit in the (fused) Adamax, its own dropout is active in training
     (hidden 0.1 / attention 0.1, modeling.py:198-301) and off in evaluation, the loss on a fixed batch goes down, the
-    checkpoint keeps the reference's habit of leaving ``Bert.*`` out."""
+    checkpoint keeps the reference's habit of leaving ``Bert.*`` out.  "16": the 16-bit encoder (bert_train16.py), whose dropout
+    multipliers are hash-generated in the kernels and regenerated in the backward pass."""
     from ruart_amd.trainer import SDNetTrainer
-    opt = default_opt(vocab_size=600, cuda=True, DROPOUT=0.0, dropout_emb=0.0, lr=2e-4)
+    opt = default_opt(vocab_size=600, cuda=True, DROPOUT=0.0, dropout_emb=0.0, lr=2e-4, bert_train_gemm=train_gemm)
     opt.pop("LOCK_BERT")
     cfg = synth.bert_config(vocab_size=2000)
     opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=7, w_std=0.02), cfg
@@ -545,6 +558,9 @@ def test_unlocked_bert_trains_with_the_fused_optimizer():
     batch = tr.ToCUDA(synth.synthetic_batch(opt, 3, seed=31, n_q=10, n_ocr=14, n_od=5, bert_vocab=2000, ragged=True))
     losses = [tr.update(batch, i) for i in range(6)]
     assert all(np.isfinite(losses)), losses
+    assert min(losses[3:]) < losses[0], losses                            # the same batch six times: the loss comes down
+    if train_gemm == "16":
+        assert type(tr.network.Bert.bert_model).__name__ == "BertModelTrainable16"
     w1 = dict(tr.network.named_parameters())["Bert.bert_model.encoder.layer.3.output.dense.weight"].detach()
     assert not torch.equal(w0, w1)                                       # the encoder moved
     a = tr.predict(batch)[0]

@@ -36,11 +36,15 @@ def _ln_bwd(lib, dy, pre, stats, gamma, p, seed, post, add=None, add_scale=None)
     R, H = dy.shape
     d_res = torch.empty(R, H, dtype=torch.float32, device=DEV)
     d_gemm = torch.empty(R, H, dtype=torch.bfloat16, device=DEV)
-    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dg, db, dbias = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), device=DEV)
     rc = lib.ruart_ln_train_bwd(hip.ptr(dy), H, hip.ptr(add), hip.ptr(add_scale), hip.ptr(pre), H, hip.ptr(stats), hip.ptr(gamma), float(p),
-                                int(seed), int(post), hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), 0, hip.ptr(ws), R, H, _st())
+                                int(seed), int(post), hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), hip.ptr(dbias), 0,
+                                hip.ptr(ws), R, H, _st())
     assert rc == 0
+    if not post:                                # the dense layer's bias gradient = column sums of what goes to d_gemm, before its rounding
+        cs = d_gemm.float().sum(0)
+        assert float((dbias - cs).abs().max()) < 4e-3 * float(d_gemm.float().abs().sum(0).max()) + 1e-6
     return d_res, d_gemm, dg, db
 
 
@@ -109,10 +113,21 @@ def test_gelu16_colsum_transpose_mix():
     ref = torch.nn.functional.gelu(hr)
     assert float((out.float() - ref).abs().max()) < 4e-3
     dg = torch.randn(R, N, generator=g).bfloat16().to(DEV)
-    dh = torch.empty_like(dg)
-    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh), R * N, _st()) == 0
+    dh, gb = torch.empty_like(dg), torch.empty_like(dg)
+    dbias = torch.empty(N, device=DEV)
+    gws = torch.empty(int(lib.ruart_gelu16_bwd_ws_floats(R, N)), device=DEV)
+    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh), hip.ptr(gb), hip.ptr(dbias), hip.ptr(gws), R, N, _st()) == 0
     ref.backward(dg.float())
     assert float((dh.float() - hr.grad).abs().max()) < 2e-2 * float(hr.grad.abs().max())      # bf16 in, bf16 out
+    assert float((gb.float() - ref.detach()).abs().max()) < 1e-2 * float(ref.abs().max())     # the activation again, in bf16
+    cs_ref = hr.grad.sum(0)
+    assert float((dbias - cs_ref).abs().max()) < 1e-4 * float(hr.grad.abs().sum(0).max())     # unrounded fp32 column sums
+    dh2 = torch.empty_like(dg)
+    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh2), None, None, None, R, N, _st()) == 0
+    assert torch.equal(dh2, dh)
+    hb = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
+    assert lib.ruart_f16_to_bf16(hip.ptr(h), hip.ptr(hb), R * N, _st()) == 0
+    assert torch.equal(hb, h.float().bfloat16())
     # column sums (bias gradients)
     ws = torch.empty(((R + 255) // 256) * N, device=DEV)
     cs = torch.zeros(N, device=DEV)
@@ -143,6 +158,24 @@ def test_gelu16_colsum_transpose_mix():
     assert float((dw - refw).abs().max()) < 1e-4 * float(refw.abs().max()) + 1e-2
 
 
+def test_intermediate_dense_keeps_preactivation():
+    """ruart_gemm_16_nt_gelu2: one product, two outputs - H = A . W^T + b and G = gelu(H) (Models/Bert/modeling.py:287-288)."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 512, 768, 256
+    A = torch.randn(M, K, generator=g).half().to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    Hh = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    G = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    assert lib.ruart_gemm_16_nt_gelu2(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(b), hip.ptr(Hh), hip.ptr(G), N, M, N, K, hip.DT_F16, _st()) == 0
+    ref = A.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    assert float((Hh.double().cpu() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    refg = torch.nn.functional.gelu(ref)
+    assert float((G.double().cpu() - refg).abs().max()) < 2e-3 * float(refg.abs().max())
+    assert lib.ruart_gemm_16_nt_gelu2(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(b), None, hip.ptr(G), N, M, N, K, hip.DT_F16, _st()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,kchunk", [(768, 768, 43008, 1536), (2304, 768, 5120, 2048), (256, 3072, 1280, 512)])
 def test_weight_gradient_splitk(M, N, K, kchunk):
     """dW = dY^T . X as a split-K NT product of the transposed 16-bit operands, slabs summed by ruart_splitk_reduce."""
@@ -167,6 +200,23 @@ def test_weight_gradient_splitk(M, N, K, kchunk):
     assert float((dW.double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-7       # exact bf16 operands, fp32 sums
     assert lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, 0.5, 1, _st()) == 0  # accumulate form
     assert float((dW.double().cpu() - 2 * ref).abs().max()) < 4e-5 * float(ref.abs().max()) + 1e-7
+    # the TN kernel takes the same operands as they lie (no transposes) and must agree with the slabs of the NT form
+    part2 = torch.empty(nz, M, N, device=DEV)
+    assert lib.ruart_gemm_16_tn_splitk(hip.ptr(dYd), M, hip.ptr(Xd), N, hip.ptr(part2), N, M, N, K, kchunk, hip.DT_BF16, _st()) == 0
+    err = float((part2.double() - part.double()).abs().max())
+    assert err < 2e-5 * float(part.abs().max()), err                                # same products, another order within a K = 32 step
+    dW2 = torch.empty(M, N, device=DEV)
+    assert lib.ruart_splitk_reduce(hip.ptr(part2), M * N, nz, hip.ptr(dW2), M * N, 0.5, 0, _st()) == 0
+    assert float((dW2.double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-7
+    # f16 operands, strided rows (a column block of a wider matrix)
+    Xw = torch.zeros(K, N + 256).half()
+    Xw[:rows] = torch.randn(rows, N + 256, generator=g).half()
+    dYh = (dY.float() * 1024).half().to(DEV)
+    Xwd = Xw.to(DEV)
+    assert lib.ruart_gemm_16_tn_splitk(hip.ptr(dYh), M, hip.ptr(Xwd[:, 256:]), N + 256, hip.ptr(part2), N, M, N, K, kchunk, hip.DT_F16, _st()) == 0
+    ref2 = (dYh.double().cpu().t() @ Xw[:, 256:].double())
+    got2 = part2.double().sum(0).cpu()
+    assert float((got2 - ref2).abs().max()) < 2e-5 * float(ref2.abs().max()) + 1e-7
 
 
 def _attn_case(g, lens, heads):
