@@ -155,6 +155,10 @@ int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* stream);
  * ws: ruart_gelu16_bwd_ws_floats(rows, cols) floats when d_bias is given. */
 size_t ruart_gelu16_bwd_ws_floats(int rows, int cols);
 int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, void* g_bf16, float* d_bias, float* ws, int rows, int cols, void* stream);
+/* One pass over an fp32 master weight W (rows x cols, row stride ldw): out16 (rows x cols f16, row stride ld16) = scale * W, the forward's
+ * GEMM operand, and outT_bf16 (cols x rows bf16, row stride ldT) = (scale * W)^T, the operand of dX = dY . W as an NT product.  Either output
+ * may be NULL; both may point into wider matrices (the fused QKV weight: three calls with row / column offsets). */
+int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols, void* stream);
 /* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
 int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */

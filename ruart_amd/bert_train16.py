@@ -81,15 +81,38 @@ class _Run:
     def _seed(self, layer, site):
         return (self.seed + 7919 * (4 * layer + site + 1)) & 0x7FFFFFFF
 
-    def _ln_fwd(self, x32, res16, g, b, p, seed, post=0):
+    def _ln_fwd(self, x32, res16, g, b, p, seed, post=0, out=None):
         Tp, H = self.Tp, self.H
-        y, pre, st = self._new(Tp, H, torch.float16), self._new(Tp, H, torch.float16), self._new(Tp, 2, torch.float32)
+        y = self._new(Tp, H, torch.float16) if out is None else out
+        pre, st = self._new(Tp, H, torch.float16), self._new(Tp, 2, torch.float32)
         _chk(self.lib.ruart_ln_train_fwd(hip.ptr(x32), H, hip.ptr(res16), H, hip.ptr(g), hip.ptr(b), 1e-12, float(p), int(seed), post, hip.ptr(y),
                                          hip.ptr(pre), hip.ptr(st), H, Tp, H, hip.stream_ptr()), "ruart_ln_train_fwd")
         return y, pre, st
 
     def _attention_ok(self):
         return self.packed.n_long_blocks == 0 and self.packed.max_len <= 64 and self.packed.key_bias is None
+
+    def _prep_weights(self, l, scale):
+        """The layer's four weights as GEMM operands, one pass per master tensor: f16 (N, K) for the forward and, kept for the backward
+        pass, bf16 (K, N) - the transpose - for dX = dY . W.  Query rows carry the 1/sqrt(d) of the scores."""
+        P, H, I, dev = self.P, self.H, self.I, self.dev
+        pre = "encoder.layer.%d." % l
+        a = pre + "attention.self."
+        wq16, wqT = torch.empty(3 * H, H, dtype=torch.float16, device=dev), torch.empty(H, 3 * H, dtype=torch.bfloat16, device=dev)
+        for i, (n, sc) in enumerate((("query", scale), ("key", 1.0), ("value", 1.0))):
+            _chk(self.lib.ruart_weight_prep(hip.ptr(P[a + n + ".weight"]), H, float(sc), hip.ptr(wq16[i * H:]), H, hip.ptr(wqT[:, i * H:]), 3 * H, H, H,
+                                            hip.stream_ptr()), "ruart_weight_prep")
+        out = [wq16]
+        back = [wqT]
+        for n, rows, cols in (("attention.output.dense", H, H), ("intermediate.dense", I, H), ("output.dense", H, I)):
+            w16 = torch.empty(rows, cols, dtype=torch.float16, device=dev)
+            wT = torch.empty(cols, rows, dtype=torch.bfloat16, device=dev)
+            _chk(self.lib.ruart_weight_prep(hip.ptr(P[pre + n + ".weight"]), cols, 1.0, hip.ptr(w16), cols, hip.ptr(wT), rows, rows, cols,
+                                            hip.stream_ptr()), "ruart_weight_prep")
+            out.append(w16)
+            back.append(wT)
+        self.wT.append(back)
+        return out
 
     # -- forward -------------------------------------------------------------------------------------------------------------
     def forward(self, layer_w):
@@ -107,17 +130,13 @@ class _Run:
         self.x_in = x16                                               # input of layer 0
         self.layers = torch.empty(NL, Tp, H, dtype=torch.float16, device=self.dev)
         self.saved = []
-        self.w16 = []
+        self.wT = []
         blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
         for l in range(NL):
             pre = "encoder.layer.%d." % l
             a = pre + "attention.self."
-            w_qkv = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0)
-            b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0).contiguous()
-            wq16 = w_qkv.to(torch.float16)
-            wo16 = P[pre + "attention.output.dense.weight"].to(torch.float16)
-            w1_16 = P[pre + "intermediate.dense.weight"].to(torch.float16)
-            w2_16 = P[pre + "output.dense.weight"].to(torch.float16)
+            b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0)
+            wq16, wo16, w1_16, w2_16 = self._prep_weights(l, scale)
             qkv = self._gemm(x16, wq16, b_qkv, self._new(Tp, 3 * H, torch.float16), hip.DT_F16)
             ctx = self._new(Tp, H, torch.float16, zero=True)
             _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0), hip.ptr(blk_q1),
@@ -130,9 +149,8 @@ class _Run:
                                             I, Tp, I, H, hip.DT_F16, st()), "ruart_gemm_16_nt_gelu2")
             ff = self._gemm(g16, w2_16, P[pre + "output.dense.bias"], ao, hip.DT_F16)           # reuses the fp32 buffer
             del g16
-            out, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
-                                          self._seed(l, 2))
-            self.layers[l].copy_(out)
+            _, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
+                                        self._seed(l, 2), out=self.layers[l])
             self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
             x16 = self.layers[l]
         self.lw = layer_w.detach().to(torch.float32).contiguous()
@@ -147,9 +165,11 @@ class _Run:
         _chk(self.lib.ruart_f16_to_bf16(hip.ptr(x16), hip.ptr(out), x16.numel(), hip.stream_ptr()), "ruart_f16_to_bf16")
         return out
 
-    def _dw(self, dY_bf16, X_bf16):
+    def _dw(self, dY_bf16, X_bf16, row_scales=None):
         """(N_out, K_in) fp32 = dY^T . X over the token rows, straight from the row-major operands: split over the token rows to fill
-        the chip (a 768 x 768 output is 9 tiles), slabs summed in slice order."""
+        the chip (a 768 x 768 output is 9 tiles), slabs summed in slice order.  ``row_scales``: [(rows, scale), ...] cuts the output
+        into separate tensors by row blocks (the fused QKV product -> query / key / value gradients, the query's with the 1/sqrt(d)
+        that the forward folded into its weights)."""
         lib, Tp = self.lib, self.Tp
         M, N = dY_bf16.shape[1], X_bf16.shape[1]
         tiles = (M // 256) * (N // 256)
@@ -159,9 +179,14 @@ class _Run:
         part = self.part[:nz * M * N]
         _chk(lib.ruart_gemm_16_tn_splitk(hip.ptr(dY_bf16), M, hip.ptr(X_bf16), N, hip.ptr(part), N, M, N, Tp, tchunk, hip.DT_BF16, hip.stream_ptr()),
              "ruart_gemm_16_tn_splitk")
-        dW = torch.empty(M, N, dtype=torch.float32, device=self.dev)
-        _chk(lib.ruart_splitk_reduce(hip.ptr(part), M * N, nz, hip.ptr(dW), M * N, 1.0, 0, hip.stream_ptr()), "ruart_splitk_reduce")
-        return dW
+        outs, r0 = [], 0
+        for rows, scale in (row_scales or [(M, 1.0)]):
+            dW = torch.empty(rows, N, dtype=torch.float32, device=self.dev)
+            _chk(lib.ruart_splitk_reduce(hip.ptr(part[r0 * N:]), M * N, nz, hip.ptr(dW), rows * N, float(scale), 0, hip.stream_ptr()),
+                 "ruart_splitk_reduce")
+            outs.append(dW)
+            r0 += rows
+        return outs if row_scales else outs[0]
 
     def _colsum(self, d_bf16):
         n = d_bf16.shape[1]
@@ -210,7 +235,7 @@ class _Run:
                                                           self._seed(l, 2))
             grads[pre + "output.LayerNorm.gamma"], grads[pre + "output.LayerNorm.beta"] = dg2, db2
             grads[pre + "output.dense.bias"] = dbias2
-            w2t = P[pre + "output.dense.weight"].t().contiguous().to(torch.bfloat16)            # (I, H): dX = dY . W as an NT product
+            w_qkv_t, wot, w1t, w2t = self.wT[l]                                                    # (K, N) bf16: dX = dY . W as NT products
             d_g = self._gemm(d_g2, w2t, None, self._new(Tp, I, torch.bfloat16), hip.DT_BF16)
             d_h, g_b = self._new(Tp, I, torch.bfloat16), self._new(Tp, I, torch.bfloat16)
             db1_ff = torch.empty(I, dtype=torch.float32, device=dev)
@@ -221,7 +246,6 @@ class _Run:
             del g_b
             grads[pre + "intermediate.dense.bias"] = db1_ff
             grads[pre + "intermediate.dense.weight"] = self._dw(d_h, self._bf16(mid))
-            w1t = P[pre + "intermediate.dense.weight"].t().contiguous().to(torch.bfloat16)      # (H, I)
             d_mid = self._gemm(d_h, w1t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res2)
             del d_h, d_res2
             # ---- attention-output LayerNorm, output projection, attention, QKV projection
@@ -230,7 +254,6 @@ class _Run:
             grads[pre + "attention.output.LayerNorm.gamma"], grads[pre + "attention.output.LayerNorm.beta"] = dg1, db1
             grads[pre + "attention.output.dense.bias"] = dbias1
             grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, self._bf16(ctx))
-            wot = P[pre + "attention.output.dense.weight"].t().contiguous().to(torch.bfloat16)
             d_ctx = self._gemm(d_g1, wot, None, self._new(Tp, H, torch.bfloat16), hip.DT_BF16)
             _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0),
                                           hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_bwd")
@@ -239,11 +262,10 @@ class _Run:
             # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise), so it is
             # not summed up out of rounded dK rows
             grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[H:2 * H]), db[2 * H:]
-            dW = self._dw(dqkv, self._bf16(x16))
-            grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = dW[:H] * scale, dW[H:2 * H], dW[2 * H:]
-            w_qkv_t = torch.cat([P[a + "query.weight"] * scale, P[a + "key.weight"], P[a + "value.weight"]], 0).t().contiguous().to(torch.bfloat16)
+            grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = self._dw(
+                dqkv, self._bf16(x16), row_scales=[(H, scale), (H, 1.0), (H, 1.0)])
             dX = self._gemm(dqkv, w_qkv_t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res1)
-            self.saved[l] = None                                                          # release this layer's activations
+            self.saved[l] = self.wT[l] = None                                             # release this layer's activations
         # ---- embeddings: dropout(LayerNorm(word + position + type))
         d_e, _, dge, dbe, _ = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
         grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe

@@ -179,12 +179,19 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
 }
 
 // out[j] (+)= sum over `n` rows of part[row * stride + j]: 32 columns per block, eight row groups (rows g, g + 8, ...) summed in a fixed
-// order - the same bits every run
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int n, size_t stride, float* __restrict__ out,
-                                                        int cols, int accumulate) {
+// order - the same bits every run.  blockIdx.y selects one of up to three (part offset, out) pairs, so the LayerNorm backward reduces its
+// gamma / beta / bias partials in one launch.
+struct ColReduceOut {
+  float* out[3];
+  size_t off[3];
+};
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int n, size_t stride, ColReduceOut o, int cols,
+                                                        int accumulate) {
   __shared__ float red[8][32];
   const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cx;
+  float* __restrict__ out = o.out[blockIdx.y];
+  part += o.off[blockIdx.y];
   float s0 = 0.f, s1 = 0.f;
   if (j < cols) {
     int r = g;
@@ -202,6 +209,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     for (int k = 1; k < 8; ++k) s += red[k][cx];
     out[j] = accumulate ? out[j] + s : s;
   }
+}
+static void colreduce(const float* part, int n, size_t stride, float* out, int cols, int accumulate, hipStream_t s) {
+  ColReduceOut o = {{out, nullptr, nullptr}, {0, 0, 0}};
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, s, part, n, stride, o, cols, accumulate);
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -279,6 +290,27 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
   __syncthreads();
   for (int c = ty; c < 64; c += 4)
     if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * ldo + r0 + tx] = tile[tx][c];
+}
+
+// One pass over an fp32 master weight (rows x cols): out16 = f16(scale * W) in place of the forward's operand, outT = bf16(scale * W)^T
+// (cols x rows) for dX = dY . W as an NT product.  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, int ldw, float scale, f16_t* __restrict__ out16, int ld16,
+                                                          bf16_t* __restrict__ outT, int ldT, int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    float v = 0.f;
+    if (r0 + r < rows && c0 + tx < cols) {
+      v = w[(size_t)(r0 + r) * ldw + c0 + tx] * scale;
+      if (out16) out16[(size_t)(r0 + r) * ld16 + c0 + tx] = (f16_t)v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (outT)
+    for (int c = ty; c < 64; c += 4)
+      if (c0 + c < cols && r0 + tx < rows) outT[(size_t)(c0 + c) * ldT + r0 + tx] = (bf16_t)tile[tx][c];
 }
 
 // C[m][n] (+)= sum_z part[z][m][n]  (fp32, z in order)
@@ -385,11 +417,9 @@ extern "C" int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, co
   const int blocks = min(LN_BWD_BLOCKS, ceil_div(rows, 4));
   hipLaunchKernelGGL(ln_train_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, add, add_scale, (const f16_t*)pre16, ld16,
                      stats, gamma, p, seed, post, d_res, ldd, (bf16_t*)d_gemm_bf16, ldg, ws, rows, H);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)3 * H, d_gamma, H, accumulate);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws + H, blocks, (size_t)3 * H, d_beta, H, accumulate);
-  if (d_bias && !post)
-    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32)), dim3(256), 0, (hipStream_t)stream, ws + 2 * H, blocks, (size_t)3 * H, d_bias, H,
-                       accumulate);
+  ColReduceOut o = {{d_gamma, d_beta, d_bias}, {0, (size_t)H, (size_t)2 * H}};
+  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32), (d_bias && !post) ? 3 : 2), dim3(256), 0, (hipStream_t)stream, ws, blocks,
+                     (size_t)3 * H, o, H, accumulate);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -426,7 +456,7 @@ extern "C" int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_b
   hipLaunchKernelGGL(gelu16_bwd_kernel, dim3(ceil_div(cols, 1024), rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg_bf16,
                      (const f16_t*)h16, (bf16_t*)dh_bf16, (bf16_t*)g_bf16, d_bias ? ws : nullptr, rows, cols);
   if (d_bias)
-    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, (hipStream_t)stream, ws, rb, (size_t)cols, d_bias, cols, 0);
+    colreduce(ws, rb, (size_t)cols, d_bias, cols, 0, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -438,7 +468,7 @@ extern "C" int ruart_colsum_bf16(const void* x_bf16, int ld, int rows, int cols,
   const int chunks = ceil_div(rows, 256);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ld, rows,
                      cols, ws);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, (hipStream_t)stream, ws, chunks, (size_t)cols, out, cols, accumulate);
+  colreduce(ws, chunks, (size_t)cols, out, cols, accumulate, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -453,6 +483,16 @@ extern "C" int ruart_transpose16(const void* in, int ldi, void* out, int ldo, in
   else
     hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ldi, (unsigned short*)out, ldo,
                        rows, cols);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols,
+                                 void* stream) {
+  RUART_ENTRY();
+  if (!w || rows <= 0 || cols <= 0 || (!out16 && !outT_bf16)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, (hipStream_t)stream, w, ldw, scale,
+                     (f16_t*)out16, ld16, (bf16_t*)outT_bf16, ldT, rows, cols);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -485,7 +525,7 @@ extern "C" int ruart_mix_rows_bwd(const void* layers16, long long layer_stride, 
   const int blocks = min(512, ceil_div(rows, 4));
   hipLaunchKernelGGL(mix_rows_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)layers16, (size_t)layer_stride, ld, n_layers,
                      g, ldg, ws, rows, H);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(n_layers, 32)), dim3(256), 0, (hipStream_t)stream, ws, blocks, (size_t)n_layers, d_w, n_layers, 0);
+  colreduce(ws, blocks, (size_t)n_layers, d_w, n_layers, 0, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }

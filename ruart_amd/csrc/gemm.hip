@@ -374,12 +374,13 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   const int fr = lane & 15, fq = lane >> 4;
   typedef typename Vec8<T16>::type frag_t;
   frag_t af[4][2], wf0[2][2], wf1[2][2];
+  // (k-step outer: LDS returns in order, and the first eight MFMAs of a quadrant need only the ks = 0 fragments)
   auto read_a = [&](int d, int h) {
     const char* sa = smem + d * kBuf + h * kHalf;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[j][ks] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + j * 16 + fr, ks * 4 + fq));
+      for (int j = 0; j < 4; ++j) af[j][ks] = *reinterpret_cast<const frag_t*>(sa + lds_off(wm * 64 + j * 16 + fr, ks * 4 + fq));
   };
   auto read_w = [&](int d, int h, frag_t (&wf)[2][2]) {
     const char* sw = smem + d * kBuf + kOper + h * kHalf;
@@ -410,6 +411,11 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   // one K-tile = four phases.  D: LDS buffer of this tile; N1: K-tile t+1 exists; N2: K-tile t+2 exists.
   // RUART_P8_BALANCED=1 (diagnostic builds): the read balancing that gemm_tn.hip ships.  Here it measures neutral (layer average 728 us
   // against 724 us over three interleaved runs of tools/gemm_corr_bench.py), so the plain schedule below stays the product.
+  // RUART_P8_FULLWAIT=0 (diagnostic builds) drops the full LDS wait behind each phase's first barrier and lets the compiler's own
+  // per-fragment waits start the MFMAs as the fragments arrive: measured neutral (712-721 vs 716 us per layer), so the waits stay.
+#ifndef RUART_P8_FULLWAIT
+#define RUART_P8_FULLWAIT 1
+#endif
 #ifndef RUART_P8_BALANCED
 #define RUART_P8_BALANCED 0
 #endif
@@ -479,21 +485,21 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     if (S1 && !(ab & 16)) stage_a(D ^ 1, 1, t + 1);
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W-h0 reads (issued first) are back: its slot may be restaged
     RUART_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (RUART_P8_FULLWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (S1) quad(0, 0, wf0, [&] { stage_a(D ^ 1, 1, t + 1); }); else quad(0, 0, wf0, nothing);
     RUART_BAR();
     // phase 1: (rows h0, cols h1); prefetch (t+2, W-h0)
     if (rd) read_w(D, 1, wf1);
     if (S2 && !(ab & 16)) stage_w(D, 0, t + 2);
     RUART_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (RUART_P8_FULLWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (S2) quad(1, 0, wf1, [&] { stage_w(D, 0, t + 2); }); else quad(1, 0, wf1, nothing);
     RUART_BAR();
     // phase 2: (rows h1, cols h1); prefetch (t+2, A-h0)
     if (rd) read_a(D, 1);
     if (S2 && !(ab & 16)) stage_a(D, 0, t + 2);
     RUART_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (RUART_P8_FULLWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (S2) quad(1, 1, wf1, [&] { stage_a(D, 0, t + 2); }); else quad(1, 1, wf1, nothing);
     RUART_BAR();
     // phase 3: (rows h1, cols h0) - operands already in registers; prefetch (t+2, W-h1)

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ruart_gelu16_bwd_ws_floats": (c_size_t, [_I, _I]),
     "ruart_gelu16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ruart_f16_to_bf16": (_I, [_P, _P, _LL, _P]),
+    "ruart_weight_prep": (_I, [_P, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "ruart_colsum_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "ruart_transpose16": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "ruart_splitk_reduce": (_I, [_P, _LL, _I, _P, _LL, _F, _I, _P]),

@@ -158,6 +158,21 @@ def test_gelu16_colsum_transpose_mix():
     assert float((dw - refw).abs().max()) < 1e-4 * float(refw.abs().max()) + 1e-2
 
 
+def test_weight_prep_f16_and_transposed_bf16():
+    lib = hip.load()
+    g = torch.Generator().manual_seed(5)
+    H = 200
+    W = torch.randn(3 * H, H + 8, generator=g).to(DEV)                                  # three (H x H) weights inside wider storage
+    w16 = torch.zeros(3 * H, H, dtype=torch.float16, device=DEV)
+    wT = torch.zeros(H, 3 * H, dtype=torch.bfloat16, device=DEV)
+    for i, sc in enumerate((0.125, 1.0, 1.0)):
+        assert lib.ruart_weight_prep(hip.ptr(W[i * H:]), H + 8, sc, hip.ptr(w16[i * H:]), H, hip.ptr(wT[:, i * H:]), 3 * H, H, H, _st()) == 0
+    ref = W[:, :H].clone()
+    ref[:H] *= 0.125
+    assert torch.equal(w16, ref.half()) and torch.equal(wT, ref.bfloat16().t())
+    assert lib.ruart_weight_prep(hip.ptr(W), H + 8, 1.0, None, 0, None, 0, H, H, _st()) != 0
+
+
 def test_intermediate_dense_keeps_preactivation():
     """ruart_gemm_16_nt_gelu2: one product, two outputs - H = A . W^T + b and G = gelu(H) (Models/Bert/modeling.py:287-288)."""
     lib = hip.load()
