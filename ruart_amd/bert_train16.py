@@ -61,6 +61,9 @@ class _Run:
         # one 31-bit stream id per pass (CPU generator: no device sync); every dropout site adds its own offset
         self.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.p_h > 0 or self.p_a > 0) else 0
 
+    def _st(self):
+        return hip.stream_ptr(self.dev)                             # the stream of the tensors' device, not of the current one
+
     # -- small launch helpers ----------------------------------------------------------------------------------------------
     def _new(self, rows, cols, dtype, zero=False):
         """(rows, cols) buffer; ``zero``: the pad rows past the last real token are cleared (the kernels behind it write the real ones)"""
@@ -75,7 +78,7 @@ class _Run:
         N = W.shape[0]
         out_dt = hip.DT_F32 if out.dtype == torch.float32 else in_dt
         _chk(self.lib.ruart_gemm_16_nt(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(bias), hip.ptr(res), N, res_dt, hip.ptr(out), N, out_dt, M, N, K, act,
-                                       in_dt, hip.stream_ptr()), "ruart_gemm_16_nt")
+                                       in_dt, self._st()), "ruart_gemm_16_nt")
         return out
 
     def _seed(self, layer, site):
@@ -86,7 +89,7 @@ class _Run:
         y = self._new(Tp, H, torch.float16) if out is None else out
         pre, st = self._new(Tp, H, torch.float16), self._new(Tp, 2, torch.float32)
         _chk(self.lib.ruart_ln_train_fwd(hip.ptr(x32), H, hip.ptr(res16), H, hip.ptr(g), hip.ptr(b), 1e-12, float(p), int(seed), post, hip.ptr(y),
-                                         hip.ptr(pre), hip.ptr(st), H, Tp, H, hip.stream_ptr()), "ruart_ln_train_fwd")
+                                         hip.ptr(pre), hip.ptr(st), H, Tp, H, self._st()), "ruart_ln_train_fwd")
         return y, pre, st
 
     def _attention_ok(self):
@@ -101,14 +104,14 @@ class _Run:
         wq16, wqT = torch.empty(3 * H, H, dtype=torch.float16, device=dev), torch.empty(H, 3 * H, dtype=torch.bfloat16, device=dev)
         for i, (n, sc) in enumerate((("query", scale), ("key", 1.0), ("value", 1.0))):
             _chk(self.lib.ruart_weight_prep(hip.ptr(P[a + n + ".weight"]), H, float(sc), hip.ptr(wq16[i * H:]), H, hip.ptr(wqT[:, i * H:]), 3 * H, H, H,
-                                            hip.stream_ptr()), "ruart_weight_prep")
+                                            self._st()), "ruart_weight_prep")
         out = [wq16]
         back = [wqT]
         for n, rows, cols in (("attention.output.dense", H, H), ("intermediate.dense", I, H), ("output.dense", H, I)):
             w16 = torch.empty(rows, cols, dtype=torch.float16, device=dev)
             wT = torch.empty(cols, rows, dtype=torch.bfloat16, device=dev)
             _chk(self.lib.ruart_weight_prep(hip.ptr(P[pre + n + ".weight"]), cols, 1.0, hip.ptr(w16), cols, hip.ptr(wT), rows, rows, cols,
-                                            hip.stream_ptr()), "ruart_weight_prep")
+                                            self._st()), "ruart_weight_prep")
             out.append(w16)
             back.append(wT)
         self.wT.append(back)
@@ -118,7 +121,7 @@ class _Run:
     def forward(self, layer_w):
         P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
         pk = self.packed
-        st = hip.stream_ptr
+        st = self._st
         scale = 1.0 / float(np.sqrt(H // self.nh))
         ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
         e = torch.zeros(Tp, H, dtype=torch.float32, device=self.dev)
@@ -162,7 +165,7 @@ class _Run:
     def _bf16(self, x16):
         """bf16 copy of a saved f16 activation (the X operand of a weight-gradient product; transient)"""
         out = self.xb[:x16.numel()].view(x16.shape)
-        _chk(self.lib.ruart_f16_to_bf16(hip.ptr(x16), hip.ptr(out), x16.numel(), hip.stream_ptr()), "ruart_f16_to_bf16")
+        _chk(self.lib.ruart_f16_to_bf16(hip.ptr(x16), hip.ptr(out), x16.numel(), self._st()), "ruart_f16_to_bf16")
         return out
 
     def _dw(self, dY_bf16, X_bf16, row_scales=None):
@@ -177,12 +180,12 @@ class _Run:
         tchunk = ((Tp + nz - 1) // nz + 127) // 128 * 128
         nz = (Tp + tchunk - 1) // tchunk
         part = self.part[:nz * M * N]
-        _chk(lib.ruart_gemm_16_tn_splitk(hip.ptr(dY_bf16), M, hip.ptr(X_bf16), N, hip.ptr(part), N, M, N, Tp, tchunk, hip.DT_BF16, hip.stream_ptr()),
+        _chk(lib.ruart_gemm_16_tn_splitk(hip.ptr(dY_bf16), M, hip.ptr(X_bf16), N, hip.ptr(part), N, M, N, Tp, tchunk, hip.DT_BF16, self._st()),
              "ruart_gemm_16_tn_splitk")
         outs, r0 = [], 0
         for rows, scale in (row_scales or [(M, 1.0)]):
             dW = torch.empty(rows, N, dtype=torch.float32, device=self.dev)
-            _chk(lib.ruart_splitk_reduce(hip.ptr(part[r0 * N:]), M * N, nz, hip.ptr(dW), rows * N, float(scale), 0, hip.stream_ptr()),
+            _chk(lib.ruart_splitk_reduce(hip.ptr(part[r0 * N:]), M * N, nz, hip.ptr(dW), rows * N, float(scale), 0, self._st()),
                  "ruart_splitk_reduce")
             outs.append(dW)
             r0 += rows
@@ -191,7 +194,7 @@ class _Run:
     def _colsum(self, d_bf16):
         n = d_bf16.shape[1]
         out = torch.empty(n, dtype=torch.float32, device=self.dev)
-        _chk(self.lib.ruart_colsum_bf16(hip.ptr(d_bf16), n, self.Tp, n, hip.ptr(out), 0, hip.ptr(self.cs_ws), hip.stream_ptr()), "ruart_colsum_bf16")
+        _chk(self.lib.ruart_colsum_bf16(hip.ptr(d_bf16), n, self.Tp, n, hip.ptr(out), 0, hip.ptr(self.cs_ws), self._st()), "ruart_colsum_bf16")
         return out
 
     def _ln_bwd(self, dy, add, add_scale, pre16, stats, gamma, p, seed, post=0):
@@ -202,13 +205,13 @@ class _Run:
         dbias = torch.empty(H, device=self.dev) if not post else None
         _chk(self.lib.ruart_ln_train_bwd(hip.ptr(dy), H, hip.ptr(add), hip.ptr(add_scale), hip.ptr(pre16), H, hip.ptr(stats), hip.ptr(gamma), float(p),
                                          int(seed), post, hip.ptr(d_res), H, hip.ptr(d_gemm), H, hip.ptr(dg), hip.ptr(db), hip.ptr(dbias), 0,
-                                         hip.ptr(self.ln_ws), self.T, H, hip.stream_ptr()), "ruart_ln_train_bwd")
+                                         hip.ptr(self.ln_ws), self.T, H, self._st()), "ruart_ln_train_bwd")
         return d_res, d_gemm, dg, db, dbias
 
     def backward(self, g_mixed):
         P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
         pk = self.packed
-        st = hip.stream_ptr
+        st = self._st
         dev = self.dev
         scale = 1.0 / float(np.sqrt(H // self.nh))
         grads = {}
