@@ -278,15 +278,29 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
   float* dst = gw + (size_t)seg_row[s] * D;
   const int G = 256 / dpad;                     // occurrence groups working side by side on narrow tables (dpad = 8..256)
   const int g = tid / dpad, dl = tid % dpad;
+  if (G == 1) {
+    // wide tables (D > 128): a frequent row (hundreds of occurrences in one batch) is a chain of dependent loads, so four occurrences
+    // are in flight per lane and the four partial sums are combined in a fixed order
+    for (int d = tid; d < D; d += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int i = beg;
+      for (; i + 3 < end; i += 4) {
+        const int o0 = order[i], o1 = order[i + 1], o2 = order[i + 2], o3 = order[i + 3];
+        a0 += gy[(size_t)o0 * D + d];
+        a1 += gy[(size_t)o1 * D + d];
+        a2 += gy[(size_t)o2 * D + d];
+        a3 += gy[(size_t)o3 * D + d];
+      }
+      for (; i < end; ++i) a0 += gy[(size_t)order[i] * D + d];
+      dst[d] = (a0 + a1) + (a2 + a3);
+    }
+    return;
+  }
   for (int d0 = 0; d0 < D; d0 += dpad) {
     const int d = d0 + dl;
     float acc = 0.f;
     if (d < D)
       for (int i = beg + g; i < end; i += G) acc += gy[(size_t)order[i] * D + d];
-    if (G == 1) {
-      if (d < D) dst[d] = acc;
-      continue;
-    }
     __syncthreads();
     red[tid] = acc;
     __syncthreads();
