@@ -292,6 +292,8 @@ class BatchIndex:
             self.plan = (bool(pack), bool(mfma_long))
             groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
             self.packed = PackedTokens(groups, None, pack=pack, mfma_long=mfma_long)
+            if "LOCK_BERT" not in opt:
+                self.packed.prepare_embedding_sorts()      # trainable encoder: its embedding gradients take the sorted, ordered path
             spans = []
             for g, (items, wk) in enumerate(((q_list, wk_q), (ocr_list, wk_o), (od_list, wk_o))):
                 wm = _np(items[wk + "_mask"])

@@ -273,9 +273,13 @@ class _Run:
         d_e, _, dge, dbe, _ = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
         grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe
         d_e = d_e[:T]
-        ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
-        grads["embeddings.word_embeddings.weight"] = torch.zeros_like(P["embeddings.word_embeddings.weight"]).index_add_(0, ids, d_e)
-        grads["embeddings.position_embeddings.weight"] = torch.zeros_like(P["embeddings.position_embeddings.weight"]).index_add_(0, pos, d_e)
+        d_e = d_e.contiguous()
+        for name, (order, seg_start, seg_row) in zip(("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"),
+                                                     pk.embedding_sorts(dev)):
+            gw = torch.zeros_like(P[name])                      # rows never looked up keep the zero
+            _chk(lib.ruart_embedding_bwd_sorted(hip.ptr(d_e), hip.ptr(order), hip.ptr(seg_start), hip.ptr(seg_row), seg_row.numel(), H, hip.ptr(gw),
+                                                st()), "ruart_embedding_bwd_sorted")
+            grads[name] = gw
         gt = torch.zeros_like(P["embeddings.token_type_embeddings.weight"])
         gt[0] = d_e.sum(0)
         grads["embeddings.token_type_embeddings.weight"] = gt

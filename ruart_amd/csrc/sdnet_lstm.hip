@@ -279,21 +279,22 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
   const int G = 256 / dpad;                     // occurrence groups working side by side on narrow tables (dpad = 8..256)
   const int g = tid / dpad, dl = tid % dpad;
   if (G == 1) {
-    // wide tables (D > 128): a frequent row (hundreds of occurrences in one batch) is a chain of dependent loads, so four occurrences
-    // are in flight per lane and the four partial sums are combined in a fixed order
-    for (int d = tid; d < D; d += 256) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int i = beg;
-      for (; i + 3 < end; i += 4) {
-        const int o0 = order[i], o1 = order[i + 1], o2 = order[i + 2], o3 = order[i + 3];
-        a0 += gy[(size_t)o0 * D + d];
-        a1 += gy[(size_t)o1 * D + d];
-        a2 += gy[(size_t)o2 * D + d];
-        a3 += gy[(size_t)o3 * D + d];
-      }
-      for (; i < end; ++i) a0 += gy[(size_t)order[i] * D + d];
-      dst[d] = (a0 + a1) + (a2 + a3);
+    // wide tables (D > 128; blockIdx.y = chunk of 256 columns): a frequent row - the position table of the trainable encoder has 64
+    // rows with ~700 occurrences each - is a chain of dependent loads, so eight occurrences are in flight per lane and the eight partial
+    // sums are combined in a fixed order
+    const int d = blockIdx.y * 256 + tid;
+    if (d >= D) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = beg;
+    for (; i + 7 < end; i += 8) {
+      int o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = order[i + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += gy[(size_t)o[k] * D + d];
     }
+    for (int k = 0; i < end; ++i, ++k) a[k] += gy[(size_t)order[i] * D + d];
+    dst[d] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     return;
   }
   for (int d0 = 0; d0 < D; d0 += dpad) {
@@ -319,8 +320,8 @@ extern "C" int ruart_embedding_bwd_sorted(const float* grad_out, const int* orde
   if (n_seg == 0) return 0;
   int dpad = 8;
   while (dpad < D && dpad < 256) dpad <<= 1;
-  hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, grad_out, order, seg_start, seg_row,
-                     grad_weight, D, dpad);
+  hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(n_seg, dpad == 256 ? (D + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, grad_out,
+                     order, seg_start, seg_row, grad_weight, D, dpad);
   RUART_CHECK_LAUNCH();
   return 0;
 }

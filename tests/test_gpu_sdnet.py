@@ -538,6 +538,43 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
     assert worst_trunk[0] < tol_trunk, worst_trunk
 
 
+def test_unlocked_16bit_encoder_is_repeatable_and_falls_back(golden_dir):
+    """The 16-bit trainable encoder, dropout ON (hash-generated multipliers): two passes from the same generator state give bitwise the
+    same scores and gradients (ordered reductions, no atomics), another seed gives other masks; a batch with a sequence longer than the
+    attention kernels' 64-token window takes the fp32-class path of bert_train.py instead of failing."""
+    z = np.load(os.path.join(golden_dir, "sdnet_e2e_unlocked.npz"))
+    net, opt = _unlocked(z, "x3", bert_train_gemm="16")
+    net.Bert.bert_model.p_hidden = net.Bert.bert_model.p_attn = 0.1
+    import ruart_amd.layers as L
+    L.set_dropout_prob(0.0)
+    net.train()
+    net.drop_emb = False
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=12, n_ocr=16, n_od=6, bert_vocab=2000, ragged=True)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        net.zero_grad(set_to_none=True)
+        scores, _ = net(q, ocr, od)
+        (torch.nn.functional.binary_cross_entropy_with_logits(scores, gt.to(scores.device)) * gt.size(1)).backward()
+        return scores.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    s1, g1 = run(5)
+    s2, g2 = run(5)
+    s3, _ = run(6)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+    assert g1.keys() == g2.keys() and all(torch.equal(g1[n], g2[n]) for n in g1), [n for n in g1 if not torch.equal(g1[n], g2[n])][:3]
+    assert any(n.startswith("Bert.") for n in g1)
+    # a 90-word question: more than 64 word pieces in one sequence
+    ql, ocrl, odl, gtl, _ = synth.synthetic_batch(opt, 2, seed=3, n_q=90, n_ocr=8, n_od=4, bert_vocab=2000, ragged=False)
+    from ruart_amd.bert_train16 import BertModelTrainable16
+    assert isinstance(net.Bert.bert_model, BertModelTrainable16)
+    net.zero_grad(set_to_none=True)
+    scores, _ = net(ql, ocrl, odl)
+    scores.sum().backward()
+    net.check_nan()
+    assert torch.isfinite(dict(net.named_parameters())["Bert.bert_model.encoder.layer.0.output.dense.weight"].grad).all()
+
+
 @pytest.mark.parametrize("train_gemm", ["x3", "16"])
 def test_unlocked_bert_trains_with_the_fused_optimizer(train_gemm):
     """The trainer path without LOCK_BERT: BERT's parameters sit in the (fused) Adamax, its own dropout is active in training
