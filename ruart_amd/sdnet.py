@@ -284,9 +284,11 @@ class SDNet(nn.Module):
             self.Bert.prefetch(self.prepare(*nxt).packed)
 
     def _use_streams(self):
-        """Question / object / OCR branches on three streams - with a frozen encoder.  The trainable encoder's step is 10x longer
-        and gains nothing measurable from the overlap; its first version (library GEMMs of extreme shape running on the three
-        streams at once) also stopped completing steps at B = 64 - DESIGN.md section 5 - so that mode stays on one stream."""
+        """Question / object / OCR branches on three streams - with a frozen encoder.  With a trainable encoder the step stays on one
+        stream: the fp32-class graph's first version (library GEMMs of extreme shape on the three streams at once) stopped completing
+        steps at B = 64, and for the 16-bit encoder the three-stream trunk was measured again in round 2 - 1 189
+        to 1 201 samples/s against 1 192 to 1 205 on one stream: the whole trunk is already queued behind the encoder's backward, so
+        there is no gap for the overlap to fill."""
         if ops.trunk_gemm != "x3":          # exact-fp32 validation mode: its projections are library GEMMs (stream-K solutions that
             return False                     # need all their workgroups resident) - never beside other streams' kernels
         return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or getattr(self.Bert, "bert_model", None) is None)
