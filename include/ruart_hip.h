@@ -286,6 +286,10 @@ int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, const float* a
  * order given (deterministic).  Replaces the device-side sort torch runs in every backward. */
 int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg, int D,
                                float* grad_weight, void* stream);
+/* Two-level form for tables where one row collects thousands of occurrences per batch (batch._sort_ids cuts such rows into sub-segments of
+ * <= 64): ws (n_sub x D floats) receives the sub-segment sums, grad_weight[row_id[r]] = sum of ws rows row_first[r] .. row_first[r+1]. */
+int ruart_embedding_bwd_split(const float* grad_out, const int* order, const int* sub_start, int n_sub, const int* row_first, const int* row_id,
+                              int n_rows, int D, float* ws, float* grad_weight, void* stream);
 
 /* PHOC table (Utils/cphoc.c:12-113 `build_phoc`, applied per vocabulary word by Utils/CoQAUtils.py:75-87): row w of `out`
  * (n_words x 604 fp32, row stride ldo >= 604, ldo % 4 == 0, 16-byte aligned) = the pyramidal histogram of characters of the word

@@ -249,9 +249,12 @@ class ItemIndex:
         self.dev = dict(zip(self._FIELDS, tensors))
 
 
-def _sort_ids(ids, padding_idx=None):
-    """(order, seg_start, seg_row) int32 of an id vector: positions grouped by id (stable), the group boundaries and the id of
-    each group; the padding row (its gradient is defined as zero) is left out."""
+def _sort_ids(ids, padding_idx=None, max_seg=64):
+    """The sort ops.embedding's backward works from, int32: positions grouped by id (stable; the padding row - its gradient is defined as
+    zero - left out).  Returns (order, seg_start, seg_row) - seg_start[s] .. seg_start[s+1] is the slice of order[] that hit table row
+    seg_row[s] - or, when some row has more than ``max_seg`` occurrences (a frequent word, [CLS] / [SEP], the first positions: one
+    workgroup would add thousands of rows one after the other), the two-level form (order, sub_start, row_first, row_id): sub-segments of
+    at most max_seg occurrences, and row r = the sum of sub-segments row_first[r] .. row_first[r+1]."""
     ids = np.asarray(ids, dtype=np.int64)
     order = np.argsort(ids, kind="stable")
     sid = ids[order]
@@ -262,7 +265,16 @@ def _sort_ids(ids, padding_idx=None):
         return np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
     first = np.concatenate([[True], sid[1:] != sid[:-1]])
     starts = np.flatnonzero(first)
-    return order.astype(np.int32), np.concatenate([starts, [len(sid)]]).astype(np.int32), sid[starts].astype(np.int32)
+    bounds = np.concatenate([starts, [len(sid)]])
+    lens = np.diff(bounds)
+    if lens.max() <= max_seg:
+        return order.astype(np.int32), bounds.astype(np.int32), sid[starts].astype(np.int32)
+    n_sub = (lens + max_seg - 1) // max_seg                           # sub-segments per row
+    row_first = np.concatenate([[0], np.cumsum(n_sub)])
+    row_of_sub = np.repeat(np.arange(len(lens)), n_sub)
+    k_in_row = np.arange(row_first[-1]) - row_first[row_of_sub]
+    sub_start = np.concatenate([starts[row_of_sub] + k_in_row * max_seg, [len(sid)]])
+    return order.astype(np.int32), sub_start.astype(np.int32), row_first.astype(np.int32), sid[starts].astype(np.int32)
 
 
 class BatchIndex:

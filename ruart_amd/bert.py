@@ -204,26 +204,29 @@ class PackedTokens:
 
     def prepare_embedding_sorts(self):
         """Host part of the trainable encoder's embedding gradients (numpy; BatchIndex calls it in the DataLoader worker when the conf has
-        no LOCK_BERT): the word-piece ids and the positions of the packed stream, each sorted into (order, seg_start, seg_row) - the
-        input of ruart_embedding_bwd_sorted, which adds the gradient rows of one table row in a fixed order (torch's index_add_ uses
-        atomics: run-to-run different bits)."""
+        no LOCK_BERT): the word-piece ids and the positions of the packed stream, each sorted by batch._sort_ids - the input of
+        ops.embedding_grad, which adds the gradient rows of one table row in a fixed order (torch's index_add_ uses atomics: run-to-run
+        different bits)."""
         if getattr(self, "_emb_sorts_host", None) is None:
             from .batch import _sort_ids
             T, Tp = self.T, self.Tp
-            parts = [a for ids in (self.host[0:T], self.host[Tp:Tp + T]) for a in _sort_ids(ids)]
-            self._emb_sorts_host = (np.concatenate(parts).astype(np.int32), [len(a) for a in parts])
+            sorts = [_sort_ids(ids) for ids in (self.host[0:T], self.host[Tp:Tp + T])]
+            self._emb_sorts_host = (np.concatenate([a for srt in sorts for a in srt]).astype(np.int32), [[len(a) for a in srt] for srt in sorts])
         return self._emb_sorts_host
 
     def embedding_sorts(self, device):
-        """[(order, seg_start, seg_row) int32 device tensors] for the word-piece table and the position table (one H2D copy, cached)."""
+        """[sort of the word-piece ids, sort of the positions] as tuples of int32 device tensors (one H2D copy, cached)."""
         if getattr(self, "_emb_sorts", None) is None:
             flat, sizes = self.prepare_embedding_sorts()
             dev = torch.from_numpy(flat).to(device, non_blocking=True)
-            views, o = [], 0
-            for n in sizes:
-                views.append(dev[o:o + n])
-                o += n
-            self._emb_sorts = [tuple(views[0:3]), tuple(views[3:6])]
+            out, o = [], 0
+            for group in sizes:
+                views = []
+                for n in group:
+                    views.append(dev[o:o + n])
+                    o += n
+                out.append(tuple(views))
+            self._emb_sorts = out
         return self._emb_sorts
 
     def __getstate__(self):

@@ -273,13 +273,9 @@ class _Run:
         d_e, _, dge, dbe, _ = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
         grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe
         d_e = d_e[:T]
-        d_e = d_e.contiguous()
-        for name, (order, seg_start, seg_row) in zip(("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"),
-                                                     pk.embedding_sorts(dev)):
-            gw = torch.zeros_like(P[name])                      # rows never looked up keep the zero
-            _chk(lib.ruart_embedding_bwd_sorted(hip.ptr(d_e), hip.ptr(order), hip.ptr(seg_start), hip.ptr(seg_row), seg_row.numel(), H, hip.ptr(gw),
-                                                st()), "ruart_embedding_bwd_sorted")
-            grads[name] = gw
+        from .ops import embedding_grad
+        for name, srt in zip(("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"), pk.embedding_sorts(dev)):
+            grads[name] = embedding_grad(d_e, srt, P[name].shape)
         gt = torch.zeros_like(P["embeddings.token_type_embeddings.weight"])
         gt[0] = d_e.sum(0)
         grads["embeddings.token_type_embeddings.weight"] = gt

@@ -268,6 +268,10 @@ extern "C" int ruart_lstm_cell_bwd(const float* grad_h, const float* grad_c, con
 // loader worker): order[] lists the lookup positions grouped by table row, seg_start[s] .. seg_start[s+1] is the slice of
 // order[] that hit row seg_row[s].  One workgroup per distinct row adds its gradient rows in that fixed order (no atomics:
 // deterministic); rows that were never looked up keep the zero the caller filled gw with.
+// A row with very many occurrences (a frequent word; [CLS], [SEP] and the first positions of the trainable encoder's tables: thousands
+// per batch) would be one long chain of dependent loads in one workgroup, so the host cuts such rows into sub-segments of <= 64
+// occurrences (batch._sort_ids): ruart_embedding_bwd_split sums the sub-segments into a workspace with this kernel (seg_row == NULL:
+// segment s -> row s) and then the sub-segment sums of each row into gw with it again (order == NULL: occurrence i is workspace row i).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* __restrict__ gy, const int* __restrict__ order,
                                                                    const int* __restrict__ seg_start, const int* __restrict__ seg_row,
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
   __shared__ float red[256];
   const int s = blockIdx.x, tid = threadIdx.x;
   const int beg = seg_start[s], end = seg_start[s + 1];
-  float* dst = gw + (size_t)seg_row[s] * D;
+  float* dst = gw + (size_t)(seg_row ? seg_row[s] : s) * D;
   const int G = 256 / dpad;                     // occurrence groups working side by side on narrow tables (dpad = 8..256)
   const int g = tid / dpad, dl = tid % dpad;
   if (G == 1) {
@@ -289,11 +293,11 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
     for (; i + 7 < end; i += 8) {
       int o[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = order[i + k];
+      for (int k = 0; k < 8; ++k) o[k] = order ? order[i + k] : i + k;
 #pragma unroll
       for (int k = 0; k < 8; ++k) a[k] += gy[(size_t)o[k] * D + d];
     }
-    for (int k = 0; i < end; ++i, ++k) a[k] += gy[(size_t)order[i] * D + d];
+    for (int k = 0; i < end; ++i, ++k) a[k] += gy[(size_t)(order ? order[i] : i) * D + d];
     dst[d] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     return;
   }
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
     const int d = d0 + dl;
     float acc = 0.f;
     if (d < D)
-      for (int i = beg + g; i < end; i += G) acc += gy[(size_t)order[i] * D + d];
+      for (int i = beg + g; i < end; i += G) acc += gy[(size_t)(order ? order[i] : i) * D + d];
     __syncthreads();
     red[tid] = acc;
     __syncthreads();
@@ -313,15 +317,32 @@ __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const float* 
   }
 }
 
+static void launch_embedding_bwd(const float* gy, const int* order, const int* seg_start, const int* seg_row, int n_seg, int D, float* out,
+                                 hipStream_t stream) {
+  int dpad = 8;
+  while (dpad < D && dpad < 256) dpad <<= 1;
+  hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(n_seg, dpad == 256 ? (D + 255) / 256 : 1), dim3(256), 0, stream, gy, order, seg_start,
+                     seg_row, out, D, dpad);
+}
+
 extern "C" int ruart_embedding_bwd_sorted(const float* grad_out, const int* order, const int* seg_start, const int* seg_row, int n_seg,
                                           int D, float* grad_weight, void* stream) {
   RUART_ENTRY();
-  if (n_seg < 0 || D <= 0 || D > 4096) return (int)hipErrorInvalidValue;
+  if (n_seg < 0 || D <= 0 || D > 4096 || (n_seg && (!order || !seg_start || !seg_row))) return (int)hipErrorInvalidValue;
   if (n_seg == 0) return 0;
-  int dpad = 8;
-  while (dpad < D && dpad < 256) dpad <<= 1;
-  hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(n_seg, dpad == 256 ? (D + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, grad_out,
-                     order, seg_start, seg_row, grad_weight, D, dpad);
+  launch_embedding_bwd(grad_out, order, seg_start, seg_row, n_seg, D, grad_weight, (hipStream_t)stream);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_embedding_bwd_split(const float* grad_out, const int* order, const int* sub_start, int n_sub, const int* row_first,
+                                         const int* row_id, int n_rows, int D, float* ws, float* grad_weight, void* stream) {
+  RUART_ENTRY();
+  if (n_sub < 0 || n_rows < 0 || n_rows > n_sub || D <= 0 || D > 4096 || (n_sub && (!order || !sub_start || !row_first || !row_id || !ws)))
+    return (int)hipErrorInvalidValue;
+  if (n_sub == 0) return 0;
+  launch_embedding_bwd(grad_out, order, sub_start, nullptr, n_sub, D, ws, (hipStream_t)stream);          // ws[s] = sum of sub-segment s
+  launch_embedding_bwd(ws, nullptr, row_first, row_id, n_rows, D, grad_weight, (hipStream_t)stream);      // gw[row] = its sub-segments, in order
   RUART_CHECK_LAUNCH();
   return 0;
 }

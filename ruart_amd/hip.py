@@ -91,6 +91,7 @@ _SIGNATURES = {
     "ruart_grad_norm_clip": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P]),
     "ruart_adamax_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _F, _F, _F, _P]),
     "ruart_embedding_bwd_sorted": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "ruart_embedding_bwd_split": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "ruart_phoc_table": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "ruart_gemm_bf16_tn": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _I, _I, _I, _P, ctypes.c_size_t, _P]),
     "ruart_gemm_x3_plan": (_I, [_I, _I, _I, _I, _I, POINTER(ctypes.c_int), POINTER(ctypes.c_size_t)]),

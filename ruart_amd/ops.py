@@ -453,25 +453,40 @@ def lstm_cell(pre, h_prev, c_prev, n_active):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def embedding_grad(gy, sort, shape):
+    """Gradient of an embedding table (``shape`` = (V, D)) from the (n, D) gradient rows of its lookups and the host-prepared sort of
+    their ids (batch._sort_ids): 3 tensors = one workgroup per looked-up row; 4 tensors = the two-level form for rows with very many
+    occurrences.  Ordered sums, no atomics: the same bits every run."""
+    V, D = shape
+    lib = hip.load()
+    gw = torch.zeros(V, D, dtype=torch.float32, device=gy.device)
+    gy = gy.reshape(-1, D).contiguous()
+    if len(sort) == 3:
+        order, seg_start, seg_row = sort
+        hip.check(lib.ruart_embedding_bwd_sorted(hip.ptr(gy), hip.ptr(order), hip.ptr(seg_start), hip.ptr(seg_row), seg_row.numel(), D, hip.ptr(gw),
+                                                 hip.stream_ptr(gy.device)), "ruart_embedding_bwd_sorted")
+    else:
+        order, sub_start, row_first, row_id = sort
+        n_sub = sub_start.numel() - 1
+        ws = torch.empty(max(n_sub, 1), D, dtype=torch.float32, device=gy.device)
+        hip.check(lib.ruart_embedding_bwd_split(hip.ptr(gy), hip.ptr(order), hip.ptr(sub_start), n_sub, hip.ptr(row_first), hip.ptr(row_id),
+                                                row_id.numel(), D, hip.ptr(ws), hip.ptr(gw), hip.stream_ptr(gy.device)), "ruart_embedding_bwd_split")
+    return gw
+
+
 class _Embedding(torch.autograd.Function):
-    """weight[ids] whose backward uses a host-prepared sort of the ids (ruart_embedding_bwd_sorted) instead of sorting on the
-    device: ``sort`` = (order, seg_start, seg_row) int32 device tensors from batch.BatchIndex (padding_idx already left out)."""
+    """weight[ids] whose backward uses a host-prepared sort of the ids (``embedding_grad``) instead of sorting on the device: ``sort`` =
+    int32 device tensors from batch.BatchIndex (padding_idx already left out)."""
 
     @staticmethod
-    def forward(ctx, weight, ids, order, seg_start, seg_row):
-        ctx.save_for_backward(order, seg_start, seg_row)
+    def forward(ctx, weight, ids, *sort):
+        ctx.save_for_backward(*sort)
         ctx.wshape = weight.shape
         return weight.index_select(0, ids.reshape(-1)).view(*ids.shape, weight.shape[1])
 
     @staticmethod
     def backward(ctx, gy):
-        order, seg_start, seg_row = ctx.saved_tensors
-        V, D = ctx.wshape
-        gw = torch.zeros(V, D, dtype=torch.float32, device=gy.device)
-        gy = gy.reshape(-1, D).contiguous()
-        hip.check(hip.load().ruart_embedding_bwd_sorted(hip.ptr(gy), hip.ptr(order), hip.ptr(seg_start), hip.ptr(seg_row),
-                                                        seg_row.numel(), D, hip.ptr(gw), hip.stream_ptr()), "ruart_embedding_bwd_sorted")
-        return gw, None, None, None, None
+        return (embedding_grad(gy, ctx.saved_tensors, ctx.wshape), None) + (None,) * len(ctx.saved_tensors)
 
 
 def embedding(module, ids, sort=None):

@@ -618,11 +618,13 @@ def test_linear_x3_fused_dropout_mask():
     assert bool((got[1][mask.unsqueeze(1).expand_as(x) == 0] == 0).all())      # dropped features get exactly zero gradient
 
 
-@pytest.mark.parametrize("V,D,n,pad", [(2000, 300, 17000, 1), (51, 12, 17000, None), (75, 8, 2560, None), (300, 300, 40, 1), (10, 1000, 500, None)])
+@pytest.mark.parametrize("V,D,n,pad", [(2000, 300, 17000, 1), (51, 12, 17000, None), (75, 8, 2560, None), (300, 300, 40, 1), (10, 1000, 500, None),
+                                       (64, 768, 43000, None), (30522, 768, 43000, None)])
 def test_embedding_backward_from_host_sort(V, D, n, pad):
     """ops.embedding: forward = table lookup; backward = ruart_embedding_bwd_sorted driven by the host-side sort of the ids
     (batch._sort_ids): must equal nn.Embedding's gradient (padding row zero), for wide word tables, narrow POS / entity tables
-    with thousands of hits per row, and rows that are never hit."""
+    with thousands of hits per row (the two-level form: ruart_embedding_bwd_split), the trainable encoder's position table (64 rows,
+    ~670 hits each) and word-piece table ([CLS] / [SEP]: 8 600 hits each), and rows that are never hit."""
     from ruart_amd import ops
     from ruart_amd.batch import _sort_ids
     g = torch.Generator().manual_seed(V + D + n)
@@ -630,7 +632,10 @@ def test_embedding_backward_from_host_sort(V, D, n, pad):
     ids = torch.randint(0, V, (n,), generator=g)
     if pad is not None:
         ids[::7] = pad
+    if V > 20000:
+        ids[::5], ids[1::5] = 101, 102
     sort = tuple(torch.from_numpy(a).cuda() for a in _sort_ids(ids.numpy(), pad))
+    assert len(sort) == (4 if n // V > 64 or V > 20000 else 3)
     gy = torch.randn(n, D, generator=g).cuda()
     out = ops.embedding(emb, ids.cuda(), sort)
     out.backward(gy)
@@ -640,7 +645,7 @@ def test_embedding_backward_from_host_sort(V, D, n, pad):
     ref_out.backward(gy)
     assert torch.equal(out, ref_out)
     ref = emb.weight.grad
-    assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     if pad is not None:
         assert float(got[pad].abs().max()) == 0.0
     out2 = ops.embedding(emb, ids.cuda(), sort)                      # deterministic: same sum order every time

@@ -382,3 +382,26 @@ def test_collate_fast_path_equals_item_walk(golden_dir, tmp_path):
     bf, bs = BatchIndex(fast[0], fast[1], fast[2], opt), BatchIndex(slow[0], slow[1], slow[2], opt)
     assert np.array_equal(bf._spans_host[0], bs._spans_host[0]) and np.array_equal(bf.packed.host, bs.packed.host)
     assert np.array_equal(bf.ocr.flat_word, bs.ocr.flat_word) and np.array_equal(bf.od.step_rows, bs.od.step_rows)
+
+
+def test_sort_ids_two_level_form():
+    """batch._sort_ids: rows with more than max_seg occurrences are cut into sub-segments; the pieces tile order[] exactly and every
+    row's sub-segments are consecutive."""
+    from ruart_amd.batch import _sort_ids
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 40, 5000)
+    ids[::3] = 7                                                    # one very frequent row
+    ids[5::11] = 1                                                  # the padding row: left out
+    flat = _sort_ids(ids, padding_idx=None, max_seg=10 ** 6)
+    assert len(flat) == 3
+    order, sub_start, row_first, row_id = _sort_ids(ids, padding_idx=1, max_seg=64)
+    assert 1 not in row_id and sorted(row_id.tolist()) == sorted(set(ids.tolist()) - {1})
+    assert sub_start[0] == 0 and sub_start[-1] == len(order) == int((ids != 1).sum())
+    assert (np.diff(sub_start) > 0).all() and np.diff(sub_start).max() <= 64
+    assert row_first[0] == 0 and row_first[-1] == len(sub_start) - 1 and (np.diff(row_first) > 0).all()
+    for r, row in enumerate(row_id):
+        occ = order[sub_start[row_first[r]]:sub_start[row_first[r + 1]]]
+        assert (ids[occ] == row).all() and len(occ) == int((ids == row).sum())
+        assert (np.diff(occ) > 0).all()                             # stable: occurrences in their original order
+    short = _sort_ids(np.array([3, 3, 5]), None)
+    assert len(short) == 3 and short[1].tolist() == [0, 2, 3] and short[2].tolist() == [3, 5]

@@ -15,8 +15,10 @@ run h2d --include-h2d
 run dp --force-dp
 run stress --stress --steps 6 --warmup 2
 run stress_bf16 --stress --precision bf16 --steps 6 --warmup 2
-run unlock --unlock-bert --steps 4 --warmup 2
-run unlock16 --unlock-bert --train-gemm 16 --steps 4 --warmup 2
+run unlock_x3 --unlock-bert --train-gemm x3 --steps 4 --warmup 2
+run unlock_16gemm --unlock-bert --train-gemm 16gemm --steps 4 --warmup 2
+run unlock16 --unlock-bert --steps 8 --warmup 3
+run unlock16_dp --unlock-bert --force-dp --steps 8 --warmup 3
 timeout -k 10 300 python bench.py --mode bert512 --precision fp16 --steps 30 --warmup 10 > gpurun_out/r02_bert512_line.json 2>/dev/null
 timeout -k 10 400 python bench.py > gpurun_out/r02_bench_line.json 2>gpurun_out/r02_bench_line.err
 cat gpurun_out/r02_bench_line.json
