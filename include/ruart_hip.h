@@ -59,6 +59,13 @@ int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16,
  * (M x N) in the operands' 16-bit type, row stride ldc.  M, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* H16, void* G16, int ldc, int M, int N, int K,
                            int in_dtype, void* stream);
+/* Backward from the output dense to the intermediate dense output in one kernel: acc = dY (M x K bf16) . Wt (N x K bf16 = W2^T)^T, then with
+ * the saved f16 pre-activation H (M x N, row stride ldh): dH = acc * gelu'(H) and G = gelu(H), both bf16 (row stride ldc); colpart (optional,
+ * ruart_gemm_16_nt_gelu_bwd_ws_floats(M, N) floats) = column sums of the unrounded dH per 128-row strip, strip-major - sum the M / 128 strips
+ * in order for the intermediate bias gradient (ruart_colsum_f32_rows).  M, N % 256 == 0, K % 128 == 0. */
+size_t ruart_gemm_16_nt_gelu_bwd_ws_floats(int M, int N);
+int ruart_gemm_16_nt_gelu_bwd(const void* dY_bf16, int lda, const void* Wt_bf16, int ldw, const void* H16, int ldh, void* dH_bf16, void* G_bf16,
+                              int ldc, float* colpart, int M, int N, int K, void* stream);
 /* Split-K form for weight gradients (dW = dY^T . X with both operands given K-contiguous, i.e. transposed: ruart_transpose16):
  * part[z] (M x N fp32, row stride ldc; slabs M * ldc floats apart) = A[:, z kchunk ...] . W[:, z kchunk ...]^T, z < ceil(K / kchunk);
  * sum the slabs with ruart_splitk_reduce.  M, N % 256 == 0, K % 128 == 0, kchunk % 128 == 0. */
@@ -148,17 +155,12 @@ size_t ruart_ln_train_bwd_ws_floats(int H);
 int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, const float* add_scale, const void* pre16, int ld16, const float* stats,
                        const float* gamma, float p, unsigned seed, int post, float* d_res, int ldd, void* d_gemm_bf16, int ldg,
                        float* d_gamma, float* d_beta, float* d_bias, int accumulate, float* ws, int rows, int H, void* stream);
-/* Models/Bert/modeling.py:52-57: g = gelu(h) (f16 -> f16; n elements, n % 4 == 0) */
-int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* stream);
-/* ... and its backward over the (rows x cols) intermediate in one pass: dh (bf16) = dg (bf16) * gelu'(h); g_bf16 (optional) = gelu(h) again
- * as the bf16 operand of the next weight gradient; d_bias (optional, cols) = column sums of the unrounded dh.
- * ws: ruart_gelu16_bwd_ws_floats(rows, cols) floats when d_bias is given. */
-size_t ruart_gelu16_bwd_ws_floats(int rows, int cols);
-int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, void* g_bf16, float* d_bias, float* ws, int rows, int cols, void* stream);
 /* One pass over an fp32 master weight W (rows x cols, row stride ldw): out16 (rows x cols f16, row stride ld16) = scale * W, the forward's
  * GEMM operand, and outT_bf16 (cols x rows bf16, row stride ldT) = (scale * W)^T, the operand of dX = dY . W as an NT product.  Either output
  * may be NULL; both may point into wider matrices (the fused QKV weight: three calls with row / column offsets). */
 int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols, void* stream);
+/* out[j] (+)= sum over `rows` rows of part[r * ld + j], rows in a fixed order (the reduction behind the partial sums above) */
+int ruart_colsum_f32_rows(const float* part, int rows, int ld, int cols, float* out, int accumulate, void* stream);
 /* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
 int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */

@@ -4,20 +4,23 @@ Same parameters, names and dropout semantics as ``bert_train.BertModelTrainable`
 whole encoder - forward and backward - is ONE ``torch.autograd.Function`` over hand-written kernels instead of an autograd graph of
 torch row-wise ops:
 
-  forward   embeddings (torch gathers) -> ``ruart_ln_train_fwd`` (LayerNorm, then dropout: modeling.py:196-199); per layer
-            QKV / attention-output / intermediate / output projections on ``ruart_gemm_16_nt`` (f16 operands, the frozen path's MFMA
-            kernel), ``ruart_attn_train_fwd`` (MFMA flash attention with hash-generated probability dropout),
-            ``ruart_ln_train_fwd`` for dense -> dropout -> + input -> LayerNorm (:260-264, :299-303), ``ruart_gelu16_fwd``;
-            the layer mix of ``SDNet.linear_sum`` (Models/SDNet.py:573-581) is taken inside (``ruart_mix_rows``), so what
-            leaves is ONE (T, H) fp32 stream instead of twelve layer outputs
+  forward   embeddings (torch gathers) -> ``ruart_ln_train_fwd`` (LayerNorm, then dropout: modeling.py:196-199); per layer the master
+            weights become GEMM operands in one pass each (``ruart_weight_prep``: f16 for the forward, transposed bf16 for the backward);
+            QKV / attention-output / output projections on ``ruart_gemm_16_nt`` (f16 operands, the frozen path's MFMA kernel), the
+            intermediate one on ``ruart_gemm_16_nt_gelu2`` (pre-activation AND its GELU out of one epilogue), ``ruart_attn_train_fwd``
+            (MFMA flash attention with hash-generated probability dropout), ``ruart_ln_train_fwd`` for dense -> dropout -> + input ->
+            LayerNorm (:260-264, :299-303); the layer mix of ``SDNet.linear_sum`` (Models/SDNet.py:573-581) is taken inside
+            (``ruart_mix_rows``), so what leaves is ONE (T, H) fp32 stream instead of twelve layer outputs
   saved     per layer, f16: layer input, QKV rows, context rows, both LayerNorm inputs (+ mean / rstd), the intermediate
-            pre-activations: 0.8 GB per layer at the bench shape (9.3 GB for bert-base) - the GELU output and every dropout mask are
+            pre-activations: 0.8 GB per layer at the bench shape (9.9 GB for bert-base) - the GELU output and every dropout mask are
             recomputed
   backward  ``ruart_ln_train_bwd`` (residual-stream gradient in fp32, GEMM-bound gradient in bf16 with the dropout multiplier
-            regenerated from the seed; the layer-mix gradient joins the stream there), dX = dY . W on the same MFMA kernel with
-            bf16 operands (weights transposed once per step), dW = dY^T . X as split-K products of transposed bf16 copies
-            (``ruart_transpose16`` + ``ruart_gemm_16_nt_splitk`` + ``ruart_splitk_reduce``), ``ruart_attn_train_bwd``,
-            ``ruart_gelu16_bwd``, ``ruart_colsum_bf16`` for the biases.
+            regenerated from the seed, gamma / beta / dense-bias partial sums; the layer-mix gradient joins the stream there),
+            dX = dY . W on the same MFMA kernel with bf16 operands - the one through the GELU as ``ruart_gemm_16_nt_gelu_bwd`` (gelu'
+            applied, gelu(h) re-emitted and the bias sums taken in its epilogue) -, dW = dY^T . X on the TN kernel straight from the
+            row-major operands (``ruart_gemm_16_tn_splitk`` + ``ruart_splitk_reduce``, slabs summed in order),
+            ``ruart_attn_train_bwd``, embedding tables through the ordered host-sorted sum (``ops.embedding_grad``).
+            Every reduction has a fixed order: two passes from the same seed give the same bits.
 
 Accuracy class: mixed-precision training - f16 activations, bf16 gradients, fp32 accumulation, master weights and residual-stream
 gradient (tests hold every parameter-gradient norm of the reference's backward to 3 %).  Sequences longer than 64 word pieces are
@@ -223,7 +226,7 @@ class _Run:
         wmax = max(3 * H, I)
         self.xb = torch.empty(Tp * H, dtype=torch.bfloat16, device=dev)
         self.part = torch.empty(max(256, Tp // 128) * 256 * 256 + 4 * wmax * H, dtype=torch.float32, device=dev)
-        self.cs_ws = torch.empty(max(((Tp + 255) // 256) * wmax, int(lib.ruart_gelu16_bwd_ws_floats(Tp, I))), dtype=torch.float32, device=dev)
+        self.cs_ws = torch.empty(max(((Tp + 255) // 256) * wmax, int(lib.ruart_gemm_16_nt_gelu_bwd_ws_floats(Tp, I))), dtype=torch.float32, device=dev)
         self.ln_ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), dtype=torch.float32, device=dev)
         dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
         dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
@@ -239,12 +242,12 @@ class _Run:
             grads[pre + "output.LayerNorm.gamma"], grads[pre + "output.LayerNorm.beta"] = dg2, db2
             grads[pre + "output.dense.bias"] = dbias2
             w_qkv_t, wot, w1t, w2t = self.wT[l]                                                    # (K, N) bf16: dX = dY . W as NT products
-            d_g = self._gemm(d_g2, w2t, None, self._new(Tp, I, torch.bfloat16), hip.DT_BF16)
+            # dY . W2 with the GELU backward in the product's epilogue: d_h, gelu(h) again and the bias partial sums in one kernel
             d_h, g_b = self._new(Tp, I, torch.bfloat16), self._new(Tp, I, torch.bfloat16)
             db1_ff = torch.empty(I, dtype=torch.float32, device=dev)
-            _chk(lib.ruart_gelu16_bwd(hip.ptr(d_g), hip.ptr(h16), hip.ptr(d_h), hip.ptr(g_b), hip.ptr(db1_ff), hip.ptr(self.cs_ws), Tp, I, st()),
-                 "ruart_gelu16_bwd")
-            del d_g
+            _chk(lib.ruart_gemm_16_nt_gelu_bwd(hip.ptr(d_g2), H, hip.ptr(w2t), H, hip.ptr(h16), I, hip.ptr(d_h), hip.ptr(g_b), I, hip.ptr(self.cs_ws),
+                                               Tp, I, H, st()), "ruart_gemm_16_nt_gelu_bwd")
+            _chk(lib.ruart_colsum_f32_rows(hip.ptr(self.cs_ws), Tp // 128, I, I, hip.ptr(db1_ff), 0, st()), "ruart_colsum_f32_rows")
             grads[pre + "output.dense.weight"] = self._dw(d_g2, g_b)
             del g_b
             grads[pre + "intermediate.dense.bias"] = db1_ff

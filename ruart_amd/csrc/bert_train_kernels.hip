@@ -6,9 +6,13 @@
 //
 //   ruart_ln_train_fwd / _bwd      BertSelfOutput / BertOutput: LayerNorm(dropout(dense) + input)       modeling.py:260-264, 299-303
 //                                  (and the embeddings' LayerNorm-then-dropout, :196-199, with `post` = 1)
-//   ruart_gelu16_fwd / _bwd        erf-GELU of the intermediate activations                                 modeling.py:52-57, 286-289
-//   ruart_colsum_bf16              bias gradients: column sums of a gradient matrix
-//   ruart_transpose16              (rows, cols) -> (cols, rows) of a 16-bit matrix: K-contiguous operands for the weight-gradient GEMMs
+//                                  (the GELU of modeling.py:52-57 and its backward ride in GEMM epilogues: ruart_gemm_16_nt_gelu2 / _gelu_bwd)
+//   ruart_colsum_bf16 / _f32_rows  bias gradients: column sums of a gradient matrix / of per-strip partial sums
+//   ruart_weight_prep              fp32 master weight -> f16 operand of the forward + transposed bf16 operand of dX = dY . W, one pass
+//   ruart_f16_to_bf16              saved activations as the bf16 operand of a weight-gradient product
+//   ruart_transpose16              (rows, cols) -> (cols, rows) of a 16-bit matrix (the first form of the weight-gradient products fed
+//                                  the NT kernel transposed copies; the TN kernel of gemm_tn.hip replaced it - kept for the tests that
+//                                  hold the two forms against each other)
 //   ruart_splitk_reduce            sums the fp32 partial slabs of a split-K GEMM (fixed order: deterministic)
 //   ruart_mix_rows / _bwd          mixed[r] = sum_l w[l] * layer_l[r] (Models/SDNet.py:573-581 on the token stream) and d w[l]
 #include "common.h"
@@ -215,45 +219,6 @@ static void colreduce(const float* part, int n, size_t stride, float* out, int c
   hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(cols, 32)), dim3(256), 0, s, part, n, stride, o, cols, accumulate);
 }
 
-__device__ __forceinline__ float gelu_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-__global__ void gelu16_fwd_kernel(const f16_t* __restrict__ h, f16_t* __restrict__ g, size_t n4) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    f32x4_t v = load4(h + i * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
-    store4(g + i * 4, v);
-  }
-}
-// Backward of the GELU between the two feed-forward products, one pass over the (rows x cols) intermediate:
-//   dh (bf16) = dg * gelu'(h)          gradient w.r.t. the intermediate dense output
-//   g  (bf16) = gelu(h)                 the activation again - the X operand of the output dense's weight gradient (not kept by the forward)
-//   part[row block][col]                column sums of the unrounded dh over the block's GELU_RB rows (the intermediate bias gradient)
-// Block = 256 threads x 4 columns (1024 columns) x GELU_RB rows.
-#define GELU_RB 128
-__global__ __launch_bounds__(256) void gelu16_bwd_kernel(const bf16_t* __restrict__ dg, const f16_t* __restrict__ h, bf16_t* __restrict__ dh,
-                                                         bf16_t* __restrict__ g, float* __restrict__ part, int rows, int cols) {
-  const int c = blockIdx.x * 1024 + threadIdx.x * 4;
-  if (c >= cols) return;
-  const int r0 = blockIdx.y * GELU_RB, r1 = min(rows, r0 + GELU_RB);
-  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int r = r0; r < r1; ++r) {
-    const size_t o = (size_t)r * cols + c;
-    const f32x4_t x = load4(h + o);
-    f32x4_t d = load4(dg + o), a;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float cdf = 0.5f * (1.0f + erff(x[k] * 0.70710678118654752440f));
-      a[k] = x[k] * cdf;
-      d[k] *= cdf + x[k] * 0.3989422804014327f * __expf(-0.5f * x[k] * x[k]);
-    }
-    sum += d;
-    store4(dh + o, d);
-    if (g) store4(g + o, a);
-  }
-  if (part) store4(part + (size_t)blockIdx.y * cols + c, sum);
-}
-
 // column sums of a bf16 matrix in two deterministic stages: block (chunk of 256 rows, 256 columns) -> part[chunk][cols]
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int ld, int rows, int cols, float* __restrict__ part) {
   __shared__ float red[4][256];
@@ -424,15 +389,6 @@ extern "C" int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, co
   return 0;
 }
 
-extern "C" int ruart_gelu16_fwd(const void* h16, void* g16, long long n, void* stream) {
-  RUART_ENTRY();
-  if (n <= 0 || n % 4) return (int)hipErrorInvalidValue;
-  const size_t n4 = (size_t)n / 4;
-  hipLaunchKernelGGL(gelu16_fwd_kernel, dim3((unsigned)min((size_t)4096, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)h16,
-                     (f16_t*)g16, n4);
-  RUART_CHECK_LAUNCH();
-  return 0;
-}
 __global__ void f16_to_bf16_kernel(const f16_t* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) store4(out + i * 4, load4(in + i * 4));
 }
@@ -442,21 +398,6 @@ extern "C" int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, 
   const size_t n4 = (size_t)n / 4;
   hipLaunchKernelGGL(f16_to_bf16_kernel, dim3((unsigned)min((size_t)4096, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)in16,
                      (bf16_t*)out_bf16, n4);
-  RUART_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" size_t ruart_gelu16_bwd_ws_floats(int rows, int cols) { return (size_t)ceil_div(rows, GELU_RB) * cols; }
-
-extern "C" int ruart_gelu16_bwd(const void* dg_bf16, const void* h16, void* dh_bf16, void* g_bf16, float* d_bias, float* ws, int rows, int cols,
-                                void* stream) {
-  RUART_ENTRY();
-  if (rows <= 0 || cols <= 0 || cols % 4 || !dg_bf16 || !h16 || !dh_bf16 || (d_bias && !ws)) return (int)hipErrorInvalidValue;
-  const int rb = ceil_div(rows, GELU_RB);
-  hipLaunchKernelGGL(gelu16_bwd_kernel, dim3(ceil_div(cols, 1024), rb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg_bf16,
-                     (const f16_t*)h16, (bf16_t*)dh_bf16, (bf16_t*)g_bf16, d_bias ? ws : nullptr, rows, cols);
-  if (d_bias)
-    colreduce(ws, rb, (size_t)cols, d_bias, cols, 0, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -483,6 +424,14 @@ extern "C" int ruart_transpose16(const void* in, int ldi, void* out, int ldo, in
   else
     hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, ldi, (unsigned short*)out, ldo,
                        rows, cols);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_colsum_f32_rows(const float* part, int rows, int ld, int cols, float* out, int accumulate, void* stream) {
+  RUART_ENTRY();
+  if (!part || !out || rows <= 0 || cols <= 0 || ld < cols) return (int)hipErrorInvalidValue;
+  colreduce(part, rows, (size_t)ld, out, cols, accumulate, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -296,7 +296,7 @@ template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
                                                            void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk,
-                                                           void* __restrict__ C2
+                                                           void* __restrict__ C2, float* __restrict__ colpart
 #ifdef RUART_P8_STAMPS
                                                            , unsigned long long* __restrict__ stamps
 #endif
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
   const int ncol = n0 + wn * 64 + rcol;
   if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) {
 #pragma unroll
@@ -575,6 +576,22 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    if (ACT == 3) {
+      // backward through the GELU (R = the f16 pre-activation H): C = acc * gelu'(H) - the gradient at the intermediate dense output -,
+      // C2 = gelu(H) again (the X operand of the next weight gradient), colsum += this pass's rows of C before their rounding
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const f32x4_t hv = load4(reinterpret_cast<const f16_t*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        f32x2_t g0, d0, g1, d1;
+        gelu_fwd_bwd_pk((f32x2_t){hv[0], hv[1]}, g0, d0);
+        gelu_fwd_bwd_pk((f32x2_t){hv[2], hv[3]}, g1, d1);
+        v[rr] *= (f32x4_t){d0.x, d0.y, d1.x, d1.y};
+        colsum += v[rr];
+        store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, (f32x4_t){g0.x, g0.y, g1.x, g1.y});
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+      }
+      continue;
+    }
     if (ACT == 2) {                                          // training forward: the pre-activation is kept for the backward pass
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
@@ -591,6 +608,15 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
       else
         store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
     }
+  }
+  if (ACT == 3 && colpart) {
+    // the wave's 128 rows: lanes l, l + 16, l + 32, l + 48 hold the same four columns
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      colsum[r] += __shfl_xor(colsum[r], 16, 64);
+      colsum[r] += __shfl_xor(colsum[r], 32, 64);
+    }
+    if (lane < 16) store4(colpart + (size_t)(tm * 2 + wm) * N + ncol, colsum);
   }
 #ifdef RUART_P8_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -782,10 +808,10 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     (void)done;
 #ifdef RUART_P8_STAMPS
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0, (void*)nullptr, g_p8_stamps);
+                       g_tile_order, 0, (void*)nullptr, (float*)nullptr, g_p8_stamps);
 #else
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0, (void*)nullptr);
+                       g_tile_order, 0, (void*)nullptr, (float*)nullptr);
 #endif
   } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
@@ -853,10 +879,10 @@ static void launch_gelu2(const void* A, int lda, const void* W, int ldw, const f
   (void)done;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout, (unsigned long long*)nullptr);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr);
 #endif
 }
 
@@ -876,6 +902,36 @@ extern "C" int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int
   return 0;
 }
 
+// Backward of the feed-forward's second half up to the intermediate dense output, in one kernel (Models/Bert/modeling.py:287-288, 300 under
+// autograd): acc = dY . W2 (dY (M x K) bf16 gradient at the output dense, Wt = W2^T (N x K) bf16), then per element with the saved f16
+// pre-activation H:  dH = acc * gelu'(H)  and  G = gelu(H), both bf16 (M x N); colpart[(M / 128) x N] = column sums of dH per 128-row
+// strip before rounding (summed in strip order by the caller: the intermediate bias gradient).  Replaces a GEMM that wrote acc in bf16, an
+// elementwise pass that read it back with H (1.1 GB of traffic per layer at the bench shape) and a column-sum pass.
+extern "C" size_t ruart_gemm_16_nt_gelu_bwd_ws_floats(int M, int N) { return (size_t)(M / 128) * N; }
+
+extern "C" int ruart_gemm_16_nt_gelu_bwd(const void* dY_bf16, int lda, const void* Wt_bf16, int ldw, const void* H16, int ldh, void* dH_bf16,
+                                         void* G_bf16, int ldc, float* colpart, int M, int N, int K, void* stream) {
+  RUART_ENTRY();
+  if (M <= 0 || M % BM4 || N % BN4 || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || (ldh & 3) || !dY_bf16 || !Wt_bf16 || !H16 || !dH_bf16 ||
+      !G_bf16)
+    return (int)hipErrorInvalidValue;
+  constexpr int lds = 2 * 2 * BM4 * BK * 2;
+  auto kern = gemm_16_nt_256p8<bf16_t, false, 0, 3>;
+  static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)done;
+  void* rec = ruart_prof_begin_((hipStream_t)stream, M, N, K);
+#ifdef RUART_P8_STAMPS
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (unsigned long long*)nullptr);
+#else
+  hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart);
+#endif
+  ruart_prof_end_(rec, (hipStream_t)stream);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
 // Split-K form of the 16-bit NT product: part[z] (M x N fp32, row stride ldc, slabs M * ldc floats apart) = A[:, z*kchunk : ...] .
 // W[:, z*kchunk : ...]^T for z < ceil(K / kchunk).  For the encoder's weight gradients dW = dY^T . X (M, N = layer widths, K = token
 // rows): a 768 x 768 output is 9 tiles, so the reduction is cut into ~28 slices to fill the 256 CUs.
@@ -888,10 +944,10 @@ static void launch_splitk(const void* A, int lda, const void* W, int ldw, float*
   const int nz = (K + kchunk - 1) / kchunk;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (unsigned long long*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr);
 #endif
 }
 

@@ -32,6 +32,27 @@ __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
   return (f32x4_t){lo.x, lo.y, hi.x, hi.y};
 }
 
+// Forward value and derivative of the same GELU in one go (the backward epilogue of the trainable encoder's output-dense dX product):
+// Phi(x) = 1 / (1 + exp2(p(x))) as above, g = x Phi, dg/dx = Phi + x phi(x) with phi(x) = exp(-x^2 / 2) / sqrt(2 pi).
+__device__ __forceinline__ void gelu_fwd_bwd_pk(f32x2_t x, f32x2_t& g, f32x2_t& d) {
+  const f32x2_t x2 = x * x;
+  f32x2_t p = x2 * -3.228988589e-06f + 8.823813550e-05f;
+  p = p * x2 + 3.602745419e-04f;
+  p = p * x2 + -1.052266881e-01f;
+  p = p * x2 + -2.302045345e+00f;
+  p = p * x;
+  f32x2_t den, phi;
+  den.x = 1.0f + __builtin_amdgcn_exp2f(p.x);
+  den.y = 1.0f + __builtin_amdgcn_exp2f(p.y);
+  phi.x = __builtin_amdgcn_exp2f(x2.x * -0.72134752044f);
+  phi.y = __builtin_amdgcn_exp2f(x2.y * -0.72134752044f);
+  f32x2_t cdf;
+  cdf.x = __builtin_amdgcn_rcpf(den.x);
+  cdf.y = __builtin_amdgcn_rcpf(den.y);
+  g = x * cdf;
+  d = cdf + x * phi * 0.3989422804f;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

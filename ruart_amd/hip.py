@@ -52,13 +52,13 @@ _SIGNATURES = {
     "ruart_bert_attention_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ruart_gemm_16_nt_splitk": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16_nt_gelu2": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16_nt_gelu_bwd_ws_floats": (c_size_t, [_I, _I]),
+    "ruart_gemm_16_nt_gelu_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "ruart_colsum_f32_rows": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "ruart_gemm_16_tn_splitk": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_ln_train_fwd": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, ctypes.c_uint, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_ln_train_bwd_ws_floats": (c_size_t, [_I]),
     "ruart_ln_train_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _F, ctypes.c_uint, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
-    "ruart_gelu16_fwd": (_I, [_P, _P, _LL, _P]),
-    "ruart_gelu16_bwd_ws_floats": (c_size_t, [_I, _I]),
-    "ruart_gelu16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "ruart_f16_to_bf16": (_I, [_P, _P, _LL, _P]),
     "ruart_weight_prep": (_I, [_P, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "ruart_colsum_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),

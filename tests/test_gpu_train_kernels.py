@@ -102,29 +102,12 @@ def test_ln_train_dropout_masks_regenerate():
     assert float((d_in - xr.grad).abs().max()) < 3e-3 * float(xr.grad.abs().max())
 
 
-def test_gelu16_colsum_transpose_mix():
+def test_colsum_transpose_cast_mix():
     lib = hip.load()
     g = torch.Generator().manual_seed(3)
     R, N = 1000, 3072
     h = (2 * torch.randn(R, N, generator=g)).half().to(DEV)
-    out = torch.empty_like(h)
-    assert lib.ruart_gelu16_fwd(hip.ptr(h), hip.ptr(out), R * N, _st()) == 0
-    hr = h.float().requires_grad_()
-    ref = torch.nn.functional.gelu(hr)
-    assert float((out.float() - ref).abs().max()) < 4e-3
     dg = torch.randn(R, N, generator=g).bfloat16().to(DEV)
-    dh, gb = torch.empty_like(dg), torch.empty_like(dg)
-    dbias = torch.empty(N, device=DEV)
-    gws = torch.empty(int(lib.ruart_gelu16_bwd_ws_floats(R, N)), device=DEV)
-    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh), hip.ptr(gb), hip.ptr(dbias), hip.ptr(gws), R, N, _st()) == 0
-    ref.backward(dg.float())
-    assert float((dh.float() - hr.grad).abs().max()) < 2e-2 * float(hr.grad.abs().max())      # bf16 in, bf16 out
-    assert float((gb.float() - ref.detach()).abs().max()) < 1e-2 * float(ref.abs().max())     # the activation again, in bf16
-    cs_ref = hr.grad.sum(0)
-    assert float((dbias - cs_ref).abs().max()) < 1e-4 * float(hr.grad.abs().sum(0).max())     # unrounded fp32 column sums
-    dh2 = torch.empty_like(dg)
-    assert lib.ruart_gelu16_bwd(hip.ptr(dg), hip.ptr(h), hip.ptr(dh2), None, None, None, R, N, _st()) == 0
-    assert torch.equal(dh2, dh)
     hb = torch.empty(R, N, dtype=torch.bfloat16, device=DEV)
     assert lib.ruart_f16_to_bf16(hip.ptr(h), hip.ptr(hb), R * N, _st()) == 0
     assert torch.equal(hb, h.float().bfloat16())
@@ -156,6 +139,33 @@ def test_gelu16_colsum_transpose_mix():
     assert lib.ruart_mix_rows_bwd(hip.ptr(layers), R * H, H, NL, hip.ptr(gm), H, hip.ptr(dw), hip.ptr(ws2), R, H, _st()) == 0
     refw = (layers.float() * gm.unsqueeze(0)).sum((1, 2))
     assert float((dw - refw).abs().max()) < 1e-4 * float(refw.abs().max()) + 1e-2
+
+
+def test_gelu_backward_in_the_gemm_epilogue():
+    """ruart_gemm_16_nt_gelu_bwd: dH = (dY . W2) * gelu'(H), G = gelu(H) and the per-strip column sums of dH, one kernel."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 512, 768, 256
+    dY = (torch.randn(M, K, generator=g) * 1e-3).bfloat16().to(DEV)
+    Wt = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)                    # W2^T: (intermediate, hidden)
+    Hh = (2 * torch.randn(M, N, generator=g)).half().to(DEV)
+    dH = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    G = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    part = torch.empty(int(lib.ruart_gemm_16_nt_gelu_bwd_ws_floats(M, N)), device=DEV)
+    assert part.numel() == (M // 128) * N
+    assert lib.ruart_gemm_16_nt_gelu_bwd(hip.ptr(dY), K, hip.ptr(Wt), K, hip.ptr(Hh), N, hip.ptr(dH), hip.ptr(G), N, hip.ptr(part), M, N, K, _st()) == 0
+    hr = Hh.double().cpu().requires_grad_()
+    ref_g = torch.nn.functional.gelu(hr)
+    acc = dY.double().cpu() @ Wt.double().cpu().t()
+    ref_g.backward(acc)
+    ref_dh = hr.grad
+    assert float((G.double().cpu() - ref_g.detach()).abs().max()) < 1e-2 * float(ref_g.abs().max())            # bf16 output
+    assert float((dH.double().cpu() - ref_dh).abs().max()) < 1e-2 * float(ref_dh.abs().max())
+    db = torch.empty(N, device=DEV)
+    assert lib.ruart_colsum_f32_rows(hip.ptr(part), M // 128, N, N, hip.ptr(db), 0, _st()) == 0
+    assert float((db.double().cpu() - ref_dh.sum(0)).abs().max()) < 2e-4 * float(ref_dh.abs().sum(0).max())     # unrounded fp32 sums
+    assert lib.ruart_gemm_16_nt_gelu_bwd(hip.ptr(dY), K, hip.ptr(Wt), K, hip.ptr(Hh), N, hip.ptr(dH), hip.ptr(G), N, None, M, N, K, _st()) == 0
+    assert lib.ruart_gemm_16_nt_gelu_bwd(hip.ptr(dY), K, hip.ptr(Wt), K, None, N, hip.ptr(dH), hip.ptr(G), N, None, M, N, K, _st()) != 0
 
 
 def test_weight_prep_f16_and_transposed_bf16():
