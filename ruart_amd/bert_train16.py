@@ -51,8 +51,9 @@ def _chk(rc, what):
 class _Run:
     """One forward / backward pass: buffers, launches and the saved activations."""
 
-    def __init__(self, model, packed, training, params):
+    def __init__(self, model, packed, training, params, keep=True):
         self.m, self.packed, self.training = model, packed, training
+        self.keep = keep                                              # False: a pass nobody will differentiate - nothing is saved
         self.P = dict(zip(model._order, params))
         self.lib = hip.load()
         self.dev = packed.ids.device
@@ -104,15 +105,16 @@ class _Run:
         P, H, I, dev = self.P, self.H, self.I, self.dev
         pre = "encoder.layer.%d." % l
         a = pre + "attention.self."
-        wq16, wqT = torch.empty(3 * H, H, dtype=torch.float16, device=dev), torch.empty(H, 3 * H, dtype=torch.bfloat16, device=dev)
+        wq16 = torch.empty(3 * H, H, dtype=torch.float16, device=dev)
+        wqT = torch.empty(H, 3 * H, dtype=torch.bfloat16, device=dev) if self.keep else None
         for i, (n, sc) in enumerate((("query", scale), ("key", 1.0), ("value", 1.0))):
-            _chk(self.lib.ruart_weight_prep(hip.ptr(P[a + n + ".weight"]), H, float(sc), hip.ptr(wq16[i * H:]), H, hip.ptr(wqT[:, i * H:]), 3 * H, H, H,
-                                            self._st()), "ruart_weight_prep")
+            _chk(self.lib.ruart_weight_prep(hip.ptr(P[a + n + ".weight"]), H, float(sc), hip.ptr(wq16[i * H:]), H,
+                                            hip.ptr(wqT[:, i * H:] if self.keep else None), 3 * H, H, H, self._st()), "ruart_weight_prep")
         out = [wq16]
         back = [wqT]
         for n, rows, cols in (("attention.output.dense", H, H), ("intermediate.dense", I, H), ("output.dense", H, I)):
             w16 = torch.empty(rows, cols, dtype=torch.float16, device=dev)
-            wT = torch.empty(cols, rows, dtype=torch.bfloat16, device=dev)
+            wT = torch.empty(cols, rows, dtype=torch.bfloat16, device=dev) if self.keep else None
             _chk(self.lib.ruart_weight_prep(hip.ptr(P[pre + n + ".weight"]), cols, 1.0, hip.ptr(w16), cols, hip.ptr(wT), rows, rows, cols,
                                             self._st()), "ruart_weight_prep")
             out.append(w16)
@@ -157,7 +159,8 @@ class _Run:
             del g16
             _, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
                                         self._seed(l, 2), out=self.layers[l])
-            self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
+            if self.keep:
+                self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
             x16 = self.layers[l]
         self.lw = layer_w.detach().to(torch.float32).contiguous()
         mixed = torch.empty(Tp, H, dtype=torch.float32, device=self.dev)
@@ -288,9 +291,9 @@ class _Run:
 
 class _Encoder16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, packed, training, layer_w, *params):
-        run = _Run(model, packed, training, params)
-        ctx.run = run
+    def forward(ctx, model, packed, training, keep, layer_w, *params):
+        run = _Run(model, packed, training, params, keep)
+        ctx.run = run if keep else None
         ctx.lw_dtype = layer_w.dtype
         return run.forward(layer_w)
 
@@ -299,7 +302,7 @@ class _Encoder16(torch.autograd.Function):
         run = ctx.run
         d_lw, grads = run.backward(g_mixed.contiguous().to(torch.float32))
         ctx.run = None
-        return (None, None, None, d_lw.to(ctx.lw_dtype)) + tuple(grads.get(n) for n in run.m._order)
+        return (None, None, None, None, d_lw.to(ctx.lw_dtype)) + tuple(grads.get(n) for n in run.m._order)
 
 
 class BertModelTrainable16(BertModelTrainable):
@@ -324,4 +327,6 @@ class BertModelTrainable16(BertModelTrainable):
         if not self.supports(packed):
             from .bert_train import mix_layers
             return mix_layers(layer_w, self.forward(packed, training=training))
-        return _Encoder16.apply(self, packed, training, layer_w, *[self._p[n] for n in self._order])
+        params = [self._p[n] for n in self._order]
+        keep = torch.is_grad_enabled() and (layer_w.requires_grad or any(p.requires_grad for p in params))
+        return _Encoder16.apply(self, packed, training, keep, layer_w, *params)

@@ -573,6 +573,13 @@ def test_unlocked_16bit_encoder_is_repeatable_and_falls_back(golden_dir):
     scores.sum().backward()
     net.check_nan()
     assert torch.isfinite(dict(net.named_parameters())["Bert.bert_model.encoder.layer.0.output.dense.weight"].grad).all()
+    # evaluation: same numbers as a training-mode pass without dropout, nothing kept for a backward pass
+    net.Bert.bert_model.p_hidden = net.Bert.bert_model.p_attn = 0.0
+    s_train, _ = net(q, ocr, od)
+    net.eval()
+    with torch.no_grad():
+        s_eval, _ = net(q, ocr, od)
+    assert torch.equal(s_train.detach(), s_eval) and not s_eval.requires_grad
 
 
 @pytest.mark.parametrize("train_gemm", ["x3", "16"])
