@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
 t0 = rows[0][0]
-enc = ("gemm_16_nt", "attn_flash", "attn_varlen", "rows_layernorm", "embed_ln")
+enc = ("gemm_16_nt", "gemm_16c_nt", "attn_flash", "attn_varlen", "rows_layernorm", "embed_ln")
 # steps are delimited by embed_ln launches (one per encoder pass)
 marks = [s for s, e, n, q, st in rows if "embed_ln" in n]
 print("encoder passes:", len(marks))
