@@ -19,6 +19,7 @@ run unlock_x3 --unlock-bert --train-gemm x3 --steps 4 --warmup 2
 run unlock_16gemm --unlock-bert --train-gemm 16gemm --steps 4 --warmup 2
 run unlock16 --unlock-bert --steps 8 --warmup 3
 run unlock16_dp --unlock-bert --force-dp --steps 8 --warmup 3
+run unlock16_stress --stress --unlock-bert --steps 3 --warmup 1
 timeout -k 10 300 python bench.py --mode bert512 --precision fp16 --steps 30 --warmup 10 > gpurun_out/r02_bert512_line.json 2>/dev/null
 timeout -k 10 400 python bench.py > gpurun_out/r02_bench_line.json 2>gpurun_out/r02_bench_line.err
 cat gpurun_out/r02_bench_line.json
