@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on one GPU: a world-size-1 RCCL process group, so the gradient hooks, the bucketed all-reduce and "
                          "the barriers of the N > 1 path all run")
+    ap.add_argument("--frozen-dropout", action="store_true",
+                    help="opt['bert_frozen_dropout']: the frozen encoder's training passes with BERT's own dropout on, as the reference's "
+                         "update() really runs them (Models/SDNetTrainer.py:332); nothing runs ahead in this mode")
     ap.add_argument("--train-gemm", default="16", choices=["x3", "16", "16gemm"], help="with --unlock-bert: GEMM form of the trainable encoder")
     ap.add_argument("--unlock-bert", action="store_true",
                     help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
@@ -271,6 +274,8 @@ def main():
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
     if a.graph_trunk is not None:
         opt["ruart_graph_trunk"] = bool(a.graph_trunk)
+    if a.frozen_dropout:
+        opt["bert_frozen_dropout"] = True
     if a.unlock_bert:
         opt.pop("LOCK_BERT")
         opt["bert_train_gemm"] = a.train_gemm

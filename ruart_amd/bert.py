@@ -454,7 +454,14 @@ class Bert(nn.Module):
         if self.opt.get("bert_frozen_dropout"):
             from .bert_train import BertModelTrainable
             state, cfg = self._source
-            model = BertModelTrainable(state, cfg, self._device, gemm="x3")
+            if (self.opt.get("bert_precision", "fp16") in ("fp16c", "fp16", "bf16") and cfg["hidden_size"] % 256 == 0
+                    and cfg["intermediate_size"] % 256 == 0):
+                # the 16-bit modes: the dropout pass runs on the 16-bit training kernels (bert_train16.py, forward only); batches it
+                # cannot take (a sequence beyond 64 word pieces) use the parent's fp32-class graph
+                from .bert_train16 import BertModelTrainable16
+                model = BertModelTrainable16(state, cfg, self._device)
+            else:
+                model = BertModelTrainable(state, cfg, self._device, gemm="x3")
             for p in model.parameters():
                 p.requires_grad_(False)
             self.__dict__["_dropout_model"] = model        # not a registered child: the state dict keeps the reference's keys
@@ -519,7 +526,9 @@ class Bert(nn.Module):
             return self.bert_model(packed, training=self.training)
         if self._frozen_dropout_active():
             with torch.no_grad():
-                return self.__dict__["_dropout_model"](packed, training=True)
+                model = self.__dict__["_dropout_model"]
+                fast = model.layers_nograd(packed, training=True) if hasattr(model, "layers_nograd") else None
+                return fast if fast is not None else model(packed, training=True)
         layers = getattr(packed, "_layers", None)
         if layers is not None:
             torch.cuda.current_stream(self._device).wait_event(packed._event)

@@ -162,6 +162,8 @@ class _Run:
             if self.keep:
                 self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
             x16 = self.layers[l]
+        if layer_w is None:
+            return self.layers                                        # frozen-encoder use: every layer output, no mix
         self.lw = layer_w.detach().to(torch.float32).contiguous()
         mixed = torch.empty(Tp, H, dtype=torch.float32, device=self.dev)
         _chk(lib.ruart_mix_rows(hip.ptr(self.layers), Tp * H, H, NL, hip.ptr(self.lw), hip.ptr(mixed), H, Tp, H, st()), "ruart_mix_rows")
@@ -322,6 +324,15 @@ class BertModelTrainable16(BertModelTrainable):
 
     def supports(self, packed):
         return packed.n_long_blocks == 0 and packed.max_len <= 64 and packed.bias_host is None and packed.Tp % 256 == 0
+
+    @torch.no_grad()
+    def layers_nograd(self, packed, training=False):
+        """(n_layers, Tp, H) f16: every layer output of one pass with this module's dropouts on or off and nothing kept for a backward
+        pass - the frozen encoder's training-mode pass under ``opt['bert_frozen_dropout']`` (Models/SDNetTrainer.py:332 switches the
+        dropout layers inside the locked BERT back on)."""
+        if not self.supports(packed):
+            return None
+        return _Run(self, packed, training, [self._p[n] for n in self._order], keep=False).forward(None)
 
     def forward_mixed(self, packed, layer_w, training=False):
         if not self.supports(packed):

@@ -205,13 +205,16 @@ def test_variational_dropout_contract():
     assert torch.equal(L.dropout(x, p=0.4, training=False), x)
 
 
-def test_frozen_bert_dropout_is_opt_in(golden):
+@pytest.mark.parametrize("precision,tol", [("x3", 2e-4), ("fp16c", 2e-4)])
+def test_frozen_bert_dropout_is_opt_in(golden, precision, tol):
     """``opt['bert_frozen_dropout']`` reproduces the reference's actual training-mode behaviour (Models/SDNetTrainer.py:332 flips the
     dropout(0.1) layers inside the frozen BERT back on, Models/Bert/modeling.py:198, 244, 263, 302): training passes become random,
     evaluation passes stay the deterministic ones; without the option nothing changes."""
     import ruart_amd.layers as L
     z = golden
-    net, opt = build(z, "x3", bert_frozen_dropout=True)
+    net, opt = build(z, precision, bert_frozen_dropout=True)
+    # (fp16c: the training-mode passes run on the 16-bit training kernels, bert_train16.BertModelTrainable16.layers_nograd)
+    assert type(net.Bert.__dict__["_dropout_model"]).__name__ == ("BertModelTrainable16" if precision == "fp16c" else "BertModelTrainable")
     q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=30, n_ocr=100, n_od=30, bert_vocab=2000, ragged=True)
     L.set_dropout_prob(0.0)
     net.drop_emb = False
@@ -219,7 +222,7 @@ def test_frozen_bert_dropout_is_opt_in(golden):
     net.eval()
     with torch.no_grad():
         e = net(q, ocr, od)[0].cpu().numpy()
-    assert np.abs(e - z["scores"]).max() < 2e-4                                # evaluation: the deterministic encoder
+    assert np.abs(e - z["scores"]).max() < tol                                 # evaluation: the deterministic encoder
     net.train()
     with torch.no_grad():
         a = net(q, ocr, od)[0].cpu().numpy()

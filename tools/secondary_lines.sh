@@ -15,6 +15,8 @@ run h2d --include-h2d
 run dp --force-dp
 run stress --stress --steps 6 --warmup 2
 run stress_bf16 --stress --precision bf16 --steps 6 --warmup 2
+run frozen_dropout --frozen-dropout --no-parity
+run frozen_dropout_x3 --frozen-dropout --precision x3 --no-parity --steps 6 --warmup 2
 run unlock_x3 --unlock-bert --train-gemm x3 --steps 4 --warmup 2
 run unlock_16gemm --unlock-bert --train-gemm 16gemm --steps 4 --warmup 2
 run unlock16 --unlock-bert --steps 8 --warmup 3
