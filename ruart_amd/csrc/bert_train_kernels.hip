@@ -240,6 +240,24 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   }
 }
 
+// the same for an fp32 matrix of any width (the trunk's bias gradients: widths 250, 300, 1000 ... - one column per thread, 128 rows per
+// block, four rows in flight)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, int ld, int rows, int cols, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * 128, r1 = min(rows, r0 + 128);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += x[(size_t)r * ld + c];
+    s1 += x[(size_t)(r + 1) * ld + c];
+    s2 += x[(size_t)(r + 2) * ld + c];
+    s3 += x[(size_t)(r + 3) * ld + c];
+  }
+  for (; r < r1; ++r) s0 += x[(size_t)r * ld + c];
+  part[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
+}
+
 // 64 x 64 tile transpose of a 16-bit matrix through LDS (row stride padded by 2 elements: conflict-light both ways)
 template <bool F16_TO_BF16>
 __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ in, int ldi, unsigned short* __restrict__ out,
@@ -409,6 +427,19 @@ extern "C" int ruart_colsum_bf16(const void* x_bf16, int ld, int rows, int cols,
   const int chunks = ceil_div(rows, 256);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ld, rows,
                      cols, ws);
+  colreduce(ws, chunks, (size_t)cols, out, cols, accumulate, (hipStream_t)stream);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t ruart_colsum_f32_ws_floats(int rows, int cols) { return (size_t)ceil_div(rows, 128) * cols; }
+
+/* out[j] (+)= sum_r x[r][j] of an fp32 matrix (any cols / ld); ws: ruart_colsum_f32_ws_floats(rows, cols) floats; fixed order */
+extern "C" int ruart_colsum_f32(const float* x, int ld, int rows, int cols, float* out, int accumulate, float* ws, void* stream) {
+  RUART_ENTRY();
+  if (!x || !out || !ws || rows <= 0 || cols <= 0 || ld < cols) return (int)hipErrorInvalidValue;
+  const int chunks = ceil_div(rows, 128);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(ceil_div(cols, 256), chunks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, ws);
   colreduce(ws, chunks, (size_t)cols, out, cols, accumulate, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;

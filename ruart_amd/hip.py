@@ -54,6 +54,8 @@ _SIGNATURES = {
     "ruart_gemm_16_nt_gelu2": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16_nt_gelu_bwd_ws_floats": (c_size_t, [_I, _I]),
     "ruart_gemm_16_nt_gelu_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "ruart_colsum_f32_ws_floats": (c_size_t, [_I, _I]),
+    "ruart_colsum_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "ruart_colsum_f32_rows": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "ruart_gemm_16_tn_splitk": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_ln_train_fwd": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, ctypes.c_uint, _I, _P, _P, _P, _I, _I, _I, _P]),

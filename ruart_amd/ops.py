@@ -212,6 +212,19 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     return out
 
 
+def colsum(x):
+    """x.sum(0) of a 2-D fp32 device matrix in two ordered stages (ruart_colsum_f32): the bias gradients of the trunk's projections -
+    torch's generic reduction takes 33 us for a (6400, 1000) gradient, this 8."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] > 64):
+        return x.sum(0)
+    rows, cols = x.shape
+    lib = hip.load()
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = _scratch(x.device, int(lib.ruart_colsum_f32_ws_floats(rows, cols)), "colsum")
+    hip.check(lib.ruart_colsum_f32(hip.ptr(x), x.stride(0), rows, cols, hip.ptr(out), 0, hip.ptr(ws), hip.stream_ptr(x.device)), "ruart_colsum_f32")
+    return out
+
+
 class _Linear(torch.autograd.Function):
     """y = (x * mask) W^T (+ b) with x (rows, K), W (N, K), mask (rows / rpm, K) or None, on ruart_gemm_x3.
     The masked input is materialised once (it is also the operand of dW = dY^T (x * mask)); the backward multiply is fused:
@@ -232,7 +245,7 @@ class _Linear(torch.autograd.Function):
         xm, w, mask = ctx.saved_tensors
         gx = mm(gy, w, mode=ctx.mode, c_scale=mask, rpm=ctx.rpm) if ctx.needs_input_grad[0] else None
         gw = mm(gy.t(), xm, mode=ctx.mode) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None
 
 

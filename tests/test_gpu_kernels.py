@@ -654,6 +654,18 @@ def test_embedding_backward_from_host_sort(V, D, n, pad):
     assert torch.equal(emb.weight.grad, got)
 
 
+@pytest.mark.parametrize("rows,cols", [(6400, 1000), (2304, 250), (65, 7), (12841, 1200), (40, 300)])
+def test_colsum_f32(rows, cols):
+    """ops.colsum: bias gradients of the trunk's projections (ruart_colsum_f32; small inputs stay on torch)."""
+    from ruart_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols + 3, generator=g).cuda()[:, :cols]                  # a row stride that is not the width
+    got = ops.colsum(x)
+    ref = x.double().sum(0)
+    assert float((got.double() - ref).abs().max()) < 1e-5 * float(x.abs().double().sum(0).max())
+    assert torch.equal(got, ops.colsum(x))                                          # ordered: the same bits again
+
+
 def test_phoc_table_matches_reference(golden_dir):
     """ruart_phoc_table (one launch for the whole word list) bit-exact against the reference's build_phoc rows, against the
     oracle on fresh random words, and the error contract for bytes outside [a-z0-9]."""
