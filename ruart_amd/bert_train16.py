@@ -26,8 +26,6 @@ Accuracy class: mixed-precision training - f16 activations, bf16 gradients, fp32
 gradient (tests hold every parameter-gradient norm of the reference's backward to 3 %).  Sequences longer than 64 word pieces are
 outside the attention kernels' window: such a batch falls back to the fp32-class path of bert_train.py.
 """
-import ctypes
-
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -95,9 +93,6 @@ class _Run:
         _chk(self.lib.ruart_ln_train_fwd(hip.ptr(x32), H, hip.ptr(res16), H, hip.ptr(g), hip.ptr(b), 1e-12, float(p), int(seed), post, hip.ptr(y),
                                          hip.ptr(pre), hip.ptr(st), H, Tp, H, self._st()), "ruart_ln_train_fwd")
         return y, pre, st
-
-    def _attention_ok(self):
-        return self.packed.n_long_blocks == 0 and self.packed.max_len <= 64 and self.packed.key_bias is None
 
     def _prep_weights(self, l, scale):
         """The layer's four weights as GEMM operands, one pass per master tensor: f16 (N, K) for the forward and, kept for the backward
