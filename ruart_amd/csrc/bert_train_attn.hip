@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __r
   __shared__ __attribute__((aligned(16))) char Ks[64 * ARS];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ARS];
   __shared__ __attribute__((aligned(16))) char Ds[64 * ARS];      // dO * scale
-  __shared__ __attribute__((aligned(16))) char PT[64 * ARS];      // Pd^T  [key][query]
-  __shared__ __attribute__((aligned(16))) char ST[64 * ARS];      // dS^T  [key][query]
+  // Pd^T and dS^T ([key][query] images for the two products that sum over queries) take over the V and K images once every wave is
+  // done with them: 37 KB of LDS per workgroup instead of 55 KB - four workgroups per CU instead of two
+  char* const PT = Vs;
+  char* const ST = Ks;
   __shared__ __attribute__((aligned(16))) int Ls[64];
   __shared__ float red[4];
   typedef f16x8_t frag_t;
@@ -265,15 +267,6 @@ __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __r
   for (int it = 0; it < 4; ++it)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[it][r] *= dp[it][r] - delta;     // s = dS^T (in units of the scaled dO)
-  // Pd^T and dS^T -> LDS [key][query] for the products that sum over queries
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = it * 16 + g * 4 + r;
-      *reinterpret_cast<f16_t*>(PT + key * ARS + qi * 2) = (f16_t)pd[it][r];
-      *reinterpret_cast<f16_t*>(ST + key * ARS + qi * 2) = (f16_t)s[it][r];
-    }
   // dQ^T = K^T . dS^T with the dS^T accumulator tiles as the B operand (permuted key order, matched by the transposed reads)
   frag_t sf[2];
   pack_cols<f16_t>(s, sf);
@@ -295,6 +288,16 @@ __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __r
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(op + dt * 16, dq[dt] * inv_dsc);
   }
+  __syncthreads();                                            // every wave has read K (dQ) and V (dPd) for the last time
+  // Pd^T and dS^T -> LDS [key][query] for the products that sum over queries
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = it * 16 + g * 4 + r;
+      *reinterpret_cast<f16_t*>(PT + key * ARS + qi * 2) = (f16_t)pd[it][r];
+      *reinterpret_cast<f16_t*>(ST + key * ARS + qi * 2) = (f16_t)s[it][r];
+    }
   __syncthreads();
   // dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]  for this wave's 16 keys (key = qi)
   f32x4_t dv[4], dk[4];
