@@ -22,6 +22,7 @@
 
 // y = LN(drop(x) + res) (post == 0)  or  y = drop(LN(x)) (post == 1, res ignored).  x fp32 (the dense output, bias included),
 // res f16 or NULL.  Saved for the backward: pre16 = f16(the LayerNorm's input), stats[row] = (mean, rstd).
+template <int NG>
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, int ldx, const f16_t* __restrict__ res, int ldr,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float p, unsigned seed, int post, f16_t* __restrict__ y, f16_t* __restrict__ pre16,
@@ -30,10 +31,10 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float keep_inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-  f32x4_t v[TMAXG];
+  f32x4_t v[NG];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < TMAXG; ++i) {
+  for (int i = 0; i < NG; ++i) {
     const int c = (i * 64 + lane) * 4;
     v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (c < H) {
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < TMAXG; ++i) {
+  for (int i = 0; i < NG; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
 #pragma unroll
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     stats[2 * row + 1] = rstd;
   }
 #pragma unroll
-  for (int i = 0; i < TMAXG; ++i) {
+  for (int i = 0; i < NG; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < H) {
       const f32x4_t g = load4(gamma + c), b = load4(beta + c);
@@ -89,28 +90,29 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
 //   post == 1: dy is first multiplied by the dropout multiplier; only d_res is written (gradient w.r.t. the embedding sum).
 // Partial column sums of d(gamma), d(beta) and (post == 0) of the unrounded d_gemm - the bias gradient of the dense layer in front - go
 // to part[(block, 0/1/2, H)]; ruart_ln_train_bwd reduces them in block order.
+template <int NG>
 __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ add,
                                                            const float* __restrict__ add_scale, const f16_t* __restrict__ pre16, int ld16,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma, float p,
                                                            unsigned seed, int post, float* __restrict__ d_res, int ldd,
                                                            bf16_t* __restrict__ d_gemm, int ldg, float* __restrict__ part, int rows, int H) {
-  __shared__ float red[3][3 * 256 * TMAXG];
+  __shared__ float red[3][3 * 256 * NG];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float keep_inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   const float a = add ? add_scale[0] : 0.f;
-  f32x4_t dgam[TMAXG], dbet[TMAXG], dbia[TMAXG], gam[TMAXG];
+  f32x4_t dgam[NG], dbet[NG], dbia[NG], gam[NG];
 #pragma unroll
-  for (int i = 0; i < TMAXG; ++i) {
+  for (int i = 0; i < NG; ++i) {
     const int c = (i * 64 + lane) * 4;
     dgam[i] = dbet[i] = dbia[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     gam[i] = c < H ? load4(gamma + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
   for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    f32x4_t g[TMAXG], xh[TMAXG];
+    f32x4_t g[NG], xh[NG];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TMAXG; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int c = (i * 64 + lane) * 4;
       g[i] = xh[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       if (c < H) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
     }
     const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
 #pragma unroll
-    for (int i = 0; i < TMAXG; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
         f32x4_t dx;
@@ -155,24 +157,24 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
   // the four waves' partial sums -> one row pair per block
   if (wv > 0) {
 #pragma unroll
-    for (int i = 0; i < TMAXG; ++i) {
+    for (int i = 0; i < NG; ++i) {
       *reinterpret_cast<f32x4_t*>(&red[wv - 1][(i * 64 + lane) * 4]) = dgam[i];
-      *reinterpret_cast<f32x4_t*>(&red[wv - 1][256 * TMAXG + (i * 64 + lane) * 4]) = dbet[i];
-      *reinterpret_cast<f32x4_t*>(&red[wv - 1][2 * 256 * TMAXG + (i * 64 + lane) * 4]) = dbia[i];
+      *reinterpret_cast<f32x4_t*>(&red[wv - 1][256 * NG + (i * 64 + lane) * 4]) = dbet[i];
+      *reinterpret_cast<f32x4_t*>(&red[wv - 1][2 * 256 * NG + (i * 64 + lane) * 4]) = dbia[i];
     }
   }
   __syncthreads();
   if (wv == 0) {
 #pragma unroll
-    for (int i = 0; i < TMAXG; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
         f32x4_t sg = dgam[i], sb = dbet[i], sx = dbia[i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           sg += *reinterpret_cast<const f32x4_t*>(&red[k][c]);
-          sb += *reinterpret_cast<const f32x4_t*>(&red[k][256 * TMAXG + c]);
-          sx += *reinterpret_cast<const f32x4_t*>(&red[k][2 * 256 * TMAXG + c]);
+          sb += *reinterpret_cast<const f32x4_t*>(&red[k][256 * NG + c]);
+          sx += *reinterpret_cast<const f32x4_t*>(&red[k][2 * 256 * NG + c]);
         }
         store4(part + ((size_t)blockIdx.x * 3) * H + c, sg);
         store4(part + ((size_t)blockIdx.x * 3 + 1) * H + c, sb);
@@ -383,8 +385,18 @@ extern "C" int ruart_ln_train_fwd(const float* x, int ldx, const void* res16, in
   RUART_ENTRY();
   if (H % 4 || H > 256 * TMAXG || rows <= 0 || (ldx & 3) || (ld16 & 3) || !y16 || !pre16 || !stats || p < 0.f || p >= 1.f)
     return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_train_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (const f16_t*)res16, ldr, gamma,
-                     beta, eps, p, seed, post, (f16_t*)y16, (f16_t*)pre16, stats, ld16, rows, H);
+  // NG = column groups of 256 a row needs: the per-lane state (and the backward's LDS) is sized for the width at hand - H = 768 runs
+  // the three-group instance (backward: 102 VGPRs and 27 KB instead of 134 and 36 KB of the H = 1024 one)
+#define LN_FWD(NG)                                                                                                                        \
+  hipLaunchKernelGGL(ln_train_fwd_kernel<NG>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, (const f16_t*)res16, ldr, \
+                     gamma, beta, eps, p, seed, post, (f16_t*)y16, (f16_t*)pre16, stats, ld16, rows, H)
+  switch (ceil_div(H, 256)) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    default: LN_FWD(4); break;
+  }
+#undef LN_FWD
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -398,8 +410,16 @@ extern "C" int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, co
   RUART_ENTRY();
   if (H % 4 || H > 256 * TMAXG || rows <= 0 || !d_res || (!post && !d_gemm_bf16) || !ws || !d_gamma || !d_beta) return (int)hipErrorInvalidValue;
   const int blocks = min(LN_BWD_BLOCKS, ceil_div(rows, 4));
-  hipLaunchKernelGGL(ln_train_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, add, add_scale, (const f16_t*)pre16, ld16,
-                     stats, gamma, p, seed, post, d_res, ldd, (bf16_t*)d_gemm_bf16, ldg, ws, rows, H);
+#define LN_BWD(NG)                                                                                                                       \
+  hipLaunchKernelGGL(ln_train_bwd_kernel<NG>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, add, add_scale, (const f16_t*)pre16, \
+                     ld16, stats, gamma, p, seed, post, d_res, ldd, (bf16_t*)d_gemm_bf16, ldg, ws, rows, H)
+  switch (ceil_div(H, 256)) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    default: LN_BWD(4); break;
+  }
+#undef LN_BWD
   ColReduceOut o = {{d_gamma, d_beta, d_bias}, {0, (size_t)H, (size_t)2 * H}};
   hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(H, 32), (d_bias && !post) ? 3 : 2), dim3(256), 0, (hipStream_t)stream, ws, blocks,
                      (size_t)3 * H, o, H, accumulate);
