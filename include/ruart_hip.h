@@ -157,14 +157,17 @@ int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, const float* 
                        float* d_gamma, float* d_beta, float* d_bias, int accumulate, float* ws, int rows, int H, void* stream);
 /* One pass over an fp32 master weight W (rows x cols, row stride ldw): out16 (rows x cols f16, row stride ld16) = scale * W, the forward's
  * GEMM operand, and outT_bf16 (cols x rows bf16, row stride ldT) = (scale * W)^T, the operand of dX = dY . W as an NT product.  Either output
- * may be NULL; both may point into wider matrices (the fused QKV weight: three calls with row / column offsets). */
+ * may be NULL; both may point into wider matrices (the fused QKV weight: three items with row / column offsets).  The batch form takes up to
+ * eight weights in one launch (the six of a BERT layer). */
+typedef struct {
+  const float* w;
+  void* out16;
+  void* outT_bf16;
+  int ldw, ld16, ldT, rows, cols;
+  float scale;
+} ruart_wprep_item;
+int ruart_weight_prep_batch(const ruart_wprep_item* items, int n, void* stream);
 int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols, void* stream);
-/* the same for an fp32 matrix of any width and row stride (the trunk's bias gradients, Models/Layers.py:155, 226 under autograd: widths 250,
- * 300, 1000 ...); ws: ruart_colsum_f32_ws_floats(rows, cols) floats */
-size_t ruart_colsum_f32_ws_floats(int rows, int cols);
-int ruart_colsum_f32(const float* x, int ld, int rows, int cols, float* out, int accumulate, float* ws, void* stream);
-/* out[j] (+)= sum over `rows` rows of part[r * ld + j], rows in a fixed order (the reduction behind the partial sums above) */
-int ruart_colsum_f32_rows(const float* part, int rows, int ld, int cols, float* out, int accumulate, void* stream);
 /* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
 int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */

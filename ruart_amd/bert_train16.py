@@ -102,18 +102,23 @@ class _Run:
         a = pre + "attention.self."
         wq16 = torch.empty(3 * H, H, dtype=torch.float16, device=dev)
         wqT = torch.empty(H, 3 * H, dtype=torch.bfloat16, device=dev) if self.keep else None
+        items = (hip.WPrepItemC * 6)()
+        k = 0
         for i, (n, sc) in enumerate((("query", scale), ("key", 1.0), ("value", 1.0))):
-            _chk(self.lib.ruart_weight_prep(hip.ptr(P[a + n + ".weight"]), H, float(sc), hip.ptr(wq16[i * H:]), H,
-                                            hip.ptr(wqT[:, i * H:] if self.keep else None), 3 * H, H, H, self._st()), "ruart_weight_prep")
+            items[k] = hip.WPrepItemC(P[a + n + ".weight"].data_ptr(), wq16[i * H:].data_ptr(), wqT[:, i * H:].data_ptr() if self.keep else None,
+                                      H, H, 3 * H, H, H, float(sc))
+            k += 1
         out = [wq16]
         back = [wqT]
         for n, rows, cols in (("attention.output.dense", H, H), ("intermediate.dense", I, H), ("output.dense", H, I)):
             w16 = torch.empty(rows, cols, dtype=torch.float16, device=dev)
             wT = torch.empty(cols, rows, dtype=torch.bfloat16, device=dev) if self.keep else None
-            _chk(self.lib.ruart_weight_prep(hip.ptr(P[pre + n + ".weight"]), cols, 1.0, hip.ptr(w16), cols, hip.ptr(wT), rows, rows, cols,
-                                            self._st()), "ruart_weight_prep")
+            items[k] = hip.WPrepItemC(P[pre + n + ".weight"].data_ptr(), w16.data_ptr(), wT.data_ptr() if self.keep else None, cols, cols, rows,
+                                      rows, cols, 1.0)
+            k += 1
             out.append(w16)
             back.append(wT)
+        _chk(self.lib.ruart_weight_prep_batch(items, 6, self._st()), "ruart_weight_prep_batch")      # the layer's six weights, one launch
         self.wT.append(back)
         return out
 

@@ -277,25 +277,36 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
     if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * ldo + r0 + tx] = tile[tx][c];
 }
 
-// One pass over an fp32 master weight (rows x cols): out16 = f16(scale * W) in place of the forward's operand, outT = bf16(scale * W)^T
-// (cols x rows) for dX = dY . W as an NT product.  64 x 64 tiles through LDS.
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, int ldw, float scale, f16_t* __restrict__ out16, int ld16,
-                                                          bf16_t* __restrict__ outT, int ldT, int rows, int cols) {
+// One pass over fp32 master weights (rows x cols each): out16 = f16(scale * W) in place of the forward's operand, outT = bf16(scale * W)^T
+// (cols x rows) for dX = dY . W as an NT product.  64 x 64 tiles through LDS; up to eight weights per launch (a BERT layer has six: the
+// per-weight launches were 72 x 12 us of latency per step).
+struct WPrepBatch {
+  ruart_wprep_item it[8];
+  int tile0[9];      // first tile of item i; tile0[n] = total
+  int n;
+};
+__global__ __launch_bounds__(256) void weight_prep_kernel(WPrepBatch b) {
   __shared__ float tile[64][65];
-  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.tile0[i + 1]) ++i;
+  const ruart_wprep_item& w = b.it[i];
+  const int t = blockIdx.x - b.tile0[i], tcols = (w.cols + 63) / 64;
+  const int c0 = (t % tcols) * 64, r0 = (t / tcols) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  f16_t* out16 = (f16_t*)w.out16;
+  bf16_t* outT = (bf16_t*)w.outT_bf16;
   for (int r = ty; r < 64; r += 4) {
     float v = 0.f;
-    if (r0 + r < rows && c0 + tx < cols) {
-      v = w[(size_t)(r0 + r) * ldw + c0 + tx] * scale;
-      if (out16) out16[(size_t)(r0 + r) * ld16 + c0 + tx] = (f16_t)v;
+    if (r0 + r < w.rows && c0 + tx < w.cols) {
+      v = w.w[(size_t)(r0 + r) * w.ldw + c0 + tx] * w.scale;
+      if (out16) out16[(size_t)(r0 + r) * w.ld16 + c0 + tx] = (f16_t)v;
     }
     tile[r][tx] = v;
   }
   __syncthreads();
   if (outT)
     for (int c = ty; c < 64; c += 4)
-      if (c0 + c < cols && r0 + tx < rows) outT[(size_t)(c0 + c) * ldT + r0 + tx] = (bf16_t)tile[tx][c];
+      if (c0 + c < w.cols && r0 + tx < w.rows) outT[(size_t)(c0 + c) * w.ldT + r0 + tx] = (bf16_t)tile[tx][c];
 }
 
 // C[m][n] (+)= sum_z part[z][m][n]  (fp32, z in order)
@@ -487,14 +498,29 @@ extern "C" int ruart_colsum_f32_rows(const float* part, int rows, int ld, int co
   return 0;
 }
 
-extern "C" int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols,
-                                 void* stream) {
+extern "C" int ruart_weight_prep_batch(const ruart_wprep_item* items, int n, void* stream) {
   RUART_ENTRY();
-  if (!w || rows <= 0 || cols <= 0 || (!out16 && !outT_bf16)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(weight_prep_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, (hipStream_t)stream, w, ldw, scale,
-                     (f16_t*)out16, ld16, (bf16_t*)outT_bf16, ldT, rows, cols);
+  if (!items || n <= 0 || n > 8) return (int)hipErrorInvalidValue;
+  WPrepBatch b;
+  b.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const ruart_wprep_item& w = items[i];
+    if (!w.w || w.rows <= 0 || w.cols <= 0 || (!w.out16 && !w.outT_bf16)) return (int)hipErrorInvalidValue;
+    b.it[i] = w;
+    b.tile0[i] = tiles;
+    tiles += ceil_div(w.cols, 64) * ceil_div(w.rows, 64);
+  }
+  b.tile0[n] = tiles;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, b);
   RUART_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols,
+                                 void* stream) {
+  const ruart_wprep_item one = {w, out16, outT_bf16, ldw, ld16, ldT, rows, cols, scale};
+  return ruart_weight_prep_batch(&one, 1, stream);
 }
 
 extern "C" int ruart_splitk_reduce(const float* part, long long slab_floats, int nz, float* C, long long n, float scale, int accumulate,

@@ -35,6 +35,11 @@ class BertModelC(Structure):
                 ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p))]
 
 
+class WPrepItemC(Structure):
+    _fields_ = [("w", c_void_p), ("out16", c_void_p), ("outT_bf16", c_void_p), ("ldw", c_int), ("ld16", c_int), ("ldT", c_int), ("rows", c_int),
+                ("cols", c_int), ("scale", c_float)]
+
+
 class BertBatchC(Structure):
     _fields_ = [("n_tokens", c_int), ("n_rows", c_int), ("ids", c_void_p), ("pos_ids", c_void_p), ("n_blocks", c_int),
                 ("blk_q0", c_void_p), ("blk_q1", c_void_p), ("blk_k0", c_void_p), ("blk_k1", c_void_p),
@@ -63,6 +68,7 @@ _SIGNATURES = {
     "ruart_ln_train_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _F, ctypes.c_uint, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
     "ruart_f16_to_bf16": (_I, [_P, _P, _LL, _P]),
     "ruart_weight_prep": (_I, [_P, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
+    "ruart_weight_prep_batch": (_I, [POINTER(WPrepItemC), _I, _P]),
     "ruart_colsum_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _P]),
     "ruart_transpose16": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     "ruart_splitk_reduce": (_I, [_P, _LL, _I, _P, _LL, _F, _I, _P]),

@@ -181,6 +181,19 @@ def test_weight_prep_f16_and_transposed_bf16():
     ref[:H] *= 0.125
     assert torch.equal(w16, ref.half()) and torch.equal(wT, ref.bfloat16().t())
     assert lib.ruart_weight_prep(hip.ptr(W), H + 8, 1.0, None, 0, None, 0, H, H, _st()) != 0
+    # the batch form: the three pieces and a fourth, non-square weight in one launch
+    W2 = torch.randn(70, 333, generator=g).to(DEV)
+    b16 = torch.zeros(3 * H, H, dtype=torch.float16, device=DEV)
+    bT = torch.zeros(H, 3 * H, dtype=torch.bfloat16, device=DEV)
+    o16, oT = torch.zeros(70, 333, dtype=torch.float16, device=DEV), torch.zeros(333, 70, dtype=torch.bfloat16, device=DEV)
+    items = (hip.WPrepItemC * 4)()
+    for i, sc in enumerate((0.125, 1.0, 1.0)):
+        items[i] = hip.WPrepItemC(W[i * H:].data_ptr(), b16[i * H:].data_ptr(), bT[:, i * H:].data_ptr(), H + 8, H, 3 * H, H, H, sc)
+    items[3] = hip.WPrepItemC(W2.data_ptr(), o16.data_ptr(), oT.data_ptr(), 333, 333, 70, 70, 333, 2.0)
+    assert lib.ruart_weight_prep_batch(items, 4, _st()) == 0
+    assert torch.equal(b16, w16) and torch.equal(bT, wT)
+    assert torch.equal(o16, (2 * W2).half()) and torch.equal(oT, (2 * W2).bfloat16().t())
+    assert lib.ruart_weight_prep_batch(items, 9, _st()) != 0
 
 
 def test_intermediate_dense_keeps_preactivation():
