@@ -168,6 +168,13 @@ typedef struct {
 } ruart_wprep_item;
 int ruart_weight_prep_batch(const ruart_wprep_item* items, int n, void* stream);
 int ruart_weight_prep(const float* w, int ldw, float scale, void* out16, int ld16, void* outT_bf16, int ldT, int rows, int cols, void* stream);
+/* bias gradients of an fp32 matrix of any width and row stride (the trunk's projections, Models/Layers.py:155, 226 under autograd: widths 250,
+ * 300, 1000 ...): out[j] (+)= sum_r x[r][j], two ordered stages; ws: ruart_colsum_f32_ws_floats(rows, cols) floats */
+size_t ruart_colsum_f32_ws_floats(int rows, int cols);
+int ruart_colsum_f32(const float* x, int ld, int rows, int cols, float* out, int accumulate, float* ws, void* stream);
+/* out[j] (+)= sum over `rows` rows of part[r * ld + j], rows in a fixed order (the reduction behind per-strip partial sums such as
+ * ruart_gemm_16_nt_gelu_bwd's colpart) */
+int ruart_colsum_f32_rows(const float* part, int rows, int ld, int cols, float* out, int accumulate, void* stream);
 /* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
 int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */
