@@ -192,11 +192,13 @@ int ruart_mix_rows_bwd(const void* layers16, long long layer_stride, int ld, int
                        int rows, int H, void* stream);
 /* Models/Bert/modeling.py:224-250 for training: windows of whole sequences (<= 64 word pieces per block [blk_q0, blk_q1), keys = the same
  * tokens), f16 [Q | K | V] rows in (Q pre-scaled), f16 context rows out, attention-probability dropout p_drop from `seed`; the backward
- * takes the context gradient (bf16) and writes [dQ | dK | dV] rows (bf16), recomputing the probabilities. */
+ * takes the context gradient (bf16) and writes [dQ | dK | dV] rows (bf16), recomputing the probabilities; bias_part (optional,
+ * n_blocks x 2H floats) receives every window's column sums of the unrounded dQ and dV rows ([dQ | dV]: the query / value bias gradients
+ * after ruart_colsum_f32_rows over the windows; the key bias gradient is identically zero - the softmax ignores a shift of a row). */
 int ruart_attn_train_fwd(const void* qkv16, int ld, void* ctx16, int ldc, int H, int n_heads, int n_blocks, const int* blk_q0,
                          const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, void* stream);
 int ruart_attn_train_bwd(const void* qkv16, int ld, const void* dctx_bf16, int ldc, void* dqkv_bf16, int ldd, int H, int n_heads, int n_blocks,
-                         const int* blk_q0, const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, void* stream);
+                         const int* blk_q0, const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, float* bias_part, void* stream);
 
 /* ---- whole BERT encoder (Models/Bert/modeling.py:585-614, all layer outputs kept as Bert.py:137 needs) ---- */
 typedef struct {

@@ -199,12 +199,6 @@ class _Run:
             r0 += rows
         return outs if row_scales else outs[0]
 
-    def _colsum(self, d_bf16):
-        n = d_bf16.shape[1]
-        out = torch.empty(n, dtype=torch.float32, device=self.dev)
-        _chk(self.lib.ruart_colsum_bf16(hip.ptr(d_bf16), n, self.Tp, n, hip.ptr(out), 0, hip.ptr(self.cs_ws), self._st()), "ruart_colsum_bf16")
-        return out
-
     def _ln_bwd(self, dy, add, add_scale, pre16, stats, gamma, p, seed, post=0):
         Tp, H = self.Tp, self.H
         d_res = self._new(Tp, H, torch.float32, zero=True)
@@ -231,8 +225,9 @@ class _Run:
         wmax = max(3 * H, I)
         self.xb = torch.empty(Tp * H, dtype=torch.bfloat16, device=dev)
         self.part = torch.empty(max(256, Tp // 128) * 256 * 256 + 4 * wmax * H, dtype=torch.float32, device=dev)
-        self.cs_ws = torch.empty(max(((Tp + 255) // 256) * wmax, int(lib.ruart_gemm_16_nt_gelu_bwd_ws_floats(Tp, I))), dtype=torch.float32, device=dev)
+        self.cs_ws = torch.empty(int(lib.ruart_gemm_16_nt_gelu_bwd_ws_floats(Tp, I)), dtype=torch.float32, device=dev)
         self.ln_ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), dtype=torch.float32, device=dev)
+        self.bias_part = torch.empty(pk.n_blocks, 2 * H, dtype=torch.float32, device=dev)
         dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
         dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
         blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
@@ -267,12 +262,13 @@ class _Run:
             grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, self._bf16(ctx))
             d_ctx = self._gemm(d_g1, wot, None, self._new(Tp, H, torch.bfloat16), hip.DT_BF16)
             _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0),
-                                          hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_bwd")
-            db = self._colsum(dqkv)
+                                          hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), hip.ptr(self.bias_part), st()),
+                 "ruart_attn_train_bwd")
+            db = torch.empty(2 * H, dtype=torch.float32, device=dev)          # [query | value] bias gradients: the windows' sums, in order
+            _chk(lib.ruart_colsum_f32_rows(hip.ptr(self.bias_part), pk.n_blocks, 2 * H, 2 * H, hip.ptr(db), 0, st()), "ruart_colsum_f32_rows")
             # the key bias shifts every score of a query row by the same q . b_k, which the softmax ignores: its gradient is
-            # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise), so it is
-            # not summed up out of rounded dK rows
-            grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[H:2 * H]), db[2 * H:]
+            # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise)
+            grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[:H]), db[H:]
             grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = self._dw(
                 dqkv, self._bf16(x16), row_scales=[(H, scale), (H, 1.0), (H, 1.0)])
             dX = self._gemm(dqkv, w_qkv_t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res1)

@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256, 2) void attn_train_fwd_kernel(const f16_t* __r
 __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __restrict__ qkv, int ld, const bf16_t* __restrict__ dctx, int ldc,
                                                                 bf16_t* __restrict__ dqkv, int ldd, int H, const int* __restrict__ bq0,
                                                                 const int* __restrict__ bq1, const int* __restrict__ tok_lo, float p_drop,
-                                                                unsigned seed) {
+                                                                unsigned seed, float* __restrict__ bias_part) {
   __shared__ __attribute__((aligned(16))) char Qs[64 * ARS];
   __shared__ __attribute__((aligned(16))) char Ks[64 * ARS];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ARS];
   __shared__ __attribute__((aligned(16))) char Ds[64 * ARS];      // dO * scale
+  __shared__ __attribute__((aligned(16))) float bsum[2][4][64];   // per wave: column sums of its 16 tokens' dQ and dV rows
   // Pd^T and dS^T ([key][query] images for the two products that sum over queries) take over the V and K images once every wave is
   // done with them: 37 KB of LDS per workgroup instead of 55 KB - four workgroups per CU instead of two
   char* const PT = Vs;
@@ -288,6 +289,20 @@ __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __r
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(op + dt * 16, dq[dt] * inv_dsc);
   }
+  // bias gradients: the window's column sums of dQ (here) and dV (below), before rounding; tokens past the window's end carry zeros.
+  // Lane (fr, g) holds columns dt*16 + g*4 .. +3 of token fr: sum over the 16 tokens of the wave by shuffles, over the waves in LDS.
+  auto colsum16 = [&](const f32x4_t (&v)[4], int which) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4_t t = v[dt];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += __shfl_xor(t[r], m, 64);
+      if (fr == 0) *reinterpret_cast<f32x4_t*>(&bsum[which][wave][dt * 16 + g * 4]) = t;
+    }
+  };
+  if (bias_part) colsum16(dq, 0);
   __syncthreads();                                            // every wave has read K (dQ) and V (dPd) for the last time
   // Pd^T and dS^T -> LDS [key][query] for the products that sum over queries
 #pragma unroll
@@ -330,6 +345,15 @@ __global__ __launch_bounds__(256, 2) void attn_train_bwd_kernel(const f16_t* __r
       store4(kp + H + dt * 16, dv[dt] * inv_dsc);
     }
   }
+  if (bias_part) {
+    colsum16(dv, 1);
+    __syncthreads();
+    if (tid < 128) {                                          // 64 columns of dQ, 64 of dV: the four waves' sums in wave order
+      const int which = tid >> 6, c = tid & 63;
+      const float t = ((bsum[which][0][c] + bsum[which][1][c]) + (bsum[which][2][c] + bsum[which][3][c])) * inv_dsc;
+      bias_part[(size_t)b * 2 * H + which * H + h * 64 + c] = t;
+    }
+  }
 }
 
 extern "C" int ruart_attn_train_fwd(const void* qkv16, int ld, void* ctx16, int ldc, int H, int n_heads, int n_blocks, const int* blk_q0,
@@ -344,11 +368,11 @@ extern "C" int ruart_attn_train_fwd(const void* qkv16, int ld, void* ctx16, int 
 
 extern "C" int ruart_attn_train_bwd(const void* qkv16, int ld, const void* dctx_bf16, int ldc, void* dqkv_bf16, int ldd, int H, int n_heads,
                                     int n_blocks, const int* blk_q0, const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed,
-                                    void* stream) {
+                                    float* bias_part, void* stream) {
   RUART_ENTRY();
   if (n_heads * 64 != H || n_blocks <= 0 || (ld & 7) || (ldc & 7) || (ldd & 3) || p_drop < 0.f || p_drop >= 1.f) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, (const f16_t*)qkv16, ld,
-                     (const bf16_t*)dctx_bf16, ldc, (bf16_t*)dqkv_bf16, ldd, H, blk_q0, blk_q1, tok_lo, p_drop, seed);
+                     (const bf16_t*)dctx_bf16, ldc, (bf16_t*)dqkv_bf16, ldd, H, blk_q0, blk_q1, tok_lo, p_drop, seed, bias_part);
   RUART_CHECK_LAUNCH();
   return 0;
 }

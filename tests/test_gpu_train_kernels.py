@@ -304,9 +304,15 @@ def test_attention_train_fwd_bwd_vs_autograd():
     dOb = dO.bfloat16()
     ref.backward(dOb.double())
     dqkv = torch.zeros(T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    bpart = torch.full((len(q0), 2 * H), float("nan"), device=DEV)
     assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dOb.to(DEV)), H, hip.ptr(dqkv), 3 * H, H, heads, len(q0), hip.ptr(q0d), hip.ptr(q1d),
-                                    hip.ptr(lod), 0.0, 0, _st()) == 0
+                                    hip.ptr(lod), 0.0, 0, hip.ptr(bpart), _st()) == 0
     got, want = dqkv.double().cpu(), xr.grad
+    # the windows' column sums of dQ and dV (bias gradients), taken before the bf16 rounding
+    bsum = bpart.double().sum(0).cpu()
+    for name, sl, bs in (("dQ", slice(0, H), bsum[:H]), ("dV", slice(2 * H, 3 * H), bsum[H:])):
+        ref_b = want[:, sl].sum(0)
+        assert float((bs - ref_b).abs().max()) < 2e-3 * float(want[:, sl].abs().sum(0).max()), name
     for name, sl in (("dQ", slice(0, H)), ("dK", slice(H, 2 * H)), ("dV", slice(2 * H, 3 * H))):
         e = float((got[:, sl] - want[:, sl]).abs().max()) / float(want[:, sl].abs().max())
         rel = float((got[:, sl] - want[:, sl]).norm() / want[:, sl].norm())
@@ -333,11 +339,11 @@ def test_attention_train_dropout_is_consistent():
     assert float((ctx.float() - ctx0.float()).abs().max()) > 1e-2                 # the mask does something
     dO = (torch.randint(-4, 5, (T, H), generator=g).float() / 64).bfloat16()
     dqkv = torch.zeros(T, 3 * H, dtype=torch.bfloat16, device=DEV)
-    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv), 3 * H, *args, p, 1234, _st()) == 0
+    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv), 3 * H, *args, p, 1234, None, _st()) == 0
     lhs = float((dO.double() * ctx.double().cpu()).sum())
     rhs = float((dqkv[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
     assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), 1e-3), (lhs, rhs)                 # same mask on both sides (f16 / bf16 rounding only)
     dqkv2 = torch.zeros_like(dqkv)
-    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv2), 3 * H, *args, p, 99, _st()) == 0
+    assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv2), 3 * H, *args, p, 99, None, _st()) == 0
     rhs2 = float((dqkv2[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
     assert abs(lhs - rhs2) > 5 * abs(lhs - rhs)                                    # another seed: another mask
