@@ -68,6 +68,7 @@ class BertEncoderWeights:
         def gemm_w8(t):
             """(out, 2 in) e4m3 companion of a weight matrix: [fp8(f16(w) 2^7) | fp8((w - f16(w)) 2^18)] (common.h)."""
             hi = t.to(torch.float16).to(torch.float32)
+            self._w_absmax = max(getattr(self, "_w_absmax", 0.0), float(t.abs().max()))      # load time: one sync per matrix
             pair = torch.cat([hi * float(1 << 7), (t - hi) * float(1 << 18)], 1).clamp_(-448.0, 448.0)
             return pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
@@ -79,6 +80,7 @@ class BertEncoderWeights:
         self.emb_ln_b = f32(e + "LayerNorm.beta")
         keys = ["w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2", "ln2_g", "ln2_b"]
         keys8 = ["w8_qkv", "w8_ao", "w8_ff1", "w8_ff2"] if self.corr8 else []
+        self._w_absmax = 0.0
         self.layers = {k: [] for k in keys + keys8}
         scale = 1.0 / 8.0                      # 1/sqrt(head_dim = 64): a power of two, exact in fp32 and bf16
         for l in range(cfg["num_hidden_layers"]):
@@ -110,6 +112,12 @@ class BertEncoderWeights:
         m.dtype, m.ln_eps = (hip.DT_F16 if self.corr8 else self.dtype), 1e-12
         m.f32_gemm = 1 if dtype == "x3" else 0
         m.corr8 = 1 if self.corr8 else 0
+        if self.corr8 and self._w_absmax >= 3.5:
+            # e4m3(f16(w) 2^7) saturates at |w| = 3.5 (csrc/common.h): beyond it the correction of the ACTIVATION's rounding residual is
+            # taken against a clipped weight - the product falls back towards plain-f16 accuracy for those weights, nothing breaks
+            import warnings
+            warnings.warn("fp16c: a BERT projection weight reaches |w| = %.2f; the fp8 correction operand saturates at 3.5 "
+                          "(accuracy of the affected products degrades towards the plain f16 mode)" % self._w_absmax)
         for k in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"):
             setattr(m, k, getattr(self, k).data_ptr())
         for k in keys + keys8:
