@@ -60,7 +60,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 32-bit BYTE offset; LDS address = wave-uniform byte address (through M0) + lane * 16.  The builtin takes one 64-bit pointer per lane
 // and hipcc then keeps every staged address as a VGPR pair plus two v_lshl_add_u64 per load in the K loop (12+ VGPRs and ~16 64-bit
 // VALU adds per K-tile in gemm_16_nt_256p8); this form needs one VGPR per operand piece and scalar pointer arithmetic.
-// Not tracked by the compiler's own s_waitcnt insertion: every kernel that uses it counts vmcnt by hand (they already do).
+// Not tracked by the compiler's own s_waitcnt insertion: every kernel that uses it counts vmcnt by hand (they already do).  M0 is a
+// reserved register the compiler neither allocates nor assumes across statements (it rewrites M0 in front of each of its own uses, and
+// the three GEMM kernels contain none: no builtin LDS-DMA, no s_movrel indexing, no LDS-direct loads), so it is not on the clobber list.
 // RUART_DMA_BUILTIN=1 (diagnostic builds) goes back to the builtin.
 #ifndef RUART_DMA_BUILTIN
 #define RUART_DMA_BUILTIN 0
