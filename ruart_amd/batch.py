@@ -298,9 +298,10 @@ class BatchIndex:
             pack, mfma_long = bert.pack, bert.weights.dtype != 0
         if "BERT" in opt or bert is not None:
             from .bert import PackedTokens, word_spans
+            from . import precision_of
             pack = (not opt.get("bert_no_pack", False)) if pack is None else pack
             # the MFMA long-sequence attention kernel serves the plain 16-bit modes only (fp32 storage modes: 64-query VALU blocks)
-            mfma_long = (opt.get("bert_precision", "fp16") in ("fp16", "bf16")) if mfma_long is None else mfma_long
+            mfma_long = (precision_of(opt) in ("fp16", "bf16")) if mfma_long is None else mfma_long
             self.plan = (bool(pack), bool(mfma_long))
             groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
             self.packed = PackedTokens(groups, None, pack=pack, mfma_long=mfma_long)

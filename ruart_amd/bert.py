@@ -402,7 +402,7 @@ def word_spans(packed, group, offsets, word_mask, offsets_arr=None):
 class Bert(nn.Module):
     """Drop-in for the reference's ``Bert`` module (Models/Bert/Bert.py:14-45).  ``opt`` keys used:
     BERT_LARGE, BERT_model_file / BERT_large_model_file, datadir, plus ruart extensions
-    ``bert_precision`` ('fp16' default | 'bf16' | 'fp32') and ``bert_state`` / ``bert_config`` to pass weights in memory."""
+    ``bert_precision`` ('fp16c' default - ruart_amd.DEFAULT_PRECISION - | 'x3' | 'fp32' | 'fp16' | 'bf16') and ``bert_state`` / ``bert_config`` to pass weights in memory."""
 
     def __init__(self, opt, device=None):
         super().__init__()
@@ -423,14 +423,16 @@ class Bert(nn.Module):
         if cfg["hidden_size"] != self.bert_dim or cfg["num_hidden_layers"] != self.bert_layer:
             raise ValueError("BERT checkpoint is %dx%d, conf expects %dx%d" % (cfg["num_hidden_layers"], cfg["hidden_size"],
                                                                               self.bert_layer, self.bert_dim))
-        self.weights = BertEncoderWeights(state, cfg, self._device, opt.get("bert_precision", "fp16"))
+        from . import precision_of
+        precision = precision_of(opt, cfg["hidden_size"] if cfg["intermediate_size"] % 256 == 0 else 1)
+        self.weights = BertEncoderWeights(state, cfg, self._device, precision)
         self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
         self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path
         self.pack = not opt.get("bert_no_pack", False)
         # CUs the run-ahead encoder pass may occupy.  In the fp16c mode the pass (19 ms) outlasts the trunk's step (15 ms), and a trunk
         # kernel otherwise waits for a GEMM workgroup (which owns a whole CU's registers and LDS for ~45 us) to retire: keeping 16
         # CUs out of the encoder's reach took the step from 26.7 to 25.8 ms.  The plain 16-bit modes gain nothing (round 1).
-        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 240 if opt.get("bert_precision", "fp16") == "fp16c" else 0))
+        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 240 if precision == "fp16c" else 0))
         self._init_pipeline()
 
     def unlock(self):
@@ -462,7 +464,7 @@ class Bert(nn.Module):
         if self.opt.get("bert_frozen_dropout"):
             from .bert_train import BertModelTrainable
             state, cfg = self._source
-            if (self.opt.get("bert_precision", "fp16") in ("fp16c", "fp16", "bf16") and cfg["hidden_size"] % 256 == 0
+            if (self.weights.precision in ("fp16c", "fp16", "bf16") and cfg["hidden_size"] % 256 == 0
                     and cfg["intermediate_size"] % 256 == 0):
                 # the 16-bit modes: the dropout pass runs on the 16-bit training kernels (bert_train16.py, forward only); batches it
                 # cannot take (a sequence beyond 64 word pieces) use the parent's fp32-class graph

@@ -62,6 +62,9 @@ class _Run:
         self.p_a = model.p_attn if training else 0.0
         # one 31-bit stream id per pass (CPU generator: no device sync); every dropout site adds its own offset
         self.seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.p_h > 0 or self.p_a > 0) else 0
+        if self.seed and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # the CPU generator is seeded identically on every data-parallel rank (trainer.py): keep the ranks' masks apart
+            self.seed = (self.seed + 0x632BE5AB * torch.distributed.get_rank()) & 0x7FFFFFFF
 
     def _st(self):
         return hip.stream_ptr(self.dev)                             # the stream of the tensors' device, not of the current one

@@ -150,8 +150,13 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {       // "lowbias32": a
   x ^= x >> 16;
   return x;
 }
-// multiplier of element `idx` under dropout(p) with stream `seed`: 0 or keep_inv = 1/(1-p)
+// multiplier of element `idx` under dropout(p) with stream `seed`: 0 or keep_inv = 1/(1-p).
+// Two keyed rounds: the streams of different sites / layers / heads differ in `seed` only, and any key that is ADDED to (or XORed
+// into) the index once makes one site's mask a translated copy of another's (mask_B[i] == mask_A[i + d], d fixed) - exactly
+// correlated wherever both indices are in range.  Here the index is hashed under one key and the result is keyed again, so no
+// index map carries one stream onto another.
 __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, float p, float keep_inv) {
-  const float u = (float)(hash32(idx * 0x9E3779B9u + seed) >> 8) * (1.0f / 16777216.0f);
+  const unsigned k2 = hash32(seed ^ 0xA511E9B3u);
+  const float u = (float)(hash32(hash32(idx + seed) ^ k2) >> 8) * (1.0f / 16777216.0f);
   return u >= p ? keep_inv : 0.f;
 }

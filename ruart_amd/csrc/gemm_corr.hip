@@ -283,20 +283,22 @@ extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const
   RUART_ENTRY();
   if (M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
   if (!A16 || !A8 || !W16 || !W8 || !C) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
-  void* rec = ruart_prof_begin_(s, M, N, K);
+  // every argument check sits in front of ruart_prof_begin_: an error return never leaves a profiling event open
   if (act == RUART_ACT_GELU) {
     if (residual || !C8 || ldc < N) return (int)hipErrorInvalidValue;
-    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, s);
   } else if (act == RUART_ACT_NONE) {
     if (C8) return (int)hipErrorInvalidValue;
-    if (residual)
-      launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, s);
-    else
-      launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, s);
   } else {
     return (int)hipErrorInvalidValue;
   }
+  hipStream_t s = (hipStream_t)stream;
+  void* rec = ruart_prof_begin_(s, M, N, K);
+  if (act == RUART_ACT_GELU)
+    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, s);
+  else if (residual)
+    launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, s);
+  else
+    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, s);
   ruart_prof_end_(rec, s);
   RUART_CHECK_LAUNCH();
   return 0;

@@ -60,9 +60,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 32-bit BYTE offset; LDS address = wave-uniform byte address (through M0) + lane * 16.  The builtin takes one 64-bit pointer per lane
 // and hipcc then keeps every staged address as a VGPR pair plus two v_lshl_add_u64 per load in the K loop (12+ VGPRs and ~16 64-bit
 // VALU adds per K-tile in gemm_16_nt_256p8); this form needs one VGPR per operand piece and scalar pointer arithmetic.
-// Not tracked by the compiler's own s_waitcnt insertion: every kernel that uses it counts vmcnt by hand (they already do).  M0 is a
-// reserved register the compiler neither allocates nor assumes across statements (it rewrites M0 in front of each of its own uses, and
-// the three GEMM kernels contain none: no builtin LDS-DMA, no s_movrel indexing, no LDS-direct loads), so it is not on the clobber list.
+// Not tracked by the compiler's own s_waitcnt insertion: every kernel that uses it counts vmcnt by hand (they already do).  M0 is on
+// the clobber list, so a compiler-initialised M0 (builtin LDS-DMA, s_movrel indexing, LDS-direct loads, sendmsg) added to a kernel
+// that includes this header is re-established after the statement instead of silently reading ours.
+// Precondition: `base_uniform` and `lds_dst_uniform` are wave-uniform (the "s" constraint would otherwise insert a readfirstlane
+// and quietly use lane 0's value for every lane).
 // RUART_DMA_BUILTIN=1 (diagnostic builds) goes back to the builtin.
 #ifndef RUART_DMA_BUILTIN
 #define RUART_DMA_BUILTIN 0
@@ -72,7 +74,7 @@ __device__ __forceinline__ void dma16(const void* base_uniform, unsigned lane_by
   __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(base_uniform) + lane_byte_off), (lptr_t)lds_dst_uniform, 16, 0, 0);
 #else
   const unsigned lds_addr = (unsigned)(size_t)(lptr_t)lds_dst_uniform;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_byte_off), "s"(base_uniform) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_byte_off), "s"(base_uniform) : "memory", "m0");
 #endif
 }
 

@@ -6,15 +6,21 @@ asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
     norm couples samples only inside a replica, so the semantics are "N reference steps, gradients averaged");
   * only what must move moves: trainable, actually-used parameters.  The dead ``get_answer.rnn.*`` GRU (never gets a
     gradient, Models/Layers.py:395-397) is excluded.  The word-embedding rows >= tune_partial are re-pinned after every
-    step (Models/SDNetTrainer.py:369-373) so their update never survives: they are NOT exchanged.  Their gradients do enter
-    the global clipping norm (:366), and every rank must clip by the same coefficient or the replicas drift - so each
-    rank adds the squared norm of its own pinned-row gradients to ONE scalar that rides along with the buckets
-    (``pinned_sq``): the clip norm becomes sqrt(|averaged trained gradients|^2 + sum_r |g_r,pinned|^2 / world^2), which is
-    the exact norm of the averaged gradient whenever the ranks' batches touch different pinned rows (the usual case: each rank's
-    64 questions hit different out-of-head words) and a bound within sqrt(world) of it otherwise.  Payload: ~37 MB
-    fp32 per step instead of 37 MB + 2 * (V - tune_partial) * 300 * 4.  The scalar path needs the fused
-    optimizer (it takes the extra term); with a torch optimizer, or ``opt['dp_exchange_pinned_rows']``, whole tables are exchanged;
-    ``opt['dp_skip_pinned_rows']`` (older switch) exchanges the head rows and zeroes the rest, dropping them from the norm;
+    step (Models/SDNetTrainer.py:369-373) so their update never survives - but their gradients do enter the global clipping
+    norm (:366), and every rank must clip by the same coefficient or the replicas drift.  Three ways to account for them:
+      - default ("full"): the whole tables are exchanged like every other gradient, so the clip norm is EXACTLY the norm of the
+        averaged gradient - the semantics the module promises ("N reference steps, gradients averaged").  Costs 2 x (V -
+        tune_partial) x 300 x 4 bytes of extra payload (78 MB instead of 39 MB per step at the shipped vocabulary: ~0.2 ms on
+        8 xGMI-connected GPUs, against a 20-27 ms step);
+      - ``opt['dp_pinned_scalar']`` (needs the fused optimizer): the rows are NOT exchanged; each rank adds the squared norm of
+        its own pinned-row gradients to ONE scalar that rides along with the buckets (``pinned_sq``) and the clip norm becomes
+        sqrt(|averaged trained gradients|^2 + sum_r |g_r,pinned|^2 / world^2).  That equals the exact norm only when the ranks'
+        batches touch disjoint pinned rows; when they share rows (frequent out-of-head words) the cross terms 2 <g_r, g_s> /
+        world^2 are missing and the norm is UNDER-estimated by up to sqrt(world) - a larger clip coefficient than N averaged
+        reference steps would use (tests/test_dp_gloo.py::test_clip_norm_when_ranks_share_pinned_rows shows both cases);
+      - ``opt['dp_skip_pinned_rows']`` (older switch) exchanges the head rows and zeroes the rest, dropping them from the norm.
+    A sparse exchange (ids + rows of the touched pinned rows) was considered and dropped: at the bench shape a rank looks up
+    ~19 k words per step, i.e. most of a 20 k vocabulary - the "sparse" all-gather would move MORE than the dense all-reduce;
   * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
     win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order.  The buckets
     are allocated once; when the last gradient of a bucket has been produced, ONE multi-tensor copy moves the bucket's
@@ -51,8 +57,9 @@ def init_process_group(device, backend="nccl", **kw):
 
 class GradSync:
     def __init__(self, network, opt, group=None, bucket_bytes=16 << 20, pinned_scalar=False):
-        """``pinned_scalar``: the caller's optimizer takes ``pinned_sq`` (FusedAdamax.clip_and_step(extra_sq=)), so the re-pinned
-        embedding rows are represented by one scalar instead of being exchanged."""
+        """``pinned_scalar``: opt-in approximation - the caller's optimizer takes ``pinned_sq`` (FusedAdamax.clip_and_step(extra_sq=)) and
+        the re-pinned embedding rows are represented by one scalar instead of being exchanged (see the module docstring: exact only
+        when the ranks touch disjoint pinned rows).  Default: whole tables exchanged, exact clip norm."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.network = network
@@ -149,12 +156,21 @@ class GradSync:
 
     def _launch_pinned_scalar(self):
         """One scalar for the rows that are never exchanged: this rank's sum of squares of their gradients."""
+        dev = self._flat[0].device
+        if dev.type == "cuda":
+            # the tables' gradients may have been accumulated on other trunk streams than the one this (last) bucket's hook runs
+            # on, and in EARLIER buckets: wait for every stream any bucket holding a pinned table noted
+            cur = torch.cuda.current_stream(dev)
+            for bi, b in enumerate(self.buckets):
+                if any(r is not None for (_, _, r) in b):
+                    for s in self._streams[bi]:
+                        if s != cur:
+                            cur.wait_stream(s)
         parts = []
         for (_, p, rows) in self._pinned:
             g = p.grad
             if g is not None and g.shape[0] > rows:
                 parts.append(g[rows:].float().pow(2).sum())
-        dev = self._flat[0].device
         sq = torch.stack(parts).sum().reshape(1) if parts else torch.zeros(1, device=dev)
         self._sq = sq
         self._sq_work = dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

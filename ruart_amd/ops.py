@@ -166,7 +166,11 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     M, K = a.shape
     N = b.shape[1]
     mode = mode or trunk_gemm
-    use_x3 = mode in ("x3", "x1") and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+    if mode in ("x3", "x1"):           # the product modes have no CPU path (torch.mm below is the fp32 VALIDATION mode only)
+        for t in (a, b):
+            if not (t.is_cuda and t.dtype == torch.float32):
+                raise hip.HipError("ops.mm: fp32 device tensors only (there is no CPU path); got %s on %s" % (t.dtype, t.device))
+    use_x3 = mode in ("x3", "x1")
     if use_x3:
         a, b = _one_unit_stride(a), _one_unit_stride(b)
         # the fused operand masks follow the operand's natural orientation only: otherwise multiply first
@@ -270,18 +274,22 @@ class _AddMM(torch.autograd.Function):
 
 def addmm(base, x, w):
     """base (M, N) + x (M, K) . w (N, K)^T."""
-    if trunk_gemm != "x3" or not x.is_cuda:
+    if trunk_gemm != "x3":             # exact-fp32 validation mode
         return torch.addmm(base, x, w.t())
+    if not x.is_cuda:
+        raise hip.HipError("ops.addmm: device tensors only (there is no CPU path)")
     return _AddMM.apply(base, x.contiguous(), w)
 
 
 def linear(x, w, b=None, mask=None):
     """F.linear for fp32 device tensors of any leading shape, through ``mm``.  ``mask`` (B, K) with x (B, T, K): variational
     dropout (x * mask[:, None, :]) applied inside the op - one multiply in the forward, none in the backward."""
-    if trunk_gemm != "x3" or not x.is_cuda:
+    if trunk_gemm != "x3":             # exact-fp32 validation mode
         if mask is not None:
             x = x * mask.unsqueeze(1)
         return torch.nn.functional.linear(x, w, b)
+    if not x.is_cuda:
+        raise hip.HipError("ops.linear: device tensors only (there is no CPU path)")
     lead = x.shape[:-1]
     rpm = 1
     if mask is not None:

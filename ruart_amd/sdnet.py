@@ -376,7 +376,7 @@ class SDNet(nn.Module):
         opt = self.opt
         dev = self.device
         # trunk projections: split-bf16 MFMA kernel, or the library's exact fp32 GEMM in the fp32 validation mode
-        prec = opt.get("bert_precision", "fp16")
+        prec = self.Bert.weights.precision if "BERT" in opt else "x3"
         ops.trunk_gemm = opt.get("ruart_trunk_gemm", "fp32" if prec == "fp32" else "x3")
         # gradients of the trunk's projections: three bf16 products like the forward ("x1": one product - measured worth only
         # 0.1-0.2 ms of a 20 ms step, these products are bound by their fp32 operand loads, so it stays an option)

@@ -121,6 +121,7 @@ class SDNetTrainer(BaseTrainer):
         random.seed(self.seed)
         np.random.seed(self.seed)
         torch.manual_seed(self.seed)
+        self._rank_seeded = False
         self.batch_size = opt["batch_size"]
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type == "cuda":
@@ -172,13 +173,31 @@ class SDNetTrainer(BaseTrainer):
         else:
             raise ValueError("loss parameter is error")
         self.updates = 0
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                              and torch.distributed.get_world_size() > 1):
+        # opt['ruart_dp'] = False: a plain single-replica trainer even inside an initialised process group (tests compare against it)
+        if self.opt.get("ruart_dp", True) and (self.process_group is not None or (
+                torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)):
             from .dp import GradSync
-            # the fused optimizer takes the re-pinned rows' share of the clip norm as one scalar: they are not exchanged
+            # default: the embedding tables are exchanged whole, so the clip norm is the exact norm of the averaged gradient;
+            # opt['dp_pinned_scalar'] (fused optimizer only) represents the re-pinned rows by one scalar instead (dp.py)
             self.grad_sync = GradSync(self.network, self.opt, group=self.process_group,
-                                      pinned_scalar=hasattr(self.optimizer, "clip_and_step"))
+                                      pinned_scalar=bool(self.opt.get("dp_pinned_scalar")) and hasattr(self.optimizer, "clip_and_step"))
             self.grad_sync.broadcast_parameters()
+            # the replicas share their parameters, not their dropout masks: every rank seeded torch identically above (so that the
+            # initial weights agree even before the broadcast), which would make all ranks draw the SAME variational-dropout masks
+            # step after step.  From here on each rank's generators run their own stream.
+            rank = torch.distributed.get_rank(self.process_group)
+            if rank > 0 and not self._rank_seeded:
+                torch.manual_seed(self.seed + 7919 * rank)
+            self._rank_seeded = True
+
+    def close(self):
+        """Release what must not outlive the process's own teardown: the encoder's run-ahead stream.  A CU-masked stream
+        (hipExtStreamCreateWithCUMask, the default in the fp16c mode) that is still alive at static destruction makes a process
+        profiled under rocprofv3 die in __cxa_finalize.  ``train()``, a stand-alone ``evaluate()`` and
+        ``predict_for_test()`` call this on every exit path; a later step simply creates a new stream."""
+        bert = getattr(getattr(self, "network", None), "Bert", None)
+        if bert is not None:
+            bert.close()
 
     def ToCUDA(self, batch):
         """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host copies,
@@ -284,6 +303,13 @@ class SDNetTrainer(BaseTrainer):
         ``submission.json`` without the wrap-around padding of the last batch) or any iterable of collated batches (metrics
         only).  Returns (mean loss, ANLS, ACC, predictions)."""
         assert mode in ("train", "dev", "test")
+        try:
+            return self._evaluate(val_data, batch_i, mode)
+        finally:
+            if not getattr(self, "_in_train", False):     # stand-alone evaluation: nothing else will release the stream
+                self.close()
+
+    def _evaluate(self, val_data, batch_i, mode):
         from torch.utils.data import Dataset
         is_dataset = isinstance(val_data, Dataset)
         loader = self._loader(val_data, VQA_Sampler(val_data, self.opt["max_batch_num"], self.batch_size, False)) if is_dataset \
@@ -343,6 +369,14 @@ class SDNetTrainer(BaseTrainer):
         runs over any iterable of collated batches.  Either way the next batch is staged one step ahead so that its frozen-BERT
         pass overlaps this step's trunk."""
         self.isTrain = True
+        self._in_train = True
+        try:
+            self._train(train_loader, val_loader, eval_every, log_every)
+        finally:
+            self._in_train = False
+            self.close()
+
+    def _train(self, train_loader, val_loader, eval_every, log_every):
         train_data = None
         batch_st = 0
         if train_loader is None:
@@ -391,7 +425,7 @@ class SDNetTrainer(BaseTrainer):
         self._setup_from_meta()
         self.load_model(os.path.join(self.opt["datadir"], self.opt["MODEL_PATH"]))
         test_data = VQA_Dataset(self._records("test"), self.opt, mode="test")
-        return self.evaluate(test_data, 0, "test")
+        return self.evaluate(test_data, 0, "test")          # a stand-alone evaluate(): closes the run-ahead stream on exit
 
     # -- checkpoints ------------------------------------------------------------------------------------------
     def load_model(self, model_path):

@@ -88,6 +88,54 @@ def test_gradsync_two_ranks(tmp_path, skip_pinned):
         assert torch.equal(r[0]["params"][name], r[1]["params"][name]), name
 
 
+def _shared_rows_worker(rank, world, port, scalar, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ruart_amd.dp import GradSync
+    torch.manual_seed(3)
+    net = Toy()
+    gs = GradSync(net, {"TUNE_PARTIAL": True, "tune_partial": 5}, bucket_bytes=64, pinned_scalar=scalar)
+    gs.broadcast_parameters()
+    # both ranks look up the pinned rows 7 and 9 (frequent out-of-head words): their gradients are strongly correlated
+    ids = torch.tensor([[1, 2, 7], [3, 9, 7]]) if rank == 0 else torch.tensor([[0, 7, 7], [9, 9, 6]])
+    net(ids).backward()
+    local = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    gs.average_gradients()
+    res = {"mode": gs.mode, "local": local, "avg": {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+           "pinned_sq": None if gs.pinned_sq is None else float(gs.pinned_sq)}
+    torch.save(res, out % rank)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scalar", [False, True])
+def test_clip_norm_when_ranks_share_pinned_rows(tmp_path, scalar):
+    """Models/SDNetTrainer.py:366 clips by the norm of THE gradient - under data parallelism the averaged one.  Default mode: the
+    tables are exchanged whole and the norm every rank computes is exactly that.  opt['dp_pinned_scalar']: the pinned rows enter as
+    sum_r |g_r|^2 / world^2, which drops the cross terms between ranks - equal to the exact norm only for disjoint rows; here (shared
+    rows, positively correlated gradients) it is an under-estimate, bounded by sqrt(world)."""
+    world, tp = 2, 5
+    out = str(tmp_path / "s%d.pt")
+    mp.spawn(_shared_rows_worker, args=(world, _free_port(), scalar, out), nprocs=world, join=True)
+    r = [torch.load(out % i) for i in range(world)]
+    names = list(r[0]["local"])
+    exact_sq = sum(float(((r[0]["local"][n] + r[1]["local"][n]) / 2).double().pow(2).sum()) for n in names)
+    if not scalar:
+        assert r[0]["mode"] == "full" and r[0]["pinned_sq"] is None
+        got_sq = sum(float(r[0]["avg"][n].double().pow(2).sum()) for n in names)
+        assert abs(got_sq - exact_sq) < 1e-6 * exact_sq
+        for n in names:
+            assert torch.equal(r[0]["avg"][n], r[1]["avg"][n]), n
+        return
+    assert r[0]["mode"] == "scalar" and r[0]["pinned_sq"] == r[1]["pinned_sq"]
+    tables = ("fast_embed.weight", "glove_embed.weight")
+    trained_sq = sum(float((r[0]["avg"][n][:tp] if n in tables else r[0]["avg"][n]).double().pow(2).sum()) for n in names)
+    got_sq = trained_sq + r[0]["pinned_sq"]
+    formula = sum(float(r[k]["local"][n][tp:].double().pow(2).sum()) for k in range(world) for n in tables) / world ** 2
+    assert abs(r[0]["pinned_sq"] - formula) < 1e-5 * formula
+    assert got_sq < exact_sq * 0.999                  # the cross terms 2 <g_0, g_1> / world^2 of the shared rows are missing
+    assert got_sq * world > exact_sq * 0.999          # ... and the estimate is never more than sqrt(world) too small
+
+
 # ---- the REAL SDNet parameter list (no forward: gradients filled by hand) -------------------------------------------------------
 class _StubBert(nn.Module):
     """Stands in for ruart_amd.bert.Bert: the frozen encoder holds no nn.Parameter, so the DP logic never sees it."""

@@ -26,6 +26,7 @@ for i in range(steps):
         torch.cuda.synchronize()
         mem.append(torch.cuda.memory_allocated() / 2**30)
         print("step %4d loss %.4f avg %.4f  mem %.2f GiB reserved %.2f GiB  %.1f s" % (i, losses[-1], np.mean(losses[-20:]), mem[-1], torch.cuda.memory_reserved() / 2**30, time.time() - t0), flush=True)
+tr.close()          # the CU-masked run-ahead stream must not outlive the process teardown
 assert all(np.isfinite(losses))
 assert np.mean(losses[-20:]) < np.mean(losses[:20]), (np.mean(losses[:20]), np.mean(losses[-20:]))
 assert mem[-1] < mem[1] * 1.15 + 0.5, mem
