@@ -224,7 +224,9 @@ def test_collate_can_prepare_the_batch_index_in_a_worker():
     host = pickle.loads(pickle.dumps(q["_ruart_host_index"]))
     q2, ocr2, od2, _, _ = VQA_collate(opt).VQA_collate_fun(samples)
     ref = BatchIndex(q2, ocr2, od2, opt)
-    assert host.plan == ref.plan == (True, True)
+    # default precision fp16c: fp32 QKV rows, 64-query split-f16 attention blocks (the MFMA long-sequence plan is the plain 16-bit modes')
+    assert host.plan == ref.plan == (True, False)
+    assert BatchIndex(q2, ocr2, od2, dict(opt, bert_precision="fp16")).plan == (True, True)
     assert np.array_equal(host.packed.host, ref.packed.host) and host.packed.T == ref.packed.T
     assert np.array_equal(host._spans_host[0], ref._spans_host[0]) and host._spans_host[1] == ref._spans_host[1]
     for a, b in ((host.ocr, ref.ocr), (host.od, ref.od)):
