@@ -55,6 +55,11 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
  * M % 256 == 0, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                       const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, void* stream);
+/* The same product with a chosen subset of the correction terms (same sites; the ablation of tools/corr_ablation.py): corr 3 = both
+ * (== ruart_gemm_16c_nt), 1 = only a_lo . w_hi (the activation's rounding residual), 2 = only a_hi . w_lo (the weight's), 0 = none
+ * (a plain f16 product through this kernel).  corr 1 / 2 need K % 256 == 0. */
+int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                          const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr, void* stream);
 /* Training forward of the intermediate dense (Models/Bert/modeling.py:287-288): G16 = gelu(A . W^T + bias) and the pre-activation H16, both
  * (M x N) in the operands' 16-bit type, row stride ldc.  M, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* H16, void* G16, int ldc, int M, int N, int K,
@@ -130,14 +135,21 @@ int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8
                                const int* tok_hi, const float* key_bias, void* stream);
 /* Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: out[dst_row[w]] = sum_l layer_w[l] *
  * mean(layer_l[span_start[w] .. +span_len[w])).  layers = n_layers matrices [rows, H], layer_stride elements apart.
+ * span_start_last (optional): the spans' first rows inside the LAST layer's matrix when ruart_bert_forward left it compacted
+ * (ruart_bert_batch.last_rows); NULL = the same rows as in every other layer.
  * Rows of `out` that no word maps to are left untouched (the caller zero-fills: masked words are zeros). */
 int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
-                        const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H,
-                        void* stream);
+                        const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo,
+                        int n_words, int H, void* stream);
 /* d(loss)/d(layer_w[l]) for the op above; partial_ws holds n_words * n_layers floats. Deterministic.  (Both: H % 4 == 0, H <= 1024.) */
 int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
-                            const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial_ws,
-                            float* grad_layer_w, int n_words, int H, void* stream);
+                            const int* span_start_last, const int* span_len, const int* dst_row, const float* grad_out, int ldg,
+                            float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream);
+/* dst_k[i][0 .. bytes_k) = src_k[rows[i]][0 .. bytes_k) for up to three row-major byte matrices (k = 0..2; a NULL src ends the list):
+ * the compaction of the last encoder layer's inputs to the rows of ruart_bert_batch.last_rows.  bytes_k % 16 == 0, 16-byte aligned. */
+int ruart_rows_gather(const int* rows, int n, const void* src0, long long sp0, void* dst0, long long dp0, int bytes0, const void* src1,
+                      long long sp1, void* dst1, long long dp1, int bytes1, const void* src2, long long sp2, void* dst2, long long dp2,
+                      int bytes2, void* stream);
 int ruart_cast_f32_to_16(const float* in, void* out, int out_dtype, long long n, float scale, void* stream);
 
 /* ---- kernels of the TRAINABLE encoder's 16-bit path (conf without LOCK_BERT, opt['bert_train_gemm'] = '16'; csrc/bert_train_*.hip).
@@ -233,9 +245,19 @@ typedef struct {
   const float* key_bias; /* NULL when every kept token is attendable */
   int n_long_blocks;     /* <=128-query blocks of sequences longer than 64 tokens (MFMA kernel); 0 in fp32 mode */
   const int *lblk_q0, *lblk_q1, *lblk_k0, *lblk_k1;
+  /* Optional: the packed rows some word span reads from the LAST layer (Models/Bert/Bert.py:153-165 pools word pieces only; the
+   * [CLS] / [SEP] rows - 41 % of the stream at ST-VQA item lengths - feed the next layer's attention and nothing else, and the last
+   * layer has no next layer).  Ascending, n_last_rows > 0: the last layer's output projection, FFN and layer norms run on these rows
+   * only and layers_out[n_layers - 1] holds them COMPACTED (row i = packed row last_rows[i]); 0 / NULL: every row, in place. */
+  int n_last_rows;
+  const int* last_rows;
 } ruart_bert_batch;
 
 size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows);
+/* fp16c mode of ruart_bert_forward (Models/Bert/modeling.py:225-227, 261, 287-288, 300): which correction products (the `corr` of
+ * ruart_gemm_16c_nt_sel) the QKV / attention-output / intermediate / output projections carry, in the layers whose bit is set in
+ * layer_mask.  Default (3, 3, 3, 3, all layers) - the only setting the parity tests hold to 1e-3.  Process-wide. */
+int ruart_bert_set_correction(int qkv, int ao, int ff1, int ff2, unsigned long long layer_mask);
 /* layers_out: [n_layers][n_rows][hidden] in m->dtype (fp32 when m->corr8).  `m` and `b` are HOST structs. */
 int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                        size_t workspace_bytes, void* stream);

@@ -302,9 +302,13 @@ class BatchIndex:
             pack = (not opt.get("bert_no_pack", False)) if pack is None else pack
             # the MFMA long-sequence attention kernel serves the plain 16-bit modes only (fp32 storage modes: 64-query VALU blocks)
             mfma_long = (precision_of(opt) in ("fp16", "bf16")) if mfma_long is None else mfma_long
-            self.plan = (bool(pack), bool(mfma_long))
+            # frozen, deterministic encoder: identical sequences are encoded once and the last layer runs on pooled rows only (both
+            # bit-neutral; opt['bert_dedup'] / opt['bert_last_rows'] = False switch them off)
+            frozen = "LOCK_BERT" in opt and not opt.get("bert_frozen_dropout")
+            dedup = frozen and bool(opt.get("bert_dedup", True)) and bool(pack)
+            self.plan = (bool(pack), bool(mfma_long), dedup)
             groups = [(q_list["bert"], q_list["bert_mask"]), (ocr_list["bert"], ocr_list["bert_mask"]), (od_list["bert"], od_list["bert_mask"])]
-            self.packed = PackedTokens(groups, None, pack=pack, mfma_long=mfma_long)
+            self.packed = PackedTokens(groups, None, pack=pack, mfma_long=mfma_long, dedup=dedup)
             if "LOCK_BERT" not in opt:
                 self.packed.prepare_embedding_sorts()      # trainable encoder: its embedding gradients take the sorted, ordered path
             spans = []
@@ -325,7 +329,26 @@ class BatchIndex:
                     keep = d >= 0                      # words beyond len_cnt never reach multi2one's consumed state
                     s, l, d, rows = s[keep], l[keep], d[keep].astype(np.int32), idx.W
                 spans.append((s, l, d, rows))
-            self._spans_host = (np.concatenate([np.concatenate(t[:3]) for t in spans]).astype(np.int32),
+            # rows of the packed stream some word span reads (Models/Bert/Bert.py:153-165 pools word pieces, never [CLS] / [SEP]):
+            # the only rows the LAST encoder layer has to produce.  last_start[w] = the span's first row after compaction to them.
+            T = self.packed.T
+            self._n_last = 0
+            last_rows = np.zeros(0, dtype=np.int32)
+            last_start = [np.zeros(0, dtype=np.int32)] * len(spans)
+            if frozen and opt.get("bert_last_rows", True) and T > 0:
+                mark = np.zeros(T + 1, dtype=np.int64)
+                for (s_, l_, _, _) in spans:
+                    np.add.at(mark, s_, 1)
+                    np.add.at(mark, s_.astype(np.int64) + l_, -1)
+                covered = np.cumsum(mark[:T]) > 0
+                if 0 < covered.sum() < T:
+                    last_rows = np.nonzero(covered)[0].astype(np.int32)
+                    remap = np.cumsum(covered) - 1
+                    last_start = [remap[t[0]].astype(np.int32) for t in spans]
+                    self._n_last = len(last_rows)
+            if self._n_last == 0:
+                last_start = [np.zeros(0, dtype=np.int32)] * len(spans)
+            self._spans_host = (np.concatenate([np.concatenate(list(t[:3]) + [ls]) for t, ls in zip(spans, last_start)] + [last_rows]).astype(np.int32),
                                 [(len(t[0]), t[3]) for t in spans])
             if "LOCK_BERT" in opt and not opt.get("bert_frozen_dropout"):
                 self.packed.group_index = None         # (N, L) maps were only needed for the spans: keep the pickle small
@@ -399,9 +422,13 @@ class BatchIndex:
             dev = h["spans"].to(self.device, non_blocking=True)
             o = 0
             self.spans = []
+            n_last = getattr(self, "_n_last", 0)
             for W, rows in shapes:
-                self.spans.append((dev[o:o + W], dev[o + W:o + 2 * W], dev[o + 2 * W:o + 3 * W], rows))
-                o += 3 * W
+                last = dev[o + 3 * W:o + 4 * W] if n_last else None
+                self.spans.append((dev[o:o + W], dev[o + W:o + 2 * W], dev[o + 2 * W:o + 3 * W], rows, last))
+                o += (4 if n_last else 3) * W
+            if n_last:
+                self.packed.set_last_rows(dev[o:o + n_last])
         return self
 
 

@@ -142,8 +142,13 @@ class PackedTokens:
     ``pack=True`` keeps only mask==1 positions; ``pack=False`` keeps every position and turns the mask into the
     reference's additive -10000 key bias (exact reference semantics for arbitrary masks)."""
 
-    def __init__(self, groups, device=None, pack=True, mfma_long=True, window=512, max_positions=None):
+    def __init__(self, groups, device=None, pack=True, mfma_long=True, window=512, max_positions=None, dedup=False):
         """Host part (numpy only; picklable, so it can run in DataLoader workers) + ``bind(device)`` when a device is given.
+        ``dedup`` (frozen encoder only): rows of a group with identical kept (position, id) sequences are encoded ONCE - every
+        duplicate's ``group_index`` points at the first occurrence's packed rows, so its word spans pool the same bits.  The
+        encoder is a deterministic function of the sequence (no dropout when frozen, block-diagonal attention), which makes this
+        bit-neutral; the ``<OCR>`` / ``<OD>`` sentinel items alone are 2 B identical sequences per batch, repeated scene words and
+        object classes come on top.
         ``window``: the reference cuts a row longer than 512 word pieces into independent 512-windows, each encoded as its own
         sequence with positions restarting at 0, and concatenates the outputs (Models/Bert/Bert.py:18, 96-99, 133-138): here
         every (row, window) with at least one kept piece is a sequence of the packed stream; a row's pieces stay contiguous, so
@@ -163,8 +168,18 @@ class PackedTokens:
             if (keep.sum(1) == 0).any():
                 raise ValueError("a BERT input row has no attendable token")
             nw = (L + window - 1) // window
+            canon = None
+            if dedup and nw == 1 and N > 1:
+                key = np.ascontiguousarray(np.where(keep, ids, -1))
+                _, first, inv = np.unique(key.view(np.dtype((np.void, key.dtype.itemsize * L))).reshape(-1), return_index=True, return_inverse=True)
+                canon = first[inv.reshape(-1)]                       # row -> its first identical row
+                if (canon == np.arange(N)).all():
+                    canon = None
+                else:
+                    keep = keep & (canon == np.arange(N))[:, None]   # duplicates contribute no packed rows
             if nw == 1:
                 lens = keep.sum(1).astype(np.int64)
+                lens = lens[lens > 0] if canon is not None else lens
             else:                        # (row, window) sequences in row-major order, empty windows dropped
                 padded = np.zeros((N, nw * window), dtype=bool)
                 padded[:, :L] = keep
@@ -173,7 +188,8 @@ class PackedTokens:
             flat = keep.reshape(-1)
             idx = np.full(N * L, -1, dtype=np.int64)
             idx[flat] = base + np.arange(int(flat.sum()))
-            self.group_index.append(idx.reshape(N, L))
+            idx = idx.reshape(N, L)
+            self.group_index.append(idx if canon is None else idx[canon])
             ids_l.append(ids.reshape(-1)[flat])
             pos_l.append(np.broadcast_to(np.arange(L) % window, (N, L)).reshape(-1)[flat])
             len_l.append(lens)
@@ -208,7 +224,7 @@ class PackedTokens:
             self.bind(device)
 
     _DEVICE_FIELDS = ("buf", "ids", "pos", "tok_lo", "tok_hi", "blk", "lblk", "key_bias", "c_batch", "_layers", "_event", "_set", "_train_plan",
-                      "_emb_sorts")
+                      "_emb_sorts", "last_rows")
 
     def prepare_embedding_sorts(self):
         """Host part of the trainable encoder's embedding gradients (numpy; BatchIndex calls it in the DataLoader worker when the conf has
@@ -269,8 +285,17 @@ class PackedTokens:
         b.key_bias = self.key_bias.data_ptr() if self.key_bias is not None else None
         b.n_long_blocks = nlb
         b.lblk_q0, b.lblk_q1, b.lblk_k0, b.lblk_k1 = [t.data_ptr() if nlb else None for t in self.lblk]
+        b.n_last_rows, b.last_rows = 0, None
         self.c_batch = b
         return self
+
+    def set_last_rows(self, rows_dev):
+        """``rows_dev``: ascending int32 device vector of the packed rows some word span pools (batch.BatchIndex).  The frozen
+        encoder then computes its LAST layer on those rows only and leaves that layer's output compacted
+        (ruart_bert_batch.last_rows); the pooling kernels take the compacted span starts beside the ordinary ones."""
+        self.last_rows = rows_dev
+        self.c_batch.n_last_rows = int(rows_dev.numel())
+        self.c_batch.last_rows = rows_dev.data_ptr()
 
     @staticmethod
     def _plan_blocks(lens, cu, mfma_long=True):
@@ -341,35 +366,37 @@ class _PoolMix(torch.autograd.Function):
     Models/SDNet.py:91-94)."""
 
     @staticmethod
-    def forward(ctx, layer_w, layers, span_start, span_len, dst_row, n_rows, dtype_code):
+    def forward(ctx, layer_w, layers, span_start, span_len, dst_row, n_rows, dtype_code, span_start_last=None):
+        """``span_start_last``: the spans' first rows in the LAST layer's matrix when the encoder left it compacted
+        (PackedTokens.set_last_rows); None = as in every other layer."""
         lib = hip.load()
         NL, Tp, H = layers.shape
         W = span_start.numel()
         out = torch.zeros(n_rows, H, dtype=torch.float32, device=layers.device)
         lw = layer_w.detach().to(torch.float32).contiguous()
         if W > 0:
-            rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_len),
+            rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
                                          hip.ptr(dst_row), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
             hip.check(rc, "ruart_bert_pool_mix")
-        ctx.save_for_backward(layers, span_start, span_len, dst_row)
+        ctx.save_for_backward(layers, span_start, span_len, dst_row, span_start_last)
         ctx.dtype_code = dtype_code
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = hip.load()
-        layers, span_start, span_len, dst_row = ctx.saved_tensors
+        layers, span_start, span_len, dst_row, span_start_last = ctx.saved_tensors
         NL, Tp, H = layers.shape
         W = span_start.numel()
         g = torch.zeros(NL, dtype=torch.float32, device=layers.device)
         if W > 0:
             grad_out = grad_out.contiguous()
             partial = torch.empty(W * NL, dtype=torch.float32, device=layers.device)
-            rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_len),
+            rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
                                              hip.ptr(dst_row), hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H,
                                              hip.stream_ptr())
             hip.check(rc, "ruart_bert_pool_mix_bwd")
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 def word_spans(packed, group, offsets, word_mask, offsets_arr=None):

@@ -52,6 +52,26 @@ extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_ro
   return t;
 }
 
+// Which correction products each projection site carries (ruart_gemm_16c_nt_sel's `corr`: 3 = both - the default and the only setting
+// the parity tests hold to 1e-3 -, 1 = a_lo . w_hi only, 2 = a_hi . w_lo only, 0 = none) and in which layers: the knobs of the ablation
+// in tools/corr_ablation.py.  Process-wide; sites in the order QKV, attention output, intermediate, output.
+static int g_corr_site[4] = {3, 3, 3, 3};
+static unsigned long long g_corr_layers = ~0ull;
+extern "C" int ruart_bert_set_correction(int qkv, int ao, int ff1, int ff2, unsigned long long layer_mask) {
+  const int v[4] = {qkv, ao, ff1, ff2};
+  for (int i = 0; i < 4; ++i)
+    if (v[i] < 0 || v[i] > 3) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < 4; ++i) g_corr_site[i] = v[i];
+  g_corr_layers = layer_mask;
+  return 0;
+}
+
+// Rows the last layer has to produce: b->n_last_rows when the caller listed them (and the encoder has a layer before the last one whose
+// output is the residual), else 0 = all.
+static int last_layer_rows(const ruart_bert_model* m, const ruart_bert_batch* b) {
+  return (b->n_last_rows > 0 && b->last_rows && b->n_last_rows < b->n_tokens && m->n_layers >= 2) ? b->n_last_rows : 0;
+}
+
 // The encoder in the f16 + fp8-correction mode.  layers_out: [n_layers][n_rows][hidden] fp32.
 static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace, void* stream) {
   const int H = m->hidden, I = m->intermediate, R = b->n_rows;
@@ -75,25 +95,46 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
   if (rc) return rc;
   ruart_prof_real_rows = b->n_tokens;
   const float* res = x32;
+  const int n_last = last_layer_rows(m, b);
   for (int l = 0; l < m->n_layers; ++l) {
     float* out = (float*)layers_out + (size_t)l * R * H;
-    if ((rc = ruart_gemm_16c_nt(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
-                                RUART_ACT_NONE, stream)))
+    const bool on = (g_corr_layers >> (l & 63)) & 1ull;
+    const int c_qkv = on ? g_corr_site[0] : 0, c_ao = on ? g_corr_site[1] : 0, c_ff1 = on ? g_corr_site[2] : 0, c_ff2 = on ? g_corr_site[3] : 0;
+    if ((rc = ruart_gemm_16c_nt_sel(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
+                                    RUART_ACT_NONE, c_qkv, stream)))
       return rc;
     if ((rc = ruart_bert_attention_split(qkv, 3 * H, ctx16, ctx8, H, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
                                          b->tok_lo, b->tok_hi, b->key_bias, stream)))
       return rc;
-    if ((rc = ruart_gemm_16c_nt(ctx16, ctx8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, R, H, H, RUART_ACT_NONE,
-                                stream)))
+    // Last layer: only the rows some word span pools are needed from here on (ruart_bert_batch.last_rows).  Their context rows and
+    // residual rows are compacted into buffers that are dead by now - the layer's own GEMM operand x16 / x8 and the QKV rows - and the
+    // rest of the layer runs on Rl = ceil(n_last / 256) * 256 rows, leaving layers_out[last] compacted.
+    int Rl = R;
+    const void *a16 = ctx16, *a8 = ctx8;
+    if (n_last > 0 && l == m->n_layers - 1) {
+      Rl = (n_last + 255) / 256 * 256;              // R is a multiple of 256 and n_last < n_tokens <= R: Rl <= R
+      if ((rc = ruart_rows_gather(b->last_rows, n_last, ctx16, (long long)H * 2, x16, (long long)H * 2, H * 2, ctx8, (long long)H * 2, x8,
+                                  (long long)H * 2, H * 2, res, (long long)H * 4, qkv, (long long)H * 4, H * 4, stream)))
+        return rc;
+      a16 = x16;
+      a8 = x8;
+      res = qkv;
+      ruart_prof_real_rows = n_last;
+    }
+    if ((rc = ruart_gemm_16c_nt_sel(a16, a8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, Rl, H, H, RUART_ACT_NONE,
+                                    c_ao, stream)))
       return rc;
-    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid32, mid16, mid8, H, R, H, stream))) return rc;
-    if ((rc = ruart_gemm_16c_nt(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, R, I, H,
-                                RUART_ACT_GELU, stream)))
+    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid32, mid16, mid8, H, Rl, H, stream))) return rc;
+    if ((rc = ruart_gemm_16c_nt_sel(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, Rl, I, H,
+                                    RUART_ACT_GELU, c_ff1, stream)))
       return rc;
-    if ((rc = ruart_gemm_16c_nt(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, R, H, I,
-                                RUART_ACT_NONE, stream)))
+    if ((rc = ruart_gemm_16c_nt_sel(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, Rl, H, I,
+                                    RUART_ACT_NONE, c_ff2, stream)))
       return rc;
-    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, x16, x8, H, R, H, stream))) return rc;
+    // (the last layer's GEMM-operand copies go to the dead context buffers: x16 / x8 may hold its compacted inputs)
+    if ((rc = ruart_rows_layernorm_split(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, Rl == R ? x16 : ctx16, Rl == R ? x8 : ctx8, H, Rl, H,
+                                         stream)))
+      return rc;
     res = out;
   }
   ruart_prof_real_rows = 0;
@@ -125,28 +166,42 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
                                dt, R, H, stream);
   if (rc) return rc;
 
-  auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act) {
+  auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act, int rows) {
     if (dt != RUART_DT_F32)
-      return ruart_gemm_16_nt(A, K, W, K, bias, res, N, dt, C, N, out_dt, R, N, K, act, dt, stream);
+      return ruart_gemm_16_nt(A, K, W, K, bias, res, N, dt, C, N, out_dt, rows, N, K, act, dt, stream);
     if (m->f32_gemm == 1)                                        // fp32 storage, split-bf16 products (no K split at these sizes)
-      return ruart_gemm_x3((const float*)A, K, 1, (const float*)W, 1, K, bias, (const float*)res, N, act, (float*)C, N, R, N, K,
+      return ruart_gemm_x3((const float*)A, K, 1, (const float*)W, 1, K, bias, (const float*)res, N, act, (float*)C, N, rows, N, K,
                            nullptr, 0, nullptr, nullptr, nullptr, 1, stream);
-    return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, R, N, K, act, stream);
+    return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, rows, N, K, act, stream);
   };
 
   ruart_prof_real_rows = b->n_tokens;
   const void* in = x0;
+  const int n_last = last_layer_rows(m, b);
   for (int l = 0; l < m->n_layers; ++l) {
     void* out = (char*)layers_out + (size_t)l * R * H * es;
-    if ((rc = gemm(in, H, m->w_qkv[l], m->b_qkv[l], nullptr, qkv, dt, 3 * H, RUART_ACT_NONE))) return rc;
+    if ((rc = gemm(in, H, m->w_qkv[l], m->b_qkv[l], nullptr, qkv, dt, 3 * H, RUART_ACT_NONE, R))) return rc;
     if ((rc = ruart_bert_attention(qkv, 3 * H, ctx, H, dt, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
                                    b->tok_lo, b->tok_hi, b->key_bias, b->n_long_blocks, b->lblk_q0, b->lblk_q1, b->lblk_k0, b->lblk_k1, stream)))
       return rc;
-    if ((rc = gemm(ctx, H, m->w_ao[l], m->b_ao[l], in, pre, RUART_DT_F32, H, RUART_ACT_NONE))) return rc;
-    if ((rc = ruart_rows_layernorm(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid, H, dt, R, H, stream))) return rc;
-    if ((rc = gemm(mid, H, m->w_ff1[l], m->b_ff1[l], nullptr, ffn, dt, I, RUART_ACT_GELU))) return rc;
-    if ((rc = gemm(ffn, I, m->w_ff2[l], m->b_ff2[l], mid, pre, RUART_DT_F32, H, RUART_ACT_NONE))) return rc;
-    if ((rc = ruart_rows_layernorm(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, H, dt, R, H, stream))) return rc;
+    // last layer on the pooled rows only (see bert_forward_corr): context -> x0 (dead since layer 0), residual -> the QKV buffer
+    int Rl = R;
+    const void *a = ctx, *res = in;
+    if (n_last > 0 && l == m->n_layers - 1) {
+      const int gran = (R % 256) ? 128 : 256;      // R's own granularity (the 256-row GEMM tile wants 256): n_last < n_tokens <= R, so Rl <= R
+      Rl = (n_last + gran - 1) / gran * gran;
+      if ((rc = ruart_rows_gather(b->last_rows, n_last, ctx, (long long)H * es, x0, (long long)H * es, (int)(H * es), in, (long long)H * es, qkv,
+                                  (long long)H * es, (int)(H * es), nullptr, 0, nullptr, 0, 0, stream)))
+        return rc;
+      a = x0;
+      res = qkv;
+      ruart_prof_real_rows = n_last;
+    }
+    if ((rc = gemm(a, H, m->w_ao[l], m->b_ao[l], res, pre, RUART_DT_F32, H, RUART_ACT_NONE, Rl))) return rc;
+    if ((rc = ruart_rows_layernorm(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid, H, dt, Rl, H, stream))) return rc;
+    if ((rc = gemm(mid, H, m->w_ff1[l], m->b_ff1[l], nullptr, ffn, dt, I, RUART_ACT_GELU, Rl))) return rc;
+    if ((rc = gemm(ffn, I, m->w_ff2[l], m->b_ff2[l], mid, pre, RUART_DT_F32, H, RUART_ACT_NONE, Rl))) return rc;
+    if ((rc = ruart_rows_layernorm(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, H, dt, Rl, H, stream))) return rc;
     in = out;
   }
   ruart_prof_real_rows = 0;

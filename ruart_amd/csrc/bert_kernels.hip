@@ -687,13 +687,15 @@ __global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __re
 #define POOL_LPB 3
 template <typename T, int NG>
 __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
-                                                       const int* __restrict__ span_start, const int* __restrict__ span_len,
+                                                       const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                       const int* __restrict__ span_len,
                                                        const int* __restrict__ dst_row, const float* __restrict__ wl,
                                                        float* __restrict__ out, int ldo, int W, int H) {
   __shared__ __attribute__((aligned(16))) float red[3][NG * 256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = blockIdx.x;
   const int st = span_start[w], n = span_len[w];
+  const int st_last = span_start_last ? span_start_last[w] : st;        // the last layer may be stored compacted (pooled rows only)
   const float inv = 1.0f / (float)n;
   const int per = (NL + 3) >> 2;
   const int l0 = wv * per, l1 = min(NL, l0 + per);
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
     for (int j = 0; j < POOL_LPB; ++j) {
       const int l = min(lb + j, l1 - 1);
       wgt[j] = (lb + j < l1) ? wl[l] * inv : 0.f;
-      const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+      const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
       const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
       for (int i = 0; i < NG; ++i) acc[i] += (v[j][0][i] + v[j][1][i] * two) * wgt[j];
     if (n > 2) {                                        // rare: words of three or more pieces
       for (int j = 0; j < POOL_LPB && lb + j < l1; ++j) {
-        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)st * ldl;
+        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
         for (int p = 2; p < n; ++p)
 #pragma unroll
           for (int i = 0; i < NG; ++i) acc[i] += load4(base + (size_t)p * ldl + col[i]) * wgt[j];
@@ -754,12 +756,14 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
 // d(loss)/d(wl[l]) partial of one word: <grad_out[dst_row[w]], mean of the word's rows of layer l>; partial[w * NL + l].
 template <typename T, int NG>
 __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
-                                                           const int* __restrict__ span_start, const int* __restrict__ span_len,
+                                                           const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                           const int* __restrict__ span_len,
                                                            const int* __restrict__ dst_row, const float* __restrict__ gout, int ldg,
                                                            float* __restrict__ partial, int W, int H) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = blockIdx.x;
   const int st = span_start[w], n = span_len[w];
+  const int st_last = span_start_last ? span_start_last[w] : st;        // the last layer may be stored compacted (pooled rows only)
   const float inv = 1.0f / (float)n;
   const int per = (NL + 3) >> 2;
   const int l0 = wv * per, l1 = min(NL, l0 + per);
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < POOL_LPB; ++j) {
       const int l = min(lb + j, l1 - 1);
-      const T* base = layers + (size_t)l * layer_stride + (size_t)st * ldl;
+      const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
       const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < NG; ++i) s4 += (v[j][0][i] + v[j][1][i] * two) * gv[i];
       if (n > 2 && lb + j < l1) {
-        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)st * ldl;
+        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
         for (int p = 2; p < n; ++p)
 #pragma unroll
           for (int i = 0; i < NG; ++i) s4 += load4(base + (size_t)p * ldl + col[i]) * gv[i];
@@ -929,50 +933,93 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
 }
 
 template <typename T>
-static void launch_pool(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_len,
-                        const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H, hipStream_t st) {
+static void launch_pool(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_start_last,
+                        const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H, hipStream_t st) {
   const dim3 grid(n_words), block(256);
-#define POOL(NG) hipLaunchKernelGGL((pool_mix_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H)
+#define POOL(NG) hipLaunchKernelGGL((pool_mix_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H)
   switch ((H + 255) / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
 #undef POOL
 }
 template <typename T>
-static void launch_pool_bwd(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_len,
-                            const int* dst_row, const float* grad_out, int ldg, float* partial, int n_words, int H, hipStream_t st) {
+static void launch_pool_bwd(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start,
+                            const int* span_start_last, const int* span_len, const int* dst_row, const float* grad_out, int ldg, float* partial, int n_words, int H, hipStream_t st) {
   const dim3 grid(n_words), block(256);
-#define POOL(NG) hipLaunchKernelGGL((pool_mix_bwd_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial, n_words, H)
+#define POOL(NG) hipLaunchKernelGGL((pool_mix_bwd_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial, n_words, H)
   switch ((H + 255) / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
 #undef POOL
 }
 
 extern "C" int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
-                                   const int* span_start, const int* span_len, const int* dst_row, const float* layer_w,
-                                   float* out, int ldo, int n_words, int H, void* stream) {
+                                   const int* span_start, const int* span_start_last, const int* span_len, const int* dst_row,
+                                   const float* layer_w, float* out, int ldo, int n_words, int H, void* stream) {
   RUART_ENTRY();
   if (H % 4 || H < 4 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0) return (int)hipErrorInvalidValue;
   if (dtype == RUART_DT_BF16)
-    launch_pool<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
+    launch_pool<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   else if (dtype == RUART_DT_F16)
-    launch_pool<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
+    launch_pool<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   else
-    launch_pool<float>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
+    launch_pool<float>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int ruart_bert_pool_mix_bwd(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers,
-                                       const int* span_start, const int* span_len, const int* dst_row, const float* grad_out,
-                                       int ldg, float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream) {
+                                       const int* span_start, const int* span_start_last, const int* span_len, const int* dst_row,
+                                       const float* grad_out, int ldg, float* partial_ws, float* grad_layer_w, int n_words, int H,
+                                       void* stream) {
   RUART_ENTRY();
   if (H % 4 || H < 4 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0) return (int)hipErrorInvalidValue;
   if (dtype == RUART_DT_BF16)
-    launch_pool_bwd<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
+    launch_pool_bwd<bf16_t>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   else if (dtype == RUART_DT_F16)
-    launch_pool_bwd<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
+    launch_pool_bwd<f16_t>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   else
-    launch_pool_bwd<float>(layers, layer_stride, ldl, n_layers, span_start, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
+    launch_pool_bwd<float>(layers, layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, partial_ws, n_words, n_layers, grad_layer_w);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst_k[i] = src_k[rows[i]] for up to three byte matrices: one workgroup (256 lanes x 16 B) per output row and matrix slot
+struct GatherArgs {
+  const char* src[3];
+  char* dst[3];
+  long long sp[3], dp[3];
+  int bytes[3];
+};
+__global__ __launch_bounds__(256) void rows_gather_kernel(const int* __restrict__ rows, GatherArgs a) {
+  const int i = blockIdx.x, r = rows[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!a.src[k]) break;
+    const char* s = a.src[k] + (size_t)r * a.sp[k];
+    char* d = a.dst[k] + (size_t)i * a.dp[k];
+    for (int o = threadIdx.x * 16; o < a.bytes[k]; o += 256 * 16) *reinterpret_cast<f32x4_t*>(d + o) = *reinterpret_cast<const f32x4_t*>(s + o);
+  }
+}
+
+extern "C" int ruart_rows_gather(const int* rows, int n, const void* src0, long long sp0, void* dst0, long long dp0, int bytes0, const void* src1,
+                                 long long sp1, void* dst1, long long dp1, int bytes1, const void* src2, long long sp2, void* dst2, long long dp2,
+                                 int bytes2, void* stream) {
+  RUART_ENTRY();
+  if (!rows || n <= 0 || !src0 || !dst0) return (int)hipErrorInvalidValue;
+  GatherArgs a;
+  const void* src[3] = {src0, src1, src2};
+  void* dst[3] = {dst0, dst1, dst2};
+  const long long sp[3] = {sp0, sp1, sp2}, dp[3] = {dp0, dp1, dp2};
+  const int by[3] = {bytes0, bytes1, bytes2};
+  for (int k = 0; k < 3; ++k) {
+    a.src[k] = (const char*)src[k];
+    a.dst[k] = (char*)dst[k];
+    a.sp[k] = sp[k];
+    a.dp[k] = dp[k];
+    a.bytes[k] = by[k];
+    if (src[k] && (!dst[k] || by[k] <= 0 || (by[k] & 15) || (sp[k] & 15) || (dp[k] & 15) || ((uintptr_t)src[k] & 15) || ((uintptr_t)dst[k] & 15)))
+      return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(rows_gather_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, rows, a);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
                                                             const char* __restrict__ W16, const char* __restrict__ W8, int pitch_w,
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             void* __restrict__ C, int ldc, unsigned char* __restrict__ C8, int M, int N,
-                                                            int K, int order) {
+                                                            int K, int order, int n8, int o8) {
   constexpr int kHalf = 128 * CBKB;              // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -86,7 +86,10 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
     tn = r / gsz;
   }
   const int m0 = tm * CBM, n0 = tn * CBN;
-  const int nt = K / 64;                         // K-tiles of the f16 phase == K-tiles of the fp8 phase (2K bytes per row)
+  const int nt = K / 64;                         // K-tiles of the f16 phase; the full fp8 phase has as many (2K bytes per row)
+  // n8 fp8 K-tiles starting at fp8 tile o8: (nt, 0) = both correction products (production); (nt / 2, 0) = a_lo . w_hi only,
+  // (nt / 2, nt / 2) = a_hi . w_lo only, (0, 0) = none - the ablation forms of ruart_gemm_16c_nt_sel
+  const int NT = nt + n8;
 
   // staging: wave w fills local rows 16w .. 16w+15 of a half-tile (two 1 KB pieces of 8 rows x 128 B, lane-linear); the XOR
   // swizzle sits on the SOURCE chunk.  Rows of A8 / W8 have the pitch of A16 / W16, so one per-lane offset serves both phases.
@@ -98,13 +101,13 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
   char* const st_base = smem + wave * 2048;
   auto stage_a = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + h * kHalf;
-    const char* src = (kt < nt ? A16 + (size_t)kt * CBKB : A8 + (size_t)(kt - nt) * CBKB) + a_row0 + h * a_h;
+    const char* src = (kt < nt ? A16 + (size_t)kt * CBKB : A8 + (size_t)(kt - nt + o8) * CBKB) + a_row0 + h * a_h;
     dma16(src, a_lane, dst);
     dma16(src + a8r, a_lane, dst + 1024);
   };
   auto stage_w = [&](int d, int h, int kt) {
     char* dst = st_base + d * kBuf + kOper + h * kHalf;
-    const char* src = (kt < nt ? W16 + (size_t)kt * CBKB : W8 + (size_t)(kt - nt) * CBKB) + w_row0 + h * w_h;
+    const char* src = (kt < nt ? W16 + (size_t)kt * CBKB : W8 + (size_t)(kt - nt + o8) * CBKB) + w_row0 + h * w_h;
     dma16(src, w_lane, dst);
     dma16(src + w8r, w_lane, dst + 1024);
   };
@@ -211,16 +214,25 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
   RUART_BAR();
   if (wave >= 4) RUART_BAR();                                 // stagger: waves 4-7 run one barrier behind
   int t = 0;
-  for (; t < nt; t += 2) {                                    // f16 phase (nt is even; its tiles always have two successors)
-    tile(Ff{}, I0{}, Tt{}, Tt{}, t);
-    tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
+  if (n8 > 0) {
+    for (; t < nt; t += 2) {                                  // f16 phase (nt is even; its tiles always have two successors)
+      tile(Ff{}, I0{}, Tt{}, Tt{}, t);
+      tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
+    }
+    for (; t + 2 < NT; t += 2) {                              // fp8 phase
+      tile(Tt{}, I0{}, Tt{}, Tt{}, t);
+      tile(Tt{}, I1{}, Tt{}, Tt{}, t + 1);
+    }
+    tile(Tt{}, I0{}, Tt{}, Ff{}, t);
+    tile(Tt{}, I1{}, Ff{}, Ff{}, t + 1);
+  } else {                                                    // no correction at all (ablation): the f16 phase ends the K loop
+    for (; t + 2 < nt; t += 2) {
+      tile(Ff{}, I0{}, Tt{}, Tt{}, t);
+      tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
+    }
+    tile(Ff{}, I0{}, Tt{}, Ff{}, t);
+    tile(Ff{}, I1{}, Ff{}, Ff{}, t + 1);
   }
-  for (; t + 2 < 2 * nt; t += 2) {                            // fp8 phase
-    tile(Tt{}, I0{}, Tt{}, Tt{}, t);
-    tile(Tt{}, I1{}, Tt{}, Tt{}, t + 1);
-  }
-  tile(Tt{}, I0{}, Tt{}, Ff{}, t);
-  tile(Tt{}, I1{}, Ff{}, Ff{}, t + 1);
   if (wave < 4) RUART_BAR();                                  // waves 0-3 pair the lagging group's last barrier
   RUART_BAR();                                                // every wave is done reading operand tiles
 
@@ -268,19 +280,22 @@ void ruart_prof_end_(void* rec, hipStream_t s);
 
 template <int EPI>
 static void launch_corr(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
-                        const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, hipStream_t s) {
+                        const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int corr, hipStream_t s) {
   constexpr int lds = 2 * 2 * CBM * CBKB;                // 128 KB
+  const int nt = K / 64;
+  const int n8 = corr == 3 ? nt : (corr ? nt / 2 : 0), o8 = corr == 2 ? nt / 2 : 0;
   auto kern = gemm_16c_nt_256p8<EPI>;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3((M / CBM) * (N / CBN)), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
-                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, g_tile_order);
+                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, g_tile_order, n8, o8);
 }
 
-extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
-                                 const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act,
-                                 void* stream) {
+extern "C" int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                                     const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr,
+                                     void* stream) {
   RUART_ENTRY();
+  if (corr < 0 || corr > 3 || ((corr == 1 || corr == 2) && K % 256)) return (int)hipErrorInvalidValue;
   if (M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
   if (!A16 || !A8 || !W16 || !W8 || !C) return (int)hipErrorInvalidValue;
   // every argument check sits in front of ruart_prof_begin_: an error return never leaves a profiling event open
@@ -294,12 +309,18 @@ extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const
   hipStream_t s = (hipStream_t)stream;
   void* rec = ruart_prof_begin_(s, M, N, K);
   if (act == RUART_ACT_GELU)
-    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, s);
+    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, corr, s);
   else if (residual)
-    launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, s);
+    launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, corr, s);
   else
-    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, s);
+    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, corr, s);
   ruart_prof_end_(rec, s);
   RUART_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                                 const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act,
+                                 void* stream) {
+  return ruart_gemm_16c_nt_sel(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, C8, M, N, K, act, 3, stream);
 }

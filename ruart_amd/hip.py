@@ -44,7 +44,8 @@ class BertBatchC(Structure):
     _fields_ = [("n_tokens", c_int), ("n_rows", c_int), ("ids", c_void_p), ("pos_ids", c_void_p), ("n_blocks", c_int),
                 ("blk_q0", c_void_p), ("blk_q1", c_void_p), ("blk_k0", c_void_p), ("blk_k1", c_void_p),
                 ("tok_lo", c_void_p), ("tok_hi", c_void_p), ("key_bias", c_void_p),
-                ("n_long_blocks", c_int), ("lblk_q0", c_void_p), ("lblk_q1", c_void_p), ("lblk_k0", c_void_p), ("lblk_k1", c_void_p)]
+                ("n_long_blocks", c_int), ("lblk_q0", c_void_p), ("lblk_q1", c_void_p), ("lblk_k0", c_void_p), ("lblk_k1", c_void_p),
+                ("n_last_rows", c_int), ("last_rows", c_void_p)]
 
 
 _P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
@@ -52,6 +53,8 @@ _SIGNATURES = {
     "ruart_version": (c_char_p, []),
     "ruart_gemm_16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16c_nt": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16c_nt_sel": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_bert_set_correction": (_I, [_I, _I, _I, _I, ctypes.c_ulonglong]),
     "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_embed_ln_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_attention_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -80,8 +83,9 @@ _SIGNATURES = {
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
-    "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "ruart_rows_gather": (_I, [_P, _I, _P, _LL, _P, _LL, _I, _P, _LL, _P, _LL, _I, _P, _LL, _P, _LL, _I, _P]),
     "ruart_cast_f32_to_16": (_I, [_P, _P, _I, _LL, _F, _P]),
     "ruart_bert_workspace_bytes": (c_size_t, [POINTER(BertModelC), _I]),
     "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),

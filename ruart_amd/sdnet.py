@@ -264,7 +264,8 @@ class SDNet(nn.Module):
         bi = q_list.get("_ruart_index")
         if bi is None or bi.device != self.device:
             host = q_list.get("_ruart_host_index")          # built by VQA_collate(prepare_index=True) in a loader worker
-            want = (self.Bert.pack, self.Bert.weights.dtype != 0)
+            frozen = "LOCK_BERT" in self.opt and not self.opt.get("bert_frozen_dropout")
+            want = (self.Bert.pack, self.Bert.weights.dtype != 0, bool(frozen and self.opt.get("bert_dedup", True) and self.Bert.pack))
             if host is not None and getattr(host, "plan", None) == want:
                 bi = host.to(self.device)
             else:
@@ -413,10 +414,10 @@ class SDNet(nn.Module):
             mixed = None
 
         def pooled(g):
-            s_, l_, dst, rows = bi.spans[g]
+            s_, l_, dst, rows, s_last = bi.spans[g]
             if trainable:
                 return bert_train.pool_words(mixed, s_, l_, dst, rows)
-            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers))
+            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last)
 
         def front(items, idx, mix):
             words, raw = self._embed_items(items, idx, mix)

@@ -676,3 +676,38 @@ def test_three_optimizer_steps_vs_reference_update(golden_dir, precision, tol_l,
         frac_off = float((np.abs(got - z[k]) > 2.05 * lr).mean())
         assert frac_off <= (0.0 if precision == "fp32" else 0.02), (k, frac_off, float(np.abs(got - z[k]).max()))
     print("update parity %s: losses %s, worst update-norm rel err %.2e (%s)" % (precision, losses, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize("precision", ["fp16c", "fp16", "x3"])
+def test_last_layer_rows_and_dedup_are_result_neutral(golden, precision):
+    """Frozen encoder: (1) computing the last layer only on the rows word spans pool (the [CLS] / [SEP] rows are never read,
+    Models/Bert/Bert.py:153-165) changes no bit of the scores or of the alpha / gamma gradients; (2) encoding identical item
+    sequences once leaves every probability within fp32 rounding (the sequences land at other offsets of their 64-token attention
+    windows, which reorders exact-zero terms inside the MFMA sums)."""
+    import ruart_amd.layers as L
+    z = golden
+    outs = {}
+    for tag, extra in (("all", dict(bert_dedup=False, bert_last_rows=False)), ("last", dict(bert_dedup=False)), ("both", {})):
+        net, opt = build(z, precision, **extra)
+        q, ocr, od, gt, _ = synth.synthetic_batch(opt, int(z["B"]), seed=int(z["batch_seed"]), n_q=30, n_ocr=100, n_od=30,
+                                                  bert_vocab=2000, ragged=True)
+        for items in (ocr, od):                      # real data spells every sentinel item the same way: make it so here
+            sent = np.cumsum(items["num_cnt"]) - 1
+            for r in sent[1:]:
+                items["bert"][r] = items["bert"][sent[0]]
+                items["bert_mask"][r] = items["bert_mask"][sent[0]]
+                items["bert_offsets"][r] = items["bert_offsets"][sent[0]]
+        L.set_dropout_prob(0.0)
+        net.train()
+        net.drop_emb = False
+        scores, _ = net(q, ocr, od)
+        gt = gt.to(scores.device)
+        (torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)).backward()
+        bi = q["_ruart_index"]
+        outs[tag] = (scores.detach().clone(), net.alphaBERT.grad.clone(), net.gammaBERT.grad.clone(), bi.packed.T, bi._n_last)
+        net.Bert.close()
+    assert outs["all"][4] == 0 and 0 < outs["last"][4] < outs["last"][3] and outs["both"][3] < outs["last"][3]
+    for k in range(3):
+        assert torch.equal(outs["all"][k], outs["last"][k]), k
+    assert float((outs["both"][0] - outs["all"][0]).abs().max()) < 2e-6
+    assert torch.allclose(outs["both"][1], outs["all"][1], rtol=1e-3, atol=1e-7)

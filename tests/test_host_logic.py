@@ -225,8 +225,11 @@ def test_collate_can_prepare_the_batch_index_in_a_worker():
     q2, ocr2, od2, _, _ = VQA_collate(opt).VQA_collate_fun(samples)
     ref = BatchIndex(q2, ocr2, od2, opt)
     # default precision fp16c: fp32 QKV rows, 64-query split-f16 attention blocks (the MFMA long-sequence plan is the plain 16-bit modes')
-    assert host.plan == ref.plan == (True, False)
-    assert BatchIndex(q2, ocr2, od2, dict(opt, bert_precision="fp16")).plan == (True, True)
+    # (third entry: frozen encoder -> identical sequences are encoded once)
+    assert host.plan == ref.plan == (True, False, True)
+    assert BatchIndex(q2, ocr2, od2, dict(opt, bert_precision="fp16")).plan == (True, True, True)
+    unlocked = {k: v for k, v in opt.items() if k != "LOCK_BERT"}
+    assert BatchIndex(q2, ocr2, od2, unlocked).plan == (True, False, False)     # trainable encoder: every sequence keeps its own rows
     assert np.array_equal(host.packed.host, ref.packed.host) and host.packed.T == ref.packed.T
     assert np.array_equal(host._spans_host[0], ref._spans_host[0]) and host._spans_host[1] == ref._spans_host[1]
     for a, b in ((host.ocr, ref.ocr), (host.od, ref.od)):
@@ -235,6 +238,62 @@ def test_collate_can_prepare_the_batch_index_in_a_worker():
         assert a.n_active == b.n_active and np.array_equal(a.mask, b.mask)
     dev = host.to("cpu")                                            # binding works on any torch device
     assert dev.packed.ids.numel() == dev.packed.Tp and len(dev.spans) == 3 and dev.ocr.dev["flat_word"].dtype == torch.int64
+
+
+def test_packed_tokens_dedup_and_last_layer_rows():
+    """Frozen encoder: identical sequences of a group are packed once (duplicates point at the first occurrence's rows), and the rows
+    the last layer must produce are exactly the rows inside word spans, with span starts remapped to the compacted order."""
+    from ruart_amd.batch import BatchIndex
+    from ruart_amd.bert import PackedTokens
+    ids = np.array([[101, 7, 8, 102, 0, 0],
+                    [101, 9, 102, 0, 0, 0],
+                    [101, 7, 8, 102, 0, 0],      # duplicate of row 0
+                    [101, 9, 102, 0, 0, 0],      # duplicate of row 1
+                    [101, 7, 102, 0, 0, 0]], dtype=np.int64)
+    g = [(torch.from_numpy(ids), torch.from_numpy(ids != 0))]
+    plain, dd = PackedTokens(g, "cpu"), PackedTokens(g, "cpu", dedup=True)
+    assert plain.T == 4 + 3 + 4 + 3 + 3 and dd.T == 4 + 3 + 3 and dd.n_seq == 3
+    gi = dd.group_index[0]
+    assert np.array_equal(gi[2], gi[0]) and np.array_equal(gi[3], gi[1]) and gi[0, 0] == 0 and gi[1, 0] == 4 and gi[4, 0] == 7
+    assert np.array_equal(dd.host[:dd.T], [101, 7, 8, 102, 101, 9, 102, 101, 7, 102])
+    assert np.array_equal(dd.host[dd.Tp:dd.Tp + dd.T], [0, 1, 2, 3, 0, 1, 2, 0, 1, 2])        # positions restart per sequence
+    same = PackedTokens([(torch.from_numpy(ids[[0, 1, 4]]), torch.from_numpy(ids[[0, 1, 4]] != 0))], "cpu", dedup=True)
+    assert np.array_equal(same.host[:same.T], dd.host[:dd.T])                                  # no duplicates: nothing changes
+    # through BatchIndex: the sentinel items of a synthetic batch are duplicates; [CLS] / [SEP] rows are not in last_rows
+    opt = default_opt()
+    samples = _samples_like_generator(opt, 3, 5)
+    q, ocr, od, _, _ = VQA_collate(opt).VQA_collate_fun(samples)
+    bi = BatchIndex(q, ocr, od, opt)
+    off = BatchIndex(q, ocr, od, dict(opt, bert_dedup=False, bert_last_rows=False))
+    assert bi.packed.T <= off.packed.T and off._n_last == 0
+    from ruart_amd import synth
+    sq, socr, sod, _, _ = synth.synthetic_batch(opt, 4, seed=5, n_q=8, n_ocr=12, n_od=5, bert_vocab=2000)
+    # (the generator spells its <OCR> sentinel items with random pieces; real data tokenizes them identically: make them so)
+    sent = np.cumsum(socr["num_cnt"]) - 1
+    for r in sent[1:]:
+        socr["bert"][r] = socr["bert"][sent[0]]
+        socr["bert_mask"][r] = socr["bert_mask"][sent[0]]
+        socr["bert_offsets"][r] = socr["bert_offsets"][sent[0]]
+    a, b = BatchIndex(sq, socr, sod, opt), BatchIndex(sq, socr, sod, dict(opt, bert_dedup=False))
+    assert a.packed.n_seq == b.packed.n_seq - (4 - 1) and a.packed.T < b.packed.T
+    W = [n for n, _ in bi._spans_host[1]]
+    flat = bi._spans_host[0]
+    o, covered = 0, np.zeros(bi.packed.T, dtype=bool)
+    starts, lasts = [], []
+    for w in W:
+        s_, l_, ls = flat[o:o + w], flat[o + w:o + 2 * w], flat[o + 3 * w:o + 4 * w]
+        for a, n in zip(s_, l_):
+            covered[a:a + n] = True
+        starts.append(s_)
+        lasts.append(ls)
+        o += 4 * w
+    rows = flat[o:]
+    assert bi._n_last == len(rows) == covered.sum() and np.array_equal(rows, np.nonzero(covered)[0])
+    pieces = bi.packed.host[:bi.packed.T]
+    # [CLS] = 101 / [SEP] = 102 are never pooled (pieces of words past an item's len_cnt are not pooled either)
+    assert not np.isin(pieces[rows], (101, 102)).any() and np.isin(pieces, (101, 102))[~covered].sum() == np.isin(pieces, (101, 102)).sum()
+    for s_, ls in zip(starts, lasts):
+        assert np.array_equal(rows[ls], s_)                        # compacted row ls holds packed row s_
 
 
 def _dataset_fixture(golden_dir, tmp_path):

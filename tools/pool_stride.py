@@ -25,7 +25,7 @@ for pad in (0, 512, 2048, 2048 + 64, 8192 + 2048, 65536 + 2048):
     stride = Tp * H + pad
     buf = torch.randn(NL * stride, device=d).to(torch.float16)
     def run():
-        rc = lib.ruart_bert_pool_mix(hip.ptr(buf), stride, H, hip.DT_F16, NL, hip.ptr(ss), hip.ptr(ll), hip.ptr(dst), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
+        rc = lib.ruart_bert_pool_mix(hip.ptr(buf), stride, H, hip.DT_F16, NL, hip.ptr(ss), None, hip.ptr(ll), hip.ptr(dst), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
         assert rc == 0
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
