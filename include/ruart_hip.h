@@ -45,9 +45,9 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
                      int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
                      void* stream);
 /* The same projections in the "f16 + fp8 correction" precision mode (csrc/gemm_corr.hip):
- *   C = act(A16 . W16^T + 2^-20 * A8 . W8^T + bias) [+ residual]
- * A16 (M, K) f16 and A8 (M, 2K) e4m3 bytes with the SAME row pitch in bytes (2 * lda): A8 row = [fp8((a - f16(a)) * 2^13), K bytes |
- * fp8(a * 2^2), K bytes]; W16 (N, K) f16 and W8 (N, 2K) likewise with [fp8(f16(w) * 2^7) | fp8((w - f16(w)) * 2^18)].  The fp8 part
+ *   C = act(A16 . W16^T + 2^-18 * A8 . W8^T + bias) [+ residual]
+ * A16 (M, K) f16 and A8 (M, 2K) e4m3 bytes with the SAME row pitch in bytes (2 * lda): A8 row = [fp8((a - f16(a)) * 2^11), K bytes |
+ * fp8(a), K bytes]; W16 (N, K) f16 and W8 (N, 2K) likewise with [fp8(f16(w) * 2^7) | fp8((w - f16(w)) * 2^18)].  The fp8 part
  * runs on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the f16 MFMA rate) into the same fp32 accumulators, so the product carries
  * ~2^-16 relative operand error instead of the 2^-12 of a plain f16 product, at 2x (not 3x) the matrix time.
  *   act NONE: C (M, N) fp32, optional fp32 residual (row stride ldr), C8 must be NULL;
@@ -55,6 +55,9 @@ int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float
  * M % 256 == 0, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                       const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, void* stream);
+/* out4 = {SA_LO, SA_HI, SW_HI, SW_LO}: the power-of-two exponents of the e4m3 companions described above, as compiled into this library
+ * (activation residual, activation value, weight value, weight residual); 2^-(SA_LO + SW_HI) is the scale of the fp8 product. */
+int ruart_f16c_shifts(int* out4);
 /* The same product with a chosen subset of the correction terms (same sites; the ablation of tools/corr_ablation.py): corr 3 = both
  * (== ruart_gemm_16c_nt), 1 = only a_lo . w_hi (the activation's rounding residual), 2 = only a_hi . w_lo (the weight's), 0 = none
  * (a plain f16 product through this kernel).  corr 1 / 2 need K % 256 == 0. */

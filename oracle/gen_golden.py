@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_full | e2e_full_ragged | e2e_stress | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_full | e2e_full_ragged | e2e_stress | e2e_outliers | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -390,6 +390,44 @@ def gen_e2e_full(which="bench"):
     _grad_summary(net, arrays)
     arrays["grad:fast_embed.weight[:64]"] = net.fast_embed.weight.grad[:64].numpy().copy()
     save(name, **arrays)
+
+
+def gen_e2e_outliers():
+    """The UNMODIFIED reference on encoder weights with pretrained-like heavy tails (synth.add_bert_outliers: a few LayerNorm gains
+    x 10-30 in the same hidden dimensions of every layer, a few word-embedding columns x 20, projection weights N(0, 0.04)): B = 2 at
+    the shipped item counts, ragged.  Pins the fp16c mode outside the range its constant e4m3 scales were chosen on
+    (Models/Bert/modeling.py:155-168, 445-531: real checkpoints look like this) -> sdnet_e2e_outliers.npz."""
+    import time
+    opt = default_opt(vocab_size=1500, max_od_num=36)
+    bert_cfg, seed, bseed, w_std, oseed = synth.bert_config(vocab_size=2000), 1033, 53, 0.04, 77
+    from Models.SDNet import SDNet
+    import Models.Layers as L
+    bw = synth.add_bert_outliers(synth.make_bert_weights(bert_cfg, seed=seed, w_std=w_std), bert_cfg, seed=oseed)
+    opt = dict(opt)
+    opt["BERT_model_file"] = _refshim.write_bert_dir(bert_cfg, bw)
+    opt["datadir"] = ""
+    sw = synth.make_sdnet_weights(opt, seed=seed)
+    emb = {"glove_embedding": T(sw["glove_embed.weight"]).clone(), "fast_embedding": T(sw["fast_embed.weight"]).clone()}
+    net = SDNet(opt, emb)
+    missing, unexpected = net.load_state_dict({k: T(v) for k, v in sw.items()}, strict=False)
+    assert not unexpected and all(k.startswith("Bert.") for k in missing), (missing, unexpected)
+    B = 2
+    q, ocr, od, gt, _ = synth.synthetic_batch(opt, B, seed=bseed, n_q=30, n_ocr=100, n_od=36, bert_vocab=2000, ragged=True)
+    # how far out the activations are: the encoder's own layer outputs on this batch
+    with torch.no_grad():
+        net.Bert.bert_model.eval()
+        layers, _ = net.Bert.bert_model(ocr["bert"], token_type_ids=None, attention_mask=ocr["bert_mask"].long())
+        amax = [float(x.abs().max()) for x in layers]
+    print("outliers: max |layer output| per layer:", ["%.1f" % a for a in amax])
+    t0 = time.perf_counter()
+    scores, loss = _run_reference_step(net, L, q, ocr, od, gt)
+    print("sdnet_e2e_outliers: reference fwd+bwd took %.1f s; loss %.6f" % (time.perf_counter() - t0, loss.item()))
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(bseed), B=np.array(B), vocab_size=np.array(1500), bert_vocab=np.array(2000),
+                  w_std=np.array(w_std), outlier_seed=np.array(oseed), layer_absmax=np.array(amax), bert_wsum=checksum(bw),
+                  sdnet_wsum=checksum(sw), scores=scores.detach().numpy(), loss=np.array(loss.item()),
+                  ocr_num_cnt=np.array(ocr["num_cnt"]), od_num_cnt=np.array(od["num_cnt"]))
+    _grad_summary(net, arrays)
+    save("sdnet_e2e_outliers", **arrays)
 
 
 def gen_e2e_stress():
@@ -835,6 +873,8 @@ if __name__ == "__main__":
         gen_e2e_full("ragged")
     if "e2e_stress" in which:
         gen_e2e_stress()
+    if "e2e_outliers" in which:
+        gen_e2e_outliers()
     if "e2e_phoc" in which:
         gen_e2e_phoc()
     if "e2e_unlocked" in which:

@@ -33,12 +33,15 @@ def _np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
-def split_f16c(x, lo_shift=13, hi_shift=2):
+def split_f16c(x, lo_shift=None, hi_shift=None):
     """fp32 (M, K) -> (f16 (M, K), uint8 (M, 2K)): the "f16 + fp8 correction" operand form of ruart_gemm_16c_nt (csrc/common.h):
     row of the second = [e4m3((x - f16(x)) 2^lo_shift) | e4m3(x 2^hi_shift)].  Weights use shifts (18, 7) and the halves swapped."""
     hi = x.to(torch.float16)
     lo = x - hi.to(torch.float32)
-    pair = torch.cat([lo * float(1 << lo_shift), x * float(1 << hi_shift)], 1).clamp_(-448.0, 448.0)
+    sa_lo, sa_hi, _, _ = hip.f16c_shifts()
+    lo_shift = sa_lo if lo_shift is None else lo_shift
+    hi_shift = sa_hi if hi_shift is None else hi_shift
+    pair = torch.cat([lo * float(2.0 ** lo_shift), x * float(2.0 ** hi_shift)], 1).clamp_(-448.0, 448.0)
     return hi.contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
 
@@ -69,7 +72,8 @@ class BertEncoderWeights:
             """(out, 2 in) e4m3 companion of a weight matrix: [fp8(f16(w) 2^7) | fp8((w - f16(w)) 2^18)] (common.h)."""
             hi = t.to(torch.float16).to(torch.float32)
             self._w_absmax = max(getattr(self, "_w_absmax", 0.0), float(t.abs().max()))      # load time: one sync per matrix
-            pair = torch.cat([hi * float(1 << 7), (t - hi) * float(1 << 18)], 1).clamp_(-448.0, 448.0)
+            _, _, sw_hi, sw_lo = hip.f16c_shifts()
+            pair = torch.cat([hi * float(2.0 ** sw_hi), (t - hi) * float(2.0 ** sw_lo)], 1).clamp_(-448.0, 448.0)
             return pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
         e = "embeddings."

@@ -112,15 +112,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- "f16 + fp8 correction" storage (RUART_DT_F16C): a value v travels as  hi = f16(v)  plus two e4m3 bytes
 //   lo8 = fp8((v - hi) * 2^SA_LO)   and   hi8 = fp8(v * 2^SA_HI)
-// so that a GEMM can take  v.w  as  hi.w_hi (f16 MFMA)  +  2^-20 (lo8.w_hi8 + hi8.w_lo8) (block-scaled fp8 MFMA, twice the
+// so that a GEMM can take  v.w  as  hi.w_hi (f16 MFMA)  +  2^-SHIFT (lo8.w_hi8 + hi8.w_lo8) (block-scaled fp8 MFMA, twice the
 // f16 rate), with w_hi8 = fp8(w_hi * 2^SW_HI), w_lo8 = fp8((w - w_hi) * 2^SW_LO) prepared once per weight matrix.
-// Exponents: SA_LO + SW_HI == SA_HI + SW_LO == RUART_C8_SHIFT.  Ranges: |v| < 112 and |w| < 3.5 stay below e4m3's 448 (larger
-// values saturate - in a correction term only); the f16 rounding residual of |v| >= 2^-8 stays a normal e4m3 number.
-#define RUART_C8_SA_LO 13
-#define RUART_C8_SA_HI 2
+// Exponents: SA_LO + SW_HI == SA_HI + SW_LO == RUART_C8_SHIFT.  Ranges: |v| < 448 and |w| < 3.5 stay below e4m3's 448 (larger
+// values saturate - in a correction term only); the f16 rounding residual of |v| >= 2^-6 stays a normal e4m3 number (smaller
+// activations carry a subnormal, 1-2 bit residual: their products are negligible next to the row's typical |v| ~ 1).
+// Round 3: (SA_LO, SA_HI) moved from (13, 2) - range 112 - to (11, 0): encoder weights with the heavy tails of a pretrained BERT
+// (a few LayerNorm gains x 10-30: layer outputs up to |v| ~ 450, tests/golden/sdnet_e2e_outliers.npz) saturated both activation
+// companions and the probabilities were off by 1.85e-3; with the wider range that fixture holds 1.6e-4 and the N(0, s) goldens are
+// unchanged to within their noise (bench B = 64: 3.9e-5, ragged: 3.3e-4, stress: 1.4e-5).
+#ifndef RUART_C8_SA_LO
+#define RUART_C8_SA_LO 11
+#endif
+#ifndef RUART_C8_SA_HI
+#define RUART_C8_SA_HI 0
+#endif
 #define RUART_C8_SW_HI 7
-#define RUART_C8_SW_LO 18
-#define RUART_C8_SHIFT 20
+#define RUART_C8_SW_LO (RUART_C8_SA_LO + RUART_C8_SW_HI - RUART_C8_SA_HI)
+#define RUART_C8_SHIFT (RUART_C8_SA_LO + RUART_C8_SW_HI)
+static_assert(RUART_C8_SA_LO + RUART_C8_SW_HI == RUART_C8_SA_HI + RUART_C8_SW_LO, "both correction products share one scale");
 
 __device__ __forceinline__ unsigned pack_fp8x4(f32x4_t v, float scale) {
   f32x4_t s;

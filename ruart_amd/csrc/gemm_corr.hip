@@ -1,6 +1,6 @@
 // Dense projections of the encoder in the "f16 + fp8 correction" precision mode (RUART_DT_F16C, common.h):
 //
-//   C[M,N] = epilogue( A . W^T + bias ) [+ residual]      with      A . W^T  ~=  A16 . W16^T  +  2^-20 * A8 . W8^T
+//   C[M,N] = epilogue( A . W^T + bias ) [+ residual]      with      A . W^T  ~=  A16 . W16^T  +  2^-18 * A8 . W8^T
 //
 // Replaces the same nn.Linear sites as gemm.hip (Models/Bert/modeling.py:225-227, 261, 287-288, 300) when the answer scores have
 // to stay within 1e-3 of the fp32 reference on every output: a plain 16-bit product carries ~2^-12 relative operand rounding, the
@@ -8,13 +8,13 @@
 // both operands are multiplied too - not with two more 16-bit products (the split-bf16 "x3" form, 3x the MFMA time) but on the
 // block-scaled fp8 matrix instruction of CDNA4, which runs at TWICE the f16 rate:
 //     A16 = f16(A)                        W16 = f16(W)                                      k = 0 .. K-1      v_mfma_f32_16x16x32_f16
-//     A8  = [ e4m3((A-A16) 2^13) | e4m3(A 2^2) ]     W8 = [ e4m3(W16 2^7) | e4m3((W-W16) 2^18) ]     k' = 0 .. 2K-1
-//                                                                                 v_mfma_scale_f32_16x16x128_f8f6f4, scale 2^-20
+//     A8  = [ e4m3((A-A16) 2^11) | e4m3(A) ]         W8 = [ e4m3(W16 2^7) | e4m3((W-W16) 2^18) ]     k' = 0 .. 2K-1
+//                                                                                 v_mfma_scale_f32_16x16x128_f8f6f4, scale 2^-18
 // A correction term needs ~5 significant bits (it is 2^-11 of the product), which e4m3 has; the dropped lo.lo term is 2^-22.
 // One byte of A8 / W8 per K element and per half, so a row of A8 is exactly as long as a row of A16 (2K bytes): the fp8 phase is
 // the SAME loop over 128-byte-per-row K-tiles - same LDS image, swizzle, staging and fragment reads as the f16 phase - with the
 // base pointers switched and one 16x16x128 MFMA (32 cycles) where the f16 phase issues two 16x16x32 (16 cycles each).  The
-// accumulators are shared: the scaled MFMA adds 2^-20 * (a8 . w8) straight into the fp32 sums.
+// accumulators are shared: the scaled MFMA adds 2^-18 * (a8 . w8) straight into the fp32 sums.
 //
 // Schedule: gemm_16_nt_256p8's (256x256 tile, 8 waves, four phases per K-tile, LDS-DMA prefetch in flight across raw barriers,
 // counted vmcnt, staggered wave groups) over 2 K/64 K-tiles.  Epilogues: fp32 out (QKV), fp32 out + fp32 residual (attention
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
 #pragma unroll
     for (int i = 0; i < 2; ++i) wf[i] = frag(sw, wn * 32 + i * 16 + fr);
   };
-  const int scale_w = 0x01010101 * (127 - RUART_C8_SHIFT), scale_a = 0x7f7f7f7f;     // E8M0: 2^-20 and 2^0
+  const int scale_w = 0x01010101 * (127 - RUART_C8_SHIFT), scale_a = 0x7f7f7f7f;     // E8M0: 2^-RUART_C8_SHIFT (2^-18) and 2^0
   auto quad = [&](auto f8tag, int hc, int hr, i32x8_t (&wf)[2]) {
     constexpr bool F8 = decltype(f8tag)::value;
     __builtin_amdgcn_s_setprio(1);
@@ -323,4 +323,15 @@ extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const
                                  const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act,
                                  void* stream) {
   return ruart_gemm_16c_nt_sel(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, C8, M, N, K, act, 3, stream);
+}
+
+// the power-of-two exponents of the e4m3 companions this library was built with (common.h): {SA_LO, SA_HI, SW_HI, SW_LO} - the host side
+// prepares weights (and tests prepare operands) with exactly these
+extern "C" int ruart_f16c_shifts(int* out4) {
+  if (!out4) return (int)hipErrorInvalidValue;
+  out4[0] = RUART_C8_SA_LO;
+  out4[1] = RUART_C8_SA_HI;
+  out4[2] = RUART_C8_SW_HI;
+  out4[3] = RUART_C8_SW_LO;
+  return 0;
 }

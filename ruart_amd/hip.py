@@ -54,6 +54,7 @@ _SIGNATURES = {
     "ruart_gemm_16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16c_nt": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ruart_gemm_16c_nt_sel": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_f16c_shifts": (_I, [POINTER(c_int)]),
     "ruart_bert_set_correction": (_I, [_I, _I, _I, _I, ctypes.c_ulonglong]),
     "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_embed_ln_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
@@ -173,6 +174,13 @@ def dtype_code(t):
 
 def ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def f16c_shifts():
+    """(SA_LO, SA_HI, SW_HI, SW_LO): the exponents of the fp16c mode's e4m3 companions as compiled into the library (csrc/common.h)."""
+    out = (c_int * 4)()
+    check(load().ruart_f16c_shifts(out), "ruart_f16c_shifts")
+    return tuple(int(v) for v in out)
 
 
 def require_gpu(t, dtype=None):

@@ -63,6 +63,23 @@ def make_bert_weights(cfg, seed=1033, w_std=0.05):
     return w
 
 
+def add_bert_outliers(w, cfg, seed=77, n_dims=4, gain=(10.0, 30.0), emb_scale=20.0, n_emb_dims=3):
+    """Give seeded random encoder weights the heavy tails a PRETRAINED BERT has and N(0, s) weights lack (in place, deterministic):
+    a few hidden dimensions - the same ones in every LayerNorm, as in the published checkpoints, where a handful of dimensions carry
+    activations an order of magnitude above the rest - get their gain multiplied by U(gain), and a few columns of the word-embedding
+    table are scaled by ``emb_scale``.  Used by the fp16c range test (tests/golden/sdnet_e2e_outliers.npz): LayerNorm outputs of
+    30-100 and embedding entries of ~1 push the e4m3 correction operands (csrc/common.h: |v| < 112, |w| < 3.5) to their limits."""
+    g = np.random.default_rng(seed)
+    H = cfg["hidden_size"]
+    dims = g.choice(H, size=n_dims, replace=False)
+    for name in sorted(w):
+        if name.endswith("LayerNorm.gamma"):
+            w[name][dims] *= g.uniform(gain[0], gain[1], size=n_dims).astype(np.float32)
+    edims = g.choice(H, size=n_emb_dims, replace=False)
+    w["bert.embeddings.word_embeddings.weight"][:, edims] *= np.float32(emb_scale)
+    return w
+
+
 # --------------------------------------------------------------------------------------
 # SDNet parameter table (names and shapes follow the reference constructor,
 # Models/SDNet.py:21-251 and Models/Layers.py; verified against the instantiated

@@ -70,7 +70,8 @@ def test_gemm_16(M, N, K, mode, dt):
 
 def _w8(W):
     hi = W.to(torch.float16).float()
-    pair = torch.cat([hi * 128.0, (W - hi) * float(1 << 18)], 1).clamp_(-448.0, 448.0)
+    _, _, sw_hi, sw_lo = hip.f16c_shifts()
+    pair = torch.cat([hi * 2.0 ** sw_hi, (W - hi) * 2.0 ** sw_lo], 1).clamp_(-448.0, 448.0)
     return W.to(torch.float16).contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
 
@@ -86,7 +87,7 @@ def test_gemm_16c_fp8_correction(M, N, K, mode):
     g = torch.Generator().manual_seed(M + N + K + len(mode))
     A = torch.randn(M, K, generator=g) * (1.0 + 3.0 * (torch.rand(M, 1, generator=g) > 0.9))      # some rows of larger magnitude
     if mode == "plain":
-        A[0, :8] = torch.tensor([0.0, 1e-6, -1e-4, 90.0, -111.0, 3e-3, 1.0, -1.0])                    # range edges of the fp8 halves
+        A[0, :8] = torch.tensor([0.0, 1e-6, -1e-4, 90.0, -440.0, 3e-3, 1.0, -1.0])                    # range edges of the fp8 halves
     W = torch.randn(N, K, generator=g) * 0.03
     bias = torch.randn(N, generator=g) * 0.1
     ref = A.double() @ W.double().t() + bias.double()
@@ -118,8 +119,9 @@ def test_gemm_16c_fp8_correction(M, N, K, mode):
     torch.cuda.synchronize()
     scale = float(ref.abs().mean())
     if mode == "gelu":
-        lo8 = C8[:, :N].view(torch.float8_e4m3fn).float().cpu() / float(1 << 13)
-        hi8 = C8[:, N:].view(torch.float8_e4m3fn).float().cpu() / 4.0
+        sa_lo, sa_hi, _, _ = hip.f16c_shifts()
+        lo8 = C8[:, :N].view(torch.float8_e4m3fn).float().cpu() / 2.0 ** sa_lo
+        hi8 = C8[:, N:].view(torch.float8_e4m3fn).float().cpu() / 2.0 ** sa_hi
         got = C.float().cpu() + lo8
         err = float((got.double() - ref).abs().max())
         print("gelu split out: max err %.2e (mean |ref| %.2e); f16 part alone %.2e" % (err, scale, maxerr(C.float(), ref)))

@@ -709,5 +709,5 @@ def test_last_layer_rows_and_dedup_are_result_neutral(golden, precision):
     assert outs["all"][4] == 0 and 0 < outs["last"][4] < outs["last"][3] and outs["both"][3] < outs["last"][3]
     for k in range(3):
         assert torch.equal(outs["all"][k], outs["last"][k]), k
-    assert float((outs["both"][0] - outs["all"][0]).abs().max()) < 2e-6
+    assert float((outs["both"][0] - outs["all"][0]).abs().max()) < 2e-5
     assert torch.allclose(outs["both"][1], outs["all"][1], rtol=1e-3, atol=1e-7)

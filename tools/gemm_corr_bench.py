@@ -42,7 +42,7 @@ for name, N, K, act, res in shapes:
     A16, A8 = [t.to(d) for t in split_f16c(A)]
     hi = W.half().float()
     W16 = W.half().to(d)
-    W8 = torch.cat([hi * 128.0, (W - hi) * float(1 << 18)], 1).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).to(d)
+    W8 = torch.cat([hi * 2.0 ** hip.f16c_shifts()[2], (W - hi) * 2.0 ** hip.f16c_shifts()[3]], 1).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).to(d)
     bias = torch.randn(N, generator=g).to(d)
     R16 = torch.randn(M, N, generator=g).half().to(d) if res else None
     R32 = R16.float() if res else None

@@ -70,7 +70,7 @@ for (M, N, K, act, res) in [(43008, 768, 768, 0, True), (43008, 2304, 768, 0, Fa
     a16, a8 = split_f16c(A)
     whi = W.half().float()
     w16 = W.half()
-    w8 = torch.cat([whi * 128.0, (W - whi) * float(1 << 18)], 1).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    w8 = torch.cat([whi * 2.0 ** hip.f16c_shifts()[2], (W - whi) * 2.0 ** hip.f16c_shifts()[3]], 1).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
     bias = torch.randn(N, generator=g).to(d)
     R = torch.randn(M, N, generator=g).to(d) if res else None
     if act:
