@@ -328,6 +328,42 @@ __device__ __forceinline__ void flash_softmax_step(f32x4_t (&sacc)[4], float& m,
     }
 }
 
+// Workgroup -> (block, head) for the MFMA attention kernels.  RUART_ATTN_MAP 1 (default): a 1-D grid, every XCD takes a contiguous
+// chunk of the logical ids (xcd_remap) and inside it the HEAD index runs fastest (short windows: the 12 x 256-byte slices of a token
+// row are fetched by neighbouring workgroups at the same time instead of by workgroups ~700 launches apart) or, for the long-sequence
+// kernel, the query blocks of one (sequence, head) are neighbours on ONE XCD (they all stream the same K / V rows: the second to
+// fourth reader hits that XCD's L2 instead of the fabric).  0: the 2-D grid (block fastest) of rounds 1-2, kept for A/B runs.
+#ifndef RUART_ATTN_MAP
+#define RUART_ATTN_MAP 1
+#endif
+#define ATTN_QGROUP 4
+__device__ __forceinline__ void attn_block_head(int n_heads, bool long_blocks, int n_blocks, int& b, int& h) {
+#if RUART_ATTN_MAP
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  if (!long_blocks) {
+    b = id / n_heads;
+    h = id - b * n_heads;
+  } else {                     // groups of ATTN_QGROUP consecutive query blocks (one 512-token sequence = 4 blocks of 128) x heads
+    const int per = ATTN_QGROUP * n_heads;
+    const int g = id / per, first = g * ATTN_QGROUP;
+    const int gsz = min(ATTN_QGROUP, n_blocks - first);
+    const int r = id - g * per;
+    h = r / gsz;
+    b = first + (r - h * gsz);
+  }
+#else
+  b = blockIdx.x;
+  h = blockIdx.y;
+#endif
+}
+static inline dim3 attn_grid(int n_blocks, int n_heads) {
+#if RUART_ATTN_MAP
+  return dim3((unsigned)n_blocks * (unsigned)n_heads);
+#else
+  return dim3(n_blocks, n_heads);
+#endif
+}
+
 template <typename T16>
 __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
                                                             const int* __restrict__ bq0, const int* __restrict__ bq1,
@@ -339,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const T16* __restric
   __shared__ __attribute__((aligned(16))) float Bs[64];
   __shared__ __attribute__((aligned(16))) int Ls[64];
   typedef typename Vec8<T16>::type frag_t;
-  const int b = blockIdx.x, h = blockIdx.y;
+  int b, h;
+  attn_block_head(H >> 6, false, 0, b, h);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
@@ -459,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   __shared__ __attribute__((aligned(16))) float Bs[64];
   __shared__ __attribute__((aligned(16))) int Ls[64];
   typedef f16x8_t frag_t;
-  const int b = blockIdx.x, h = blockIdx.y;
+  int b, h;
+  attn_block_head(H >> 6, false, 0, b, h);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
@@ -569,13 +607,14 @@ template <typename T16>
 __global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
                                                                  const int* __restrict__ bq0, const int* __restrict__ bq1,
                                                                  const int* __restrict__ bk0, const int* __restrict__ bk1,
-                                                                 const float* __restrict__ key_bias) {
+                                                                 const float* __restrict__ key_bias, int n_long) {
   constexpr int RS = 144;
   __shared__ __attribute__((aligned(16))) char Ks[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char Vs[2][64 * RS];
   __shared__ __attribute__((aligned(16))) float Bs[2][64];
   typedef typename Vec8<T16>::type frag_t;
-  const int b = blockIdx.x, h = blockIdx.y;
+  int b, h;
+  attn_block_head(H >> 6, true, n_long, b, h);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
@@ -874,7 +913,7 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
     hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr,
                        ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
   else
-    hipLaunchKernelGGL(attn_flash_split_kernel, dim3(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16,
+    hipLaunchKernelGGL(attn_flash_split_kernel, attn_grid(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16,
                        (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
   RUART_CHECK_LAUNCH();
   return 0;
@@ -914,7 +953,7 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
   // 16-bit: MFMA kernels.  Short windows are a one-tile call with a block-diagonal mask; long sequences come as blocks of up to
   // 128 queries that see the whole sequence.
   if (n_blocks > 0) {
-    const dim3 grid(n_blocks, n_heads), block(256);
+    const dim3 grid = attn_grid(n_blocks, n_heads), block(256);
     if (dtype == RUART_DT_BF16)
       hipLaunchKernelGGL(attn_flash_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
     else
@@ -922,11 +961,11 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
     RUART_CHECK_LAUNCH();
   }
   if (n_long_blocks > 0) {
-    const dim3 grid(n_long_blocks, n_heads), block(256);
+    const dim3 grid = attn_grid(n_long_blocks, n_heads), block(256);
     if (dtype == RUART_DT_BF16)
-      hipLaunchKernelGGL(attn_flash_long_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+      hipLaunchKernelGGL(attn_flash_long_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, ld, (bf16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias, n_long_blocks);
     else
-      hipLaunchKernelGGL(attn_flash_long_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias);
+      hipLaunchKernelGGL(attn_flash_long_kernel<f16_t>, grid, block, 0, st, (const f16_t*)qkv, ld, (f16_t*)ctx, ldc, H, lblk_q0, lblk_q1, lblk_k0, lblk_k1, key_bias, n_long_blocks);
     RUART_CHECK_LAUNCH();
   }
   return 0;

@@ -129,8 +129,13 @@ def test_gemm_16c_fp8_correction(M, N, K, mode):
         assert float((hi8.double() - ref).abs().max()) < 0.07 * float(ref.abs().max()) + 2e-3      # e4m3: 3 mantissa bits
         return
     err_c, err_p = maxerr(C, ref), maxerr(P, ref)
-    rms_c = float((C.double().cpu() - ref).pow(2).mean().sqrt())
-    rms_p = float((P.double().cpu() - ref).pow(2).mean().sqrt())
+    # (row 0 of the "plain" case carries the range-edge values - its products are two orders above the matrix's typical magnitude,
+    # so it is held to its own scale below and left out of the matrix-wide rms)
+    r0 = 1 if mode == "plain" else 0
+    rms_c = float((C.double().cpu() - ref)[r0:].pow(2).mean().sqrt())
+    rms_p = float((P.double().cpu() - ref)[r0:].pow(2).mean().sqrt())
+    if mode == "plain":
+        assert float((C.double().cpu() - ref)[0].abs().max()) < 1e-4 * float(ref[0].abs().max())
     print("K=%d %s: corrected max %.2e rms %.2e | plain f16 max %.2e rms %.2e | mean |ref| %.2e" % (K, mode, err_c, rms_c, err_p, rms_p, scale))
     assert rms_c < rms_p / 8 and err_c < err_p / 4
     assert rms_c < 2e-5 * scale * max(1.0, (K / 768) ** 0.5)
