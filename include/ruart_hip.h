@@ -304,6 +304,10 @@ int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, 
  *   hprev : (B, T, ndir*h)   h of the previous step of the same direction (0 at its first step): the right-hand operand of
  *                            grad_W_hh = grad_xproj^T . hprev, so the caller needs no shifted copy of y
  * h <= 128, ndir in {1, 2}. */
+/* Kernel form of ruart_lstm_fwd / ruart_lstm_bwd: 1 (default) = 16 batch rows per workgroup, the recurrent product on the matrix cores
+ * with split-bf16 operands (hi.hi + hi.lo + lo.hi, fp32 accumulation - the arithmetic of ruart_gemm_x3), B * ndir / 16 workgroups;
+ * 0 = one workgroup per (row, direction) with exact fp32 FMAs (rounds 1-2).  Process-wide. */
+int ruart_lstm_set_variant(int variant);
 int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, float* hprev, int B, int T, int h,
                    int ndir, void* stream);
 /* BPTT for the op above: grad_y (B,T,ndir*h) -> grad_xproj (B,T,ndir*4h) (gradient w.r.t. the gate pre-activations).

@@ -155,6 +155,312 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same recurrence with 16 batch rows per workgroup on the matrix cores (round 3; default, ruart_lstm_set_variant).
+//
+// The per-row kernels above pin one CU per (batch row, direction) - 128 workgroups x ~110 us for a (64, 100) layer - and every CU
+// they sit on is lost to an encoder GEMM workgroup, which needs a whole CU.  Here a workgroup advances 16
+// batch rows at once: the step's recurrent product P (16 x 4h) = h_{t-1} (16 x h) . W_hh^T is an MFMA product with the SDNet
+// trunk's split-bf16 arithmetic (hi.hi + hi.lo + lo.hi, fp32 accumulation: ~2^-16 per product, sdnet_gemm.hip), W_hh's hi / lo
+// fragments live in VGPRs for the whole sequence (128 per lane, as before), the running h in LDS as the bf16 hi / lo operand
+// image (double-buffered: ONE barrier per step).  B x ndir / 16 = 8 workgroups instead of 128.
+//
+// Ownership.  Wave w, MFMA row m (0..15) stands for hidden unit  unit(w, m) = min(16 w + (m & ~3), h - 4) + (m & 3)  and owns all
+// FOUR gate rows of it (the W rows are gathered that way once), so after the MFMAs lane (fr, fq) holds the i, f, g, o
+// pre-activations of the four CONSECUTIVE units u0 .. u0 + 3, u0 = min(16 w + 4 fq, h - 4), of batch row fr: the cell update is
+// lane-local, c and the previous h stay in registers, nothing is exchanged but the new h.  The clamp makes every lane's four units
+// real ones: where 16 w + 4 fq + 3 runs past h (h = 125: the lanes of "units 124..127") the lane recomputes the last four real
+// units instead - the same bits as their first owner (same operands, same instruction) - so EVERY lane issues the same full
+// 16-byte loads and stores and the loop has no divergent path at all (the first version special-cased the ragged end: ~900
+// instructions of exec-mask bookkeeping per step).  Duplicated positions must not be counted twice in a contraction: the W
+// entries of a duplicate position are zero.  Batch rows past B are clamped to B - 1 the same way (duplicate, identical stores).
+// The backward kernel mirrors it: the lane computes da_i..da_o of its units from the saved gates / cells, writes them to the
+// global grad_xproj and to an LDS operand image da (16 x 512 positions, bf16 hi / lo), and after the barrier every wave takes
+// dh_{t-1} of ITS 16 positions = da . W_hh[:, units] over all positions from W_hh^T fragments in VGPRs - the result lands in
+// the lanes that own those units.
+// Memory waits: vmcnt counts loads and stores in one in-order queue, so each step first waits for the NEXT step's operands
+// (issued at the top of the step, a whole step ago) and only then issues its own stores - otherwise the wait for the loads would
+// also drain the stores (a write latency per step: measured, 1.1 us).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef RUART_LSTM_ABL
+#define RUART_LSTM_ABL 0       // diagnostic builds: 1 no x loads in the loop, 2 no global stores, 4 no gate transcendental, 8 no MFMAs
+#endif
+#define LRB 16                 // batch rows per workgroup
+#define LHS 272                // forward h image: 128 bf16 per row + 16 bytes pad
+#define LDS_DA 1040            // backward da image: 512 bf16 per row + 16 bytes pad
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // 4 consecutive floats at any 4-byte aligned address
+
+__device__ __forceinline__ float sigm_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float tanh_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900817779268f)) - 1.0f; }
+
+__device__ __forceinline__ void split_bf16_(float x, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)x;
+  lo = (bf16_t)(x - (float)hi);
+}
+// hidden unit of ownership position (w, m), and whether that position is the unit's first (counted) one
+__device__ __forceinline__ int lstm_unit(int w, int m, int h) { return min(16 * w + (m & ~3), h - 4) + (m & 3); }
+// Is ownership position q = 16 w + m the one whose weights COUNT in a contraction over positions?  Natural positions (group base
+// q & ~3 <= h - 4) always; of the clamped groups only the first one, and there only the units no natural position covers.
+__device__ __forceinline__ bool lstm_counted(int q, int h) {
+  const int base = q & ~3, b0 = (h - 4) & ~3;
+  if (base <= h - 4) return true;
+  return base == b0 + 4 && (h - 4 + (q & 3)) > b0 + 3;
+}
+
+__global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                            float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cells,
+                                                            float* __restrict__ hprev, int B, int T, int h, int ndir,
+                                                            int* __restrict__ nan_flag) {
+  __shared__ __attribute__((aligned(16))) char himg[2][2][LRB * LHS];      // [buffer][hi | lo], k = ownership position 16 w + m
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int G = 4 * h;
+  // W_hh fragments: first MFMA operand of tile (gate type i, k-step ks) = gate row i*h + unit(w, fr), contraction positions
+  // k = 32 ks + 8 fq .. + 7 -> hidden unit of that position; duplicate positions carry zero weights
+  bf16x8_t wh[4][4], wl[4][4];
+  {
+    const int unit = lstm_unit(w, fr, h);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 32 + fq * 8 + e, kw = k >> 4, km = k & 15;
+        const int ku = lstm_unit(kw, km, h);
+        const bool counted = lstm_counted(k, h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = counted ? w_hh[((size_t)d * G + (size_t)i * h + unit) * h + ku] : 0.f;
+          bf16_t a, b;
+          split_bf16_(v, a, b);
+          wh[i][ks][e] = a;
+          wl[i][ks][e] = b;
+        }
+      }
+  }
+  for (int i = tid; i < 2 * 2 * LRB * LHS / 4; i += 512) reinterpret_cast<int*>(&himg[0][0][0])[i] = 0;     // h_0 = 0; pads stay 0
+  const int b = min((int)blockIdx.x * LRB + fr, B - 1);
+  const int u0 = min(16 * w + 4 * fq, h - 4);          // the lane's units u0 .. u0 + 3 of batch row b
+  float c[4] = {0.f, 0.f, 0.f, 0.f}, hp[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t ldx = (size_t)ndir * G, ldy = (size_t)ndir * h;
+  const int t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
+  const long long sx = (long long)dt * (long long)ldx, sy = (long long)dt * (long long)ldy;      // pointer steps per time step
+  const float* xp = xproj + ((size_t)b * T + t0) * ldx + (size_t)d * G + u0;
+  const size_t oy = ((size_t)b * T + t0) * ldy + (size_t)d * h + u0, og_ = ((size_t)b * T + t0) * ldx + (size_t)d * G + u0;
+  float* yp = y + oy;
+  float* cp_ = cells ? cells + oy : nullptr;
+  float* hpp = hprev ? hprev + oy : nullptr;
+  float* gp = gates ? gates + og_ : nullptr;
+  auto load_x = [&](const float* p, f32x4_t (&x)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_u v = *reinterpret_cast<const f32x4_u*>(p + (size_t)i * h);
+      x[i] = (f32x4_t){v[0], v[1], v[2], v[3]};
+    }
+  };
+  f32x4_t xcur[4], xnext[4];
+  load_x(xp, xcur);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xnext[i] = xcur[i];
+  __syncthreads();
+  bool bad = false;
+  int cur = 0;
+  for (int s = 0; s < T; ++s, cur ^= 1) {
+    xp += sx;
+    if (s + 1 < T && !(RUART_LSTM_ABL & 1)) load_x(xp, xnext);
+    bf16x8_t hh[4], hl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      hh[ks] = *reinterpret_cast<const bf16x8_t*>(&himg[cur][0][fr * LHS + (ks * 32 + fq * 8) * 2]);
+      hl[ks] = *reinterpret_cast<const bf16x8_t*>(&himg[cur][1][fr * LHS + (ks * 32 + fq * 8) * 2]);
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (!(RUART_LSTM_ABL & 8)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] = mfma_16x16x32(wl[i][ks], hh[ks], acc[i]);       // small terms first
+          acc[i] = mfma_16x16x32(wh[i][ks], hl[ks], acc[i]);
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mfma_16x16x32(wh[i][ks], hh[ks], acc[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][0] = (float)hh[i][0] + (float)hl[i][1] + (float)wh[i][0][0];
+    }
+    // lane-local cell update of units u0 + r, batch row b
+    f32x4_t ga[4], hv, cv, hpv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pi = acc[0][r] + xcur[0][r], pf = acc[1][r] + xcur[1][r], pg = acc[2][r] + xcur[2][r], po = acc[3][r] + xcur[3][r];
+#if RUART_LSTM_ABL & 4
+      const float ig = pi * 0.1f, fg = pf * 0.1f, gg = pg * 0.1f, og = po * 0.1f;
+      c[r] = fg * c[r] + ig * gg;
+      const float tc = c[r];
+#else
+      // sigmoid(x) = rcp(1 + exp2(-x log2 e)), tanh(x) = 2 sigmoid(2x) - 1 on the raw v_exp_f32 / v_rcp_f32 (1 ulp each): the IEEE
+      // divide of 1.0f / (...) is a ten-instruction sequence
+      const float ig = sigm_(pi), fg = sigm_(pf), gg = tanh_(pg), og = sigm_(po);
+      c[r] = fg * c[r] + ig * gg;
+      const float tc = tanh_(c[r]);
+#endif
+      const float hn = og * tc;
+      ga[0][r] = ig; ga[1][r] = fg; ga[2][r] = gg; ga[3][r] = og;
+      hv[r] = hn;
+      cv[r] = c[r];
+      hpv[r] = hp[r];
+      hp[r] = hn;
+      bad |= !(hn == hn);
+    }
+    {
+      // the new h as next step's second operand, at the lane's ownership positions 16 w + 4 fq .. + 3 of row fr
+      bf16x4_t vh, vl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf16_t a, bb;
+        split_bf16_(hv[r], a, bb);
+        vh[r] = a;
+        vl[r] = bb;
+      }
+      *reinterpret_cast<bf16x4_t*>(&himg[cur ^ 1][0][fr * LHS + (16 * w + 4 * fq) * 2]) = vh;
+      *reinterpret_cast<bf16x4_t*>(&himg[cur ^ 1][1][fr * LHS + (16 * w + 4 * fq) * 2]) = vl;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next step's x landed; only the PREVIOUS step's stores were behind it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xcur[i] = xnext[i];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!((RUART_LSTM_ABL & 2) && s + 1 < T)) {
+      *reinterpret_cast<f32x4_u*>(yp) = (f32x4_u){hv[0], hv[1], hv[2], hv[3]};
+      if (cp_) *reinterpret_cast<f32x4_u*>(cp_) = (f32x4_u){cv[0], cv[1], cv[2], cv[3]};
+      if (hpp) *reinterpret_cast<f32x4_u*>(hpp) = (f32x4_u){hpv[0], hpv[1], hpv[2], hpv[3]};
+      if (gp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_u*>(gp + (size_t)i * h) = (f32x4_u){ga[i][0], ga[i][1], ga[i][2], ga[i][3]};
+      }
+    }
+    yp += sy;
+    if (cp_) cp_ += sy;
+    if (hpp) hpp += sy;
+    if (gp) gp += sx;
+    __syncthreads();                                   // the new h image is complete; the old one is dead for every wave
+  }
+  if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_mfma_kernel(const float* __restrict__ grad_y, const float* __restrict__ w_hh,
+                                                            const float* __restrict__ gates, const float* __restrict__ cells,
+                                                            float* __restrict__ grad_xproj, int B, int T, int h, int ndir) {
+  __shared__ __attribute__((aligned(16))) char daimg[2][2][LRB * LDS_DA];    // [buffer][hi | lo], 66 KB
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int G = 4 * h;
+  // W_hh^T fragments: first operand of k-step ks (16 of them) = output position (w, fr) -> unit(w, fr); contraction index
+  // p = 32 ks + 8 fq + e = 64 w' + 16 type + m  <->  gate row type*h + unit(w', m); duplicate positions (w', m) carry zero weights
+  bf16x8_t wh[16], wl[16];
+  {
+    const int unit = lstm_unit(w, fr, h);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int p = ks * 32 + fq * 8 + e;
+        const int wp = p >> 6, type = (p >> 4) & 3, m = p & 15;
+        const int gu = lstm_unit(wp, m, h);
+        const bool counted = lstm_counted(16 * wp + m, h);
+        const float v = counted ? w_hh[((size_t)d * G + (size_t)type * h + gu) * h + unit] : 0.f;
+        bf16_t a, b;
+        split_bf16_(v, a, b);
+        wh[ks][e] = a;
+        wl[ks][e] = b;
+      }
+  }
+  const int b = min((int)blockIdx.x * LRB + fr, B - 1);
+  const int u0 = min(16 * w + 4 * fq, h - 4);
+  const size_t ldx = (size_t)ndir * G, ldy = (size_t)ndir * h;
+  const int t0 = d ? 0 : T - 1, dt = d ? 1 : -1;       // the forward order walked backwards
+  const long long sx = (long long)dt * (long long)ldx, sy = (long long)dt * (long long)ldy;
+  float dh_rec[4] = {0.f, 0.f, 0.f, 0.f}, dc_next[4] = {0.f, 0.f, 0.f, 0.f};
+  struct StepIn { f32x4_t ig, fg, gg, og, cc, cp, gy; };
+  const float* gp = gates + ((size_t)b * T + t0) * ldx + (size_t)d * G + u0;
+  const float* cp_ = cells + ((size_t)b * T + t0) * ldy + (size_t)d * h + u0;
+  const float* gyp = grad_y + ((size_t)b * T + t0) * ldy + (size_t)d * h + u0;
+  float* gx = grad_xproj + ((size_t)b * T + t0) * ldx + (size_t)d * G + u0;
+  auto ld = [&](const float* p) -> f32x4_t {
+    const f32x4_u v = *reinterpret_cast<const f32x4_u*>(p);
+    return (f32x4_t){v[0], v[1], v[2], v[3]};
+  };
+  // one unconditional 16-byte load per operand, issued ONE STEP AHEAD of their use; `prev`: the forward's previous step exists
+  auto load_step = [&](bool prev, StepIn& in) {
+    in.ig = ld(gp);
+    in.fg = ld(gp + h);
+    in.gg = ld(gp + 2 * (size_t)h);
+    in.og = ld(gp + 3 * (size_t)h);
+    in.cc = ld(cp_);
+    in.cp = ld(prev ? cp_ + sy : cp_);                 // (multiplied by 0 below when there is none)
+    in.gy = ld(gyp);
+  };
+  StepIn in, nxt;
+  load_step(T > 1, in);
+  nxt = in;
+  int cur = 0;
+  for (int s = 0; s < T; ++s, cur ^= 1) {
+    gp += sx;
+    cp_ += sy;
+    gyp += sy;
+    if (s + 1 < T) load_step(s + 2 < T, nxt);
+    const float has_prev = (s + 1 < T) ? 1.f : 0.f;
+    f32x4_t da[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = in.gy[r] + dh_rec[r];
+      const float tc = tanh_(in.cc[r]);
+      const float dc = dc_next[r] + dh * in.og[r] * (1.f - tc * tc);
+      da[0][r] = dc * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
+      da[1][r] = dc * (in.cp[r] * has_prev) * in.fg[r] * (1.f - in.fg[r]);
+      da[2][r] = dc * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
+      da[3][r] = dh * tc * in.og[r] * (1.f - in.og[r]);
+      dc_next[r] = dc * in.fg[r];
+    }
+    // da as the second MFMA operand: row fr, position p = 64 w + 16 type + 4 fq + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4_t vh, vl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf16_t a, bb;
+        split_bf16_(da[i][r], a, bb);
+        vh[r] = a;
+        vl[r] = bb;
+      }
+      const int off = fr * LDS_DA + (64 * w + 16 * i + 4 * fq) * 2;
+      *reinterpret_cast<bf16x4_t*>(&daimg[cur][0][off]) = vh;
+      *reinterpret_cast<bf16x4_t*>(&daimg[cur][1][off]) = vl;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next step's operands in registers before this step's stores are issued
+    in = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_u*>(gx + (size_t)i * h) = (f32x4_u){da[i][0], da[i][1], da[i][2], da[i][3]};
+    gx += sx;
+    __syncthreads();                                   // (double-buffered: the next step writes the other image)
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8_t dh_ = *reinterpret_cast<const bf16x8_t*>(&daimg[cur][0][fr * LDS_DA + (ks * 32 + fq * 8) * 2]);
+      const bf16x8_t dl_ = *reinterpret_cast<const bf16x8_t*>(&daimg[cur][1][fr * LDS_DA + (ks * 32 + fq * 8) * 2]);
+      acc2 = mfma_16x16x32(wl[ks], dh_, acc2);         // the two small products in their own accumulator ...
+      acc2 = mfma_16x16x32(wh[ks], dl_, acc2);
+      acc = mfma_16x16x32(wh[ks], dh_, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r] + acc2[r];     // ... added last
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Fused LSTM cell for the wide, short `multi2one` LSTM (hidden 300: W_hh does not fit one CU's registers, and the
 // sequences are only 1-3 real words long).  The recurrent product h W_hh^T is a plain GEMM per step; this kernel does the
 // whole pointwise part of a step in one pass over a ragged, length-sorted batch: rows < n_active are advanced, rows
@@ -216,10 +522,23 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 
 extern int* ruart_nan_flag_ptr;
 
+static int g_lstm_variant = 1;       // 1: 16 batch rows per workgroup on the matrix cores (default); 0: one workgroup per row, fp32 VALU
+extern "C" int ruart_lstm_set_variant(int v) {
+  if (v != 0 && v != 1) return (int)hipErrorInvalidValue;
+  g_lstm_variant = v;
+  return 0;
+}
+
 extern "C" int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates, float* cells, float* hprev, int B, int T,
                               int h, int ndir, void* stream) {
   RUART_ENTRY();
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
+  if (g_lstm_variant == 1 && h >= 4) {
+    hipLaunchKernelGGL(lstm_fwd_mfma_kernel, dim3((B + LRB - 1) / LRB, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells,
+                       hprev, B, T, h, ndir, ruart_nan_flag_ptr);
+    RUART_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, xproj, w_hh, y, gates, cells, hprev, T, h, ndir,
                      ruart_nan_flag_ptr);
   RUART_CHECK_LAUNCH();
@@ -230,6 +549,12 @@ extern "C" int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const floa
                               int B, int T, int h, int ndir, void* stream) {
   RUART_ENTRY();
   if (B <= 0 || T <= 0 || h <= 0 || h > HP || ndir < 1 || ndir > 2) return (int)hipErrorInvalidValue;
+  if (g_lstm_variant == 1 && h >= 4) {
+    hipLaunchKernelGGL(lstm_bwd_mfma_kernel, dim3((B + LRB - 1) / LRB, ndir), dim3(512), 0, (hipStream_t)stream, grad_y, w_hh, gates, cells,
+                       grad_xproj, B, T, h, ndir);
+    RUART_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(512), 0, (hipStream_t)stream, grad_y, w_hh, gates, cells, grad_xproj, T, h,
                      ndir);
   RUART_CHECK_LAUNCH();

@@ -471,8 +471,18 @@ def test_whole_layer_norm(layers_golden):
     assert maxerr(yd, ref) < 5e-6 and maxerr(bd.grad, bc.grad) < 5e-6
 
 
-@pytest.mark.parametrize("B,Tn,Din,Hh,bid", [(3, 11, 10, 6, True), (5, 4, 14, 9, False), (64, 100, 300, 125, True), (2, 1, 5, 128, True)])
-def test_lstm_layer(B, Tn, Din, Hh, bid):
+@pytest.fixture(params=[1, 0], ids=["mfma16", "valu"])
+def lstm_variant(request):
+    """both kernel forms of the persistent recurrence: 16 batch rows per workgroup on the matrix cores (default) / one row, fp32 FMAs"""
+    lib = hip.load()
+    assert lib.ruart_lstm_set_variant(request.param) == 0
+    yield request.param
+    assert lib.ruart_lstm_set_variant(1) == 0
+
+
+@pytest.mark.parametrize("B,Tn,Din,Hh,bid", [(3, 11, 10, 6, True), (5, 4, 14, 9, False), (64, 100, 300, 125, True), (2, 1, 5, 128, True),
+                                             (19, 7, 12, 125, True), (33, 40, 20, 124, False)])
+def test_lstm_layer(B, Tn, Din, Hh, bid, lstm_variant):
     from ruart_amd import ops
     d = dev()
     g = torch.Generator().manual_seed(B + Tn + Hh)
