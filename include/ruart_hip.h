@@ -388,6 +388,20 @@ int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, i
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
                   const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
                   const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
+/* All weight gradients of a training step in ONE launch (+ one for the split-K sums): problem i is dW_i (M x N, row stride ldc) (+)=
+ * dY_i^T . X_i with dY_i (K rows, M columns, row stride lda) and X_i (K rows, N columns, row stride ldb) as the backward pass holds
+ * them - autograd's grad_weight = grad_output.t().mm(input) of the nn.Linear sites at Models/Layers.py:155, 166, 226-227.  Every
+ * problem is tiled, split along K and summed exactly as ruart_gemm_x3 would do it alone (bitwise the same result); `accumulate`:
+ * add to the existing dW (a module used twice).  Problems that write the SAME dW must not be in one call.  `probs` is a HOST array;
+ * ws: ruart_gemm_x3_tn_grouped_ws(probs, n) bytes. */
+typedef struct {
+  const float* A;
+  const float* B;
+  float* C;
+  int lda, ldb, ldc, M, N, K, accumulate;
+} ruart_x3_tn_problem;
+size_t ruart_gemm_x3_tn_grouped_ws(const ruart_x3_tn_problem* probs, int n);
+int ruart_gemm_x3_tn_grouped(const ruart_x3_tn_problem* probs, int n, float* ws, size_t ws_bytes, void* stream);
 /* ruart_gemm_x3 with ONE bf16 product (hi.hi) instead of three: the operands are rounded to bf16, the accumulation stays fp32.
  * Same arguments, layouts, epilogue and workspace rule.  For products whose result is a gradient (dX, dW) beside a 16-bit encoder. */
 int ruart_gemm_x1(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,

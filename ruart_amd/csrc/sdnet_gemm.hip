@@ -146,13 +146,14 @@ __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, 
   }
 }
 
-template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP = 3>     // NP = 1: the hi.hi product only (plain bf16)
-__global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
-                                                            long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
-                                                            int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
-                                                            const float* __restrict__ a_scale, const float* __restrict__ b_scale,
-                                                            const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
-                                                            int ldr, int act) {
+// One workgroup's share of a product: output tile `id / splitk`, K slice `id % splitk` (the body of gemm_x3_kernel and of the grouped
+// weight-gradient kernel below)
+template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP>
+__device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk, long sbn,
+                                        const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N, int K, int splitk,
+                                        float* __restrict__ ws, const float* __restrict__ a_scale, const float* __restrict__ b_scale,
+                                        const float* __restrict__ c_scale, int rpm, const float* __restrict__ R, int ldr, int act,
+                                        int id) {
   typedef XT<TM> T;
   constexpr int ARR = T::ARR, JT = T::JT;
   extern __shared__ __attribute__((aligned(1024))) char smem[];          // 2 stages x (A_hi, A_lo, B_hi, B_lo)
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
   const int wm = wave / T::WN, wn = wave % T::WN;                        // 2 x WN waves; a wave owns (TM/2) rows x 64 columns
   const int fr = lane & 15, fq = lane >> 4;
   const int ntn = (N + TM - 1) / TM;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id / splitk, slice = id - tile * splitk;             // the slices of a tile are neighbours: same XCD / L2
   const int m0 = (tile / ntn) * TM, n0 = (tile % ntn) * TM;
   const int ksteps = (K + XBK - 1) / XBK;
@@ -268,18 +268,58 @@ __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restr
   }
 }
 
+template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP = 3>     // NP = 1: the hi.hi product only (plain bf16)
+__global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
+                                                            long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
+                                                            int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
+                                                            const float* __restrict__ a_scale, const float* __restrict__ b_scale,
+                                                            const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
+                                                            int ldr, int act) {
+  x3_tile<TM, AMODE, BMODE, VECA, VECB, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, a_scale, b_scale, c_scale, rpm, R,
+                                            ldr, act, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// ---- grouped weight gradients --------------------------------------------------------------------------------------------------
+// dW_p (M_p x N_p) = dY_p^T . X_p over the rows of a projection's input: ~45 such products per training step, each a small output
+// with a long reduction - alone they fill 10-30 % of the chip for 20-50 us and each drags a split-K reduction launch behind it.  Here
+// ALL of a step's weight gradients run as one launch (and one reduction launch): the workgroups of problem p are the id range
+// [blk0, blk0 + tiles * splitk) of a 1-D grid, each runs x3_tile exactly as the single-problem kernel would (same tiles, same K
+// slices, same summation order: bitwise the same dW).  `accum`: dW += (a weight used twice - deep attention, the shared RNNs - gets
+// its second contribution in a second wave of the same kind).
+#define X3G_MAX 44
+struct X3GProb {
+  const float* A;      // dY (rows, M): element (m, k) at A[k * lda + m]
+  const float* B;      // X  (rows, N): element (k, n) at B[k * ldb + n]
+  float* C;            // dW (M, N), row stride ldc
+  float* ws;           // this problem's split-K slabs
+  int lda, ldb, ldc, M, N, K, splitk, blk0, red0, accum;
+};
+struct X3GArgs {
+  X3GProb p[X3G_MAX];
+  int n;
+};
+template <bool VECA, bool VECB>
+__global__ __launch_bounds__(256, 2) void gemm_x3_grouped_tn_kernel(const X3GArgs g) {
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int q = 0;
+  while (q + 1 < g.n && id >= g.p[q + 1].blk0) ++q;          // wave-uniform scan over <= 44 problems
+  const X3GProb& P = g.p[q];
+  const float* R = (P.accum && P.splitk == 1) ? P.C : nullptr;
+  x3_tile<128, 1, 1, VECA, VECB, 3>(P.A, 1, P.lda, P.B, P.ldb, 1, nullptr, P.C, P.ldc, P.M, P.N, P.K, P.splitk, P.ws, nullptr, nullptr,
+                                    nullptr, 1, R, P.ldc, RUART_ACT_NONE, id - P.blk0);
+}
+
 // second launch of a split-K product: one thread per 4 output floats adds the slices in slice order and writes C (+ bias)
 template <int TM>
-__global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                           float* __restrict__ C, int ldc, int M, int N, int splitk,
-                                                           const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
-                                                           int ldr, int act) {
+__device__ __forceinline__ void x3_reduce_body(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                               int M, int N, int splitk, const float* __restrict__ c_scale, int rpm,
+                                               const float* __restrict__ R, int ldr, int act, int blk) {
   typedef XT<TM> T;
   constexpr int JT = T::JT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 15, fq = lane >> 4;
   const int ntn = (N + TM - 1) / TM;
-  const int tile = blockIdx.x / (4 * JT), ij = blockIdx.x % (4 * JT), i = ij / JT, j = ij % JT;
+  const int tile = blk / (4 * JT), ij = blk % (4 * JT), i = ij / JT, j = ij % JT;
   const int m = (tile / ntn) * TM + wm * (TM / 2) + j * 16 + fr, n = (tile % ntn) * TM + wn * 64 + i * 16 + fq * 4;
   if (m >= M || n >= N) return;
   const float* p = ws + (size_t)tile * splitk * (TM * TM) + (ij * T::THREADS + tid) * 4;
@@ -294,6 +334,24 @@ __global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restri
       if (R) v += R[(size_t)m * ldr + n + r];
       C[(size_t)m * ldc + n + r] = v;
     }
+}
+
+template <int TM>
+__global__ __launch_bounds__(TM * 2) void x3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                           float* __restrict__ C, int ldc, int M, int N, int splitk,
+                                                           const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
+                                                           int ldr, int act) {
+  x3_reduce_body<TM>(ws, bias, C, ldc, M, N, splitk, c_scale, rpm, R, ldr, act, blockIdx.x);
+}
+
+// the slice sums of every split problem of a group, one launch (problem p: blocks [red0, red0 + tiles * 16))
+__global__ __launch_bounds__(256) void x3_reduce_grouped_kernel(const X3GArgs g) {
+  const int id = blockIdx.x;
+  int q = 0;
+  while (q + 1 < g.n && id >= g.p[q + 1].red0) ++q;
+  const X3GProb& P = g.p[q];
+  if (P.splitk <= 1) return;                           // (problems without a split own no reduction blocks; defensive)
+  x3_reduce_body<128>(P.ws, nullptr, P.C, P.ldc, P.M, P.N, P.splitk, nullptr, 1, P.accum ? P.C : nullptr, P.ldc, RUART_ACT_NONE, id - P.red0);
 }
 
 struct Plan { int tm, tiles, splitk; };
@@ -422,4 +480,86 @@ extern "C" int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const floa
   // A stored (K, M): element (m, k) at A[k * sak_rows + m]; B stored (K, N)
   return gemm_xn<1>(A, 1, sak_rows, B, sbk_rows, 1, nullptr, nullptr, 0, RUART_ACT_NONE, C, ldc, M, N, K, ws, ws_bytes, nullptr, nullptr,
                     nullptr, 1, stream);
+}
+
+// ---- grouped weight gradients: host side ---------------------------------------------------------------------------------------
+extern "C" size_t ruart_gemm_x3_tn_grouped_ws(const ruart_x3_tn_problem* probs, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const Plan p = make_plan(probs[i].M, probs[i].N, probs[i].K, 1, 1);
+    if (p.splitk > 1) total += (size_t)p.tiles * p.splitk * 128 * 128 * sizeof(float);
+  }
+  return total;
+}
+
+extern "C" int ruart_gemm_x3_tn_grouped(const ruart_x3_tn_problem* probs, int n, float* ws, size_t ws_bytes, void* stream) {
+  RUART_ENTRY();
+  if (n <= 0 || !probs) return (int)hipErrorInvalidValue;
+  if (ruart_gemm_x3_tn_grouped_ws(probs, n) > ws_bytes) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  // four classes by 16-byte loadability of the two operands; inside a class, launches of at most X3G_MAX problems
+  size_t ws_off = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const bool va = cls & 1, vb = cls & 2;
+    X3GArgs g;
+    g.n = 0;
+    int blk = 0, red = 0;
+    auto flush = [&]() -> int {
+      if (g.n == 0) return 0;
+      constexpr int lds = 2 * 4 * XT<128>::ARR;
+#define X3G_LAUNCH(VA, VB)                                                                                                  \
+  do {                                                                                                                       \
+    auto kern = gemm_x3_grouped_tn_kernel<VA, VB>;                                                                           \
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);    \
+    (void)done;                                                                                                              \
+    hipLaunchKernelGGL(kern, dim3(blk), dim3(256), lds, s, g);                                                               \
+  } while (0)
+      if (va && vb) X3G_LAUNCH(true, true);
+      else if (va) X3G_LAUNCH(true, false);
+      else if (vb) X3G_LAUNCH(false, true);
+      else X3G_LAUNCH(false, false);
+#undef X3G_LAUNCH
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      if (red > 0) {
+        hipLaunchKernelGGL(x3_reduce_grouped_kernel, dim3(red), dim3(256), 0, s, g);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+      }
+      g.n = 0;
+      blk = red = 0;
+      return 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      const ruart_x3_tn_problem& q = probs[i];
+      if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return (int)hipErrorInvalidValue;
+      const bool qa = ((reinterpret_cast<uintptr_t>(q.A) & 15) == 0) && ((q.lda & 3) == 0);
+      const bool qb = ((reinterpret_cast<uintptr_t>(q.B) & 15) == 0) && ((q.ldb & 3) == 0);
+      if (qa != va || qb != vb) continue;
+      const Plan pl = make_plan(q.M, q.N, q.K, 1, 1);          // (a transposed-read B operand always plans the 128 tile)
+      X3GProb& P = g.p[g.n];
+      P.A = q.A; P.B = q.B; P.C = q.C;
+      P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
+      P.M = q.M; P.N = q.N; P.K = q.K;
+      P.splitk = pl.splitk;
+      P.accum = q.accumulate ? 1 : 0;
+      P.blk0 = blk;
+      P.red0 = red;
+      P.ws = nullptr;
+      if (pl.splitk > 1) {
+        P.ws = ws + ws_off / sizeof(float);
+        ws_off += (size_t)pl.tiles * pl.splitk * 128 * 128 * sizeof(float);
+        red += pl.tiles * 4 * XT<128>::JT;
+      }
+      blk += pl.tiles * pl.splitk;
+      if (++g.n == X3G_MAX) {
+        // unsplit problems own no reduction blocks: give the scan a sentinel by leaving red0 equal to the next problem's
+        const int rc = flush();
+        if (rc) return rc;
+      }
+    }
+    const int rc = flush();
+    if (rc) return rc;
+  }
+  return 0;
 }

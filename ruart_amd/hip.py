@@ -35,6 +35,11 @@ class BertModelC(Structure):
                 ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p))]
 
 
+class X3TnProblemC(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("accumulate", c_int)]
+
+
 class WPrepItemC(Structure):
     _fields_ = [("w", c_void_p), ("out16", c_void_p), ("outT_bf16", c_void_p), ("ldw", c_int), ("ld16", c_int), ("ldT", c_int), ("rows", c_int),
                 ("cols", c_int), ("scale", c_float)]
@@ -108,6 +113,8 @@ _SIGNATURES = {
     "ruart_embedding_bwd_split": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "ruart_phoc_table": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "ruart_gemm_bf16_tn": (_I, [_P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _I, _I, _I, _P, ctypes.c_size_t, _P]),
+    "ruart_gemm_x3_tn_grouped_ws": (c_size_t, [POINTER(X3TnProblemC), _I]),
+    "ruart_gemm_x3_tn_grouped": (_I, [POINTER(X3TnProblemC), _I, _P, c_size_t, _P]),
     "ruart_gemm_x3_plan": (_I, [_I, _I, _I, _I, _I, POINTER(ctypes.c_int), POINTER(ctypes.c_size_t)]),
     "ruart_gemm_x3": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _P, _I, _I,
                            _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _I, _P]),

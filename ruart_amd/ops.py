@@ -229,6 +229,80 @@ def colsum(x):
     return out
 
 
+# ---- deferred weight gradients ------------------------------------------------------------------------------------------------
+# A training step has ~45 nn.Linear sites in the trunk.  Alone, each dW = dY^T X is a small output with a long reduction: 10-30 % of
+# the chip for 20-50 us plus a split-K reduction launch.  With ``defer_weight_grads`` on (SDNet sets it for training passes), the
+# backward of ``_Linear`` only RECORDS (dY, X, W) and queues one end-of-backward callback with the autograd engine; the callback runs
+# all recorded products as ruart_gemm_x3_tn_grouped launches (one per alignment class and wave), writes / accumulates ``W.grad`` and
+# fires the parameters' post-accumulate hooks (dp.GradSync) - all still inside ``loss.backward()``, so callers see nothing new.
+# Every product is tiled, split and summed exactly as the single launch would: bitwise the same gradients.
+defer_weight_grads = False
+_deferred = []
+
+
+def _flush_weight_grads():
+    global _deferred
+    items, _deferred = _deferred, []
+    if not items:
+        return
+    lib = hip.load()
+    dev = items[0][0].device
+    with torch.cuda.device(dev):
+        # the operands were produced on the trunk's three streams: this (the caller's) stream waits for each of them once, and the
+        # caching allocator learns that their memory is read here
+        cur = torch.cuda.current_stream(dev)
+        for st in {it[3] for it in items}:
+            if st != cur:
+                cur.wait_stream(st)
+        for gy, xm, _, st in items:
+            if st != cur:
+                gy.record_stream(cur)
+                xm.record_stream(cur)
+        # waves: a weight's k-th contribution goes to wave k (problems of one call must write distinct outputs)
+        seen, waves = {}, []
+        for gy, xm, w, _ in items:
+            k = seen.get(id(w), 0)
+            seen[id(w)] = k + 1
+            while len(waves) <= k:
+                waves.append([])
+            waves[k].append((gy, xm, w))
+        out = {}
+        for k, wave in enumerate(waves):
+            arr = (hip.X3TnProblemC * len(wave))()
+            for i, (gy, xm, w) in enumerate(wave):
+                if k == 0:
+                    out[id(w)] = (w, torch.empty(w.shape, dtype=torch.float32, device=dev))
+                c = out[id(w)][1]
+                q = arr[i]
+                q.A, q.B, q.C = gy.data_ptr(), xm.data_ptr(), c.data_ptr()
+                q.lda, q.ldb, q.ldc = gy.stride(0), xm.stride(0), c.stride(0)
+                q.M, q.N, q.K = gy.shape[1], xm.shape[1], gy.shape[0]
+                q.accumulate = 1 if k > 0 else 0
+            nbytes = int(lib.ruart_gemm_x3_tn_grouped_ws(arr, len(wave)))
+            ws = _scratch(dev, nbytes // 4, "x3g") if nbytes else None
+            hip.check(lib.ruart_gemm_x3_tn_grouped(arr, len(wave), hip.ptr(ws), nbytes, hip.stream_ptr(dev)), "ruart_gemm_x3_tn_grouped")
+        for w, g in out.values():
+            if w.grad is None:
+                w.grad = g
+            else:
+                w.grad = w.grad + g
+            for hook in (getattr(w, "_post_accumulate_grad_hooks", None) or {}).values():
+                hook(w)
+
+
+def _defer_weight_grad(gy, xm, w):
+    """Record dW += gy^T xm for the end of this backward pass; False when the operands do not fit the grouped kernel."""
+    if not (gy.dim() == 2 and xm.dim() == 2 and gy.stride(1) == 1 and xm.stride(1) == 1 and w.is_leaf and w.dim() == 2
+            and w.shape == (gy.shape[1], xm.shape[1]) and gy.dtype == torch.float32 and xm.dtype == torch.float32):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    if not _deferred:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_weight_grads)
+    _deferred.append((gy, xm, w, torch.cuda.current_stream(gy.device)))
+    return True
+
+
 class _Linear(torch.autograd.Function):
     """y = (x * mask) W^T (+ b) with x (rows, K), W (N, K), mask (rows / rpm, K) or None, on ruart_gemm_x3.
     The masked input is materialised once (it is also the operand of dW = dY^T (x * mask)); the backward multiply is fused:
@@ -236,9 +310,14 @@ class _Linear(torch.autograd.Function):
     the kernel - was measured 1.5-2x slower than the separate multiply: the mask is a second load stream per element.)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, mask, rpm):
+    def forward(ctx, x, w, b, mask, rpm, wparts=None):
+        """``wparts``: [(Parameter, row0, row1), ...] when ``w`` is a concatenation of parameters along its rows (the two directions of a
+        BiLSTM input projection): deferred weight gradients are then taken per part, straight into the parameters."""
         xm = x if mask is None else (x.view(-1, rpm, x.shape[1]) * mask.unsqueeze(1)).view(x.shape)
         ctx.save_for_backward(xm, w, mask)
+        # the Parameter behind w, when w IS one (a grouped end-of-backward product writes its .grad directly, see above)
+        ctx.wparam = w if (isinstance(w, torch.nn.Parameter) and w.requires_grad) else None
+        ctx.wparts = wparts
         ctx.has_bias = b is not None
         ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm       # form of the two backward products
         ctx.rpm = rpm
@@ -248,9 +327,19 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gy):
         xm, w, mask = ctx.saved_tensors
         gx = mm(gy, w, mode=ctx.mode, c_scale=mask, rpm=ctx.rpm) if ctx.needs_input_grad[0] else None
-        gw = mm(gy.t(), xm, mode=ctx.mode) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            wp, parts = ctx.wparam, ctx.wparts
+            done = False
+            if defer_weight_grads and ctx.mode == "x3" and gy.stride(1) == 1:
+                if wp is not None:
+                    done = _defer_weight_grad(gy, xm, wp)
+                elif parts and all(p.requires_grad and p.is_leaf for p, _, _ in parts):
+                    done = all([_defer_weight_grad(gy[:, r0:r1], xm, p) for p, r0, r1 in parts])
+            if not done:
+                gw = mm(gy.t(), xm, mode=ctx.mode)
         gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class _AddMM(torch.autograd.Function):
@@ -281,7 +370,7 @@ def addmm(base, x, w):
     return _AddMM.apply(base, x.contiguous(), w)
 
 
-def linear(x, w, b=None, mask=None):
+def linear(x, w, b=None, mask=None, wparts=None):
     """F.linear for fp32 device tensors of any leading shape, through ``mm``.  ``mask`` (B, K) with x (B, T, K): variational
     dropout (x * mask[:, None, :]) applied inside the op - one multiply in the forward, none in the backward."""
     if trunk_gemm != "x3":             # exact-fp32 validation mode
@@ -298,7 +387,7 @@ def linear(x, w, b=None, mask=None):
         rpm = x.shape[1]
         mask = mask.contiguous()
     x2 = x.reshape(-1, x.shape[-1])
-    y = _Linear.apply(x2, w, b, mask, rpm)
+    y = _Linear.apply(x2, w, b, mask, rpm, wparts)
     return y.view(*lead, w.shape[0])
 
 
@@ -431,13 +520,16 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None,
     """One nn.LSTM layer (batch_first, zero state), uni- or bidirectional, on the persistent HIP recurrence.
     Parameters use torch's nn.LSTM layout so checkpoints load unchanged."""
     bidir = w_ih_r is not None
+    wparts = None
     if bidir:
         w = torch.cat([w_ih, w_ih_r], 0)
         b = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r], 0)
         whh = torch.stack([w_hh, w_hh_r], 0)
+        if isinstance(w_ih, torch.nn.Parameter) and isinstance(w_ih_r, torch.nn.Parameter):
+            wparts = [(w_ih, 0, w_ih.shape[0]), (w_ih_r, w_ih.shape[0], w.shape[0])]
     else:
         w, b, whh = w_ih, b_ih + b_hh, w_hh.unsqueeze(0)
-    xproj = linear(x, w, b, mask=mask)            # mask: the input's variational-dropout mask, fused into the projection
+    xproj = linear(x, w, b, mask=mask, wparts=wparts)   # mask: the input's variational-dropout mask, fused into the projection
     return _LstmRecurrence.apply(xproj.contiguous(), whh.contiguous(), 2 if bidir else 1)
 
 

@@ -17,6 +17,8 @@ Supported configuration: the shipped conf and its simple toggles.  Branches the 
 (img_feature, fixed_answers, ES post_process, ModelParallel, PRE_ALIGN_after_rnn, label_yesno, bidirectional
 multi2one) raise NotImplementedError - they are out of the hot path's scope.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -382,6 +384,11 @@ class SDNet(nn.Module):
         # gradients of the trunk's projections: three bf16 products like the forward ("x1": one product - measured worth only
         # 0.1-0.2 ms of a 20 ms step, these products are bound by their fp32 operand loads, so it stays an option)
         ops.trunk_grad_gemm = opt.get("ruart_trunk_grad_gemm", "x3")
+        # opt['ruart_defer_dw'] (off): record every projection's weight gradient and compute them in grouped launches at the end of
+        # backward (ops._flush_weight_grads; bitwise the same gradients, ~80 launches fewer).  Measured SLOWER, 26.9-27.0 against
+        # 25.2-25.8 ms per step on one box: the products no longer hide inside backward but land in front of the step's final sync
+        ops.defer_weight_grads = bool(self.training and torch.is_grad_enabled() and opt.get("ruart_defer_dw", os.environ.get("RUART_DEFER_DW", "0") == "1")
+                                      and not opt.get("ruart_graph_trunk", False))
         bi = self.prepare(q_list, ocr_list, od_list)
         if self.training or self.drop_emb:
             L.mask_bank.begin_step(dev)
