@@ -141,6 +141,8 @@ int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8
  * span_start_last (optional): the spans' first rows inside the LAST layer's matrix when ruart_bert_forward left it compacted
  * (ruart_bert_batch.last_rows); NULL = the same rows as in every other layer.
  * Rows of `out` that no word maps to are left untouched (the caller zero-fills: masked words are zeros). */
+/* forward kernel form: 1 (default) = workgroup split along the columns (no cross-wave sum) where H % 256 == 0; 0 = split along layers */
+int ruart_bert_pool_set_variant(int cols);
 int ruart_bert_pool_mix(const void* layers, long long layer_stride, int ldl, int dtype, int n_layers, const int* span_start,
                         const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo,
                         int n_words, int H, void* stream);

@@ -12,6 +12,7 @@
 // All math is fp32; storage type T of activations is float (validation mode) or bf16.
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 #include "ruart_hip.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -745,35 +746,40 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
     acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     col[i] = min((i * 64 + lane) * 4, H - 4);
   }
-  for (int lb = l0; lb < l1; lb += POOL_LPB) {
-    f32x4_t v[POOL_LPB][2][NG];
-    float wgt[POOL_LPB];
+  // n is the same for the whole workgroup: one-piece words (half of them at ST-VQA item lengths) take the path without the second
+  // row's loads (the first version loaded piece 0 twice with weight 0: a quarter of the kernel's L2 traffic for nothing)
+  auto body = [&](auto two_tag) {
+    constexpr bool TWO = decltype(two_tag)::value;
+    for (int lb = l0; lb < l1; lb += POOL_LPB) {
+      f32x4_t v[POOL_LPB][TWO ? 2 : 1][NG];
+      float wgt[POOL_LPB];
 #pragma unroll
-    for (int j = 0; j < POOL_LPB; ++j) {
-      const int l = min(lb + j, l1 - 1);
-      wgt[j] = (lb + j < l1) ? wl[l] * inv : 0.f;
-      const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
-      const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
+      for (int j = 0; j < POOL_LPB; ++j) {
+        const int l = min(lb + j, l1 - 1);
+        wgt[j] = (lb + j < l1) ? wl[l] * inv : 0.f;
+        const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
 #pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        v[j][0][i] = load4(base + col[i]);
-        v[j][1][i] = load4(base1 + col[i]);
+        for (int i = 0; i < NG; ++i) {
+          v[j][0][i] = load4(base + col[i]);
+          if (TWO) v[j][TWO ? 1 : 0][i] = load4(base + (size_t)ldl + col[i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < POOL_LPB; ++j)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) acc[i] += (TWO ? v[j][0][i] + v[j][TWO ? 1 : 0][i] : v[j][0][i]) * wgt[j];
+      if (TWO && n > 2) {                                 // rare: words of three or more pieces
+        for (int j = 0; j < POOL_LPB && lb + j < l1; ++j) {
+          const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
+          for (int p = 2; p < n; ++p)
+#pragma unroll
+            for (int i = 0; i < NG; ++i) acc[i] += load4(base + (size_t)p * ldl + col[i]) * wgt[j];
+        }
       }
     }
-    const float two = n > 1 ? 1.f : 0.f;
-#pragma unroll
-    for (int j = 0; j < POOL_LPB; ++j)
-#pragma unroll
-      for (int i = 0; i < NG; ++i) acc[i] += (v[j][0][i] + v[j][1][i] * two) * wgt[j];
-    if (n > 2) {                                        // rare: words of three or more pieces
-      for (int j = 0; j < POOL_LPB && lb + j < l1; ++j) {
-        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
-        for (int p = 2; p < n; ++p)
-#pragma unroll
-          for (int i = 0; i < NG; ++i) acc[i] += load4(base + (size_t)p * ldl + col[i]) * wgt[j];
-      }
-    }
-  }
+  };
+  if (n > 1) body(std::true_type{});
+  else body(std::false_type{});
   if (wv > 0) {
 #pragma unroll
     for (int i = 0; i < NG; ++i) *reinterpret_cast<f32x4_t*>(&red[wv - 1][(i * 64 + lane) * 4]) = acc[i];
@@ -790,6 +796,50 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
       if (c < H) store4(o + c, r);
     }
   }
+}
+
+// The same op with the workgroup cut along the COLUMNS instead of the layers: wave g owns columns 256 g .. 256 g + 255 of the word's row
+// for all layers, so nothing is exchanged - no LDS image, no barrier, no wave waiting for the slowest of four (the layer-split form
+// above sits at 3.1 TB/s against 4.6 for its own backward, which has the same reads and no cross-wave sum).  Six layers' loads (x one
+// or two pieces) are in flight per lane at a time.  Used when H is a multiple of 256 (bert-base / bert-large).
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mix_cols_kernel(const T* __restrict__ layers, size_t layer_stride, int ldl, int NL,
+                                                            const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                            const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                            const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H) {
+  constexpr int LB = 6;
+  const int w = blockIdx.x;
+  const int st = span_start[w], n = span_len[w];
+  const int st_last = span_start_last ? span_start_last[w] : st;
+  const float inv = 1.0f / (float)n;
+  const int col = threadIdx.x * 4;                       // blockDim.x = H / 4
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  auto body = [&](auto two_tag) {
+    constexpr bool TWO = decltype(two_tag)::value;
+    for (int lb = 0; lb < NL; lb += LB) {
+      f32x4_t v[LB][TWO ? 2 : 1];
+      float wgt[LB];
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int l = min(lb + j, NL - 1);
+        wgt[j] = (lb + j < NL) ? wl[l] * inv : 0.f;
+        const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl + col;
+        v[j][0] = load4(base);
+        if (TWO) v[j][TWO ? 1 : 0] = load4(base + (size_t)ldl);
+      }
+#pragma unroll
+      for (int j = 0; j < LB; ++j) acc += (TWO ? v[j][0] + v[j][TWO ? 1 : 0] : v[j][0]) * wgt[j];
+      if (TWO && n > 2) {
+        for (int j = 0; j < LB && lb + j < NL; ++j) {
+          const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl + col;
+          for (int p = 2; p < n; ++p) acc += load4(base + (size_t)p * ldl) * wgt[j];
+        }
+      }
+    }
+  };
+  if (n > 1) body(std::true_type{});
+  else body(std::false_type{});
+  store4(out + (size_t)dst_row[w] * ldo + col, acc);
 }
 
 // d(loss)/d(wl[l]) partial of one word: <grad_out[dst_row[w]], mean of the word's rows of layer l>; partial[w * NL + l].
@@ -816,35 +866,38 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__
     gv[i] = load4(g + col[i]);
     if (c >= H) gv[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // lanes past the row's end contribute nothing
   }
-  for (int lb = l0; lb < l1; lb += POOL_LPB) {
-    f32x4_t v[POOL_LPB][2][NG];
+  auto body = [&](auto two_tag) {                        // see pool_mix_kernel: one-piece words skip the second row's loads
+    constexpr bool TWO = decltype(two_tag)::value;
+    for (int lb = l0; lb < l1; lb += POOL_LPB) {
+      f32x4_t v[POOL_LPB][TWO ? 2 : 1][NG];
 #pragma unroll
-    for (int j = 0; j < POOL_LPB; ++j) {
-      const int l = min(lb + j, l1 - 1);
-      const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
-      const T* base1 = base + (n > 1 ? (size_t)ldl : 0);
+      for (int j = 0; j < POOL_LPB; ++j) {
+        const int l = min(lb + j, l1 - 1);
+        const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
 #pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        v[j][0][i] = load4(base + col[i]);
-        v[j][1][i] = load4(base1 + col[i]);
+        for (int i = 0; i < NG; ++i) {
+          v[j][0][i] = load4(base + col[i]);
+          if (TWO) v[j][TWO ? 1 : 0][i] = load4(base + (size_t)ldl + col[i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < POOL_LPB; ++j) {
+        f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NG; ++i) s4 += (TWO ? v[j][0][i] + v[j][TWO ? 1 : 0][i] : v[j][0][i]) * gv[i];
+        if (TWO && n > 2 && lb + j < l1) {
+          const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
+          for (int p = 2; p < n; ++p)
+#pragma unroll
+            for (int i = 0; i < NG; ++i) s4 += load4(base + (size_t)p * ldl + col[i]) * gv[i];
+        }
+        const float d = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) * inv;
+        if (lane == 0 && lb + j < l1) partial[(size_t)w * NL + lb + j] = d;
       }
     }
-    const float two = n > 1 ? 1.f : 0.f;
-#pragma unroll
-    for (int j = 0; j < POOL_LPB; ++j) {
-      f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < NG; ++i) s4 += (v[j][0][i] + v[j][1][i] * two) * gv[i];
-      if (n > 2 && lb + j < l1) {
-        const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
-        for (int p = 2; p < n; ++p)
-#pragma unroll
-          for (int i = 0; i < NG; ++i) s4 += load4(base + (size_t)p * ldl + col[i]) * gv[i];
-      }
-      const float d = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) * inv;
-      if (lane == 0 && lb + j < l1) partial[(size_t)w * NL + lb + j] = d;
-    }
-  }
+  };
+  if (n > 1) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nrows, int NL, float* __restrict__ out) {
@@ -971,10 +1024,21 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
   return 0;
 }
 
+static int g_pool_cols = 1;        // 1: column-split pooling kernel where H % 256 == 0 (default); 0: the layer-split form (A/B runs)
+extern "C" int ruart_bert_pool_set_variant(int cols) {
+  g_pool_cols = cols ? 1 : 0;
+  return 0;
+}
+
 template <typename T>
 static void launch_pool(const void* layers, long long layer_stride, int ldl, int n_layers, const int* span_start, const int* span_start_last,
                         const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo, int n_words, int H, hipStream_t st) {
   const dim3 grid(n_words), block(256);
+  if (H % 256 == 0 && g_pool_cols) {
+    hipLaunchKernelGGL((pool_mix_cols_kernel<T>), grid, dim3(H / 4), 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start,
+                       span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H);
+    return;
+  }
 #define POOL(NG) hipLaunchKernelGGL((pool_mix_kernel<T, NG>), grid, block, 0, st, (const T*)layers, (size_t)layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H)
   switch ((H + 255) / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
 #undef POOL

@@ -734,6 +734,7 @@ extern "C" int ruart_gemm_set_stamps(unsigned long long* p) {
   RUART_ENTRY(); g_p8_stamps = p; return 0; }
 #endif
 int g_tile_order = 8;            // GROUP_M of the tile walk (0 = plain row-major); tuning knob, see ruart_gemm_set_tile_order
+int g_tile_order_auto = 1;       // the fp16c kernel picks GROUP_M per shape until ruart_gemm_set_tile_order is called (gemm_corr.hip)
 int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row count (the GEMM itself runs on padded rows)
 
 extern int g_gemm_variant;
@@ -741,6 +742,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
   RUART_ENTRY();
   if (group_m < 0 || group_m > 64) return (int)hipErrorInvalidValue;
   g_tile_order = group_m;
+  g_tile_order_auto = 0;
   return 0;
 }
 extern "C" int ruart_gemm_set_variant(int v) {

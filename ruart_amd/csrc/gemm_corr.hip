@@ -274,7 +274,17 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
   }
 }
 
-extern int g_tile_order;
+extern int g_tile_order, g_tile_order_auto;
+// GROUP_M of the tile walk per projection shape (measured, tools/gemm_corr_order_sweep.py, 42 880 rows, three interleaved runs on one
+// box, profiles/r03_gemm_order_sweep_time.log): wide outputs want tall groups (QKV N = 2304: 269 us at 16 against 283 at 8; FF1
+// N = 3072: 405 against 413), the long-K output dense a short one (FF2 K = 3072: 327 at 6 against 331), N = K = 768 stays at 8.
+// L2-miss traffic moves the OTHER way (smallest at GROUP_M 2-3, profiles/r03_gemm_order_sweep_fetch.log): it is not what bounds
+// this kernel.  An explicit ruart_gemm_set_tile_order overrides.
+static inline int corr_tile_order(int N, int K) {
+  if (!g_tile_order_auto) return g_tile_order;
+  if (N >= 2048) return 16;
+  return K >= 2048 ? 6 : 8;
+}
 void* ruart_prof_begin_(hipStream_t s, int M, int N, int K);
 void ruart_prof_end_(void* rec, hipStream_t s);
 
@@ -288,7 +298,7 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3((M / CBM) * (N / CBN)), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
-                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, g_tile_order, n8, o8);
+                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, corr_tile_order(N, K), n8, o8);
 }
 
 extern "C" int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,

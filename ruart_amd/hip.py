@@ -89,6 +89,7 @@ _SIGNATURES = {
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_bert_attention": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "ruart_bert_pool_set_variant": (_I, [_I]),
     "ruart_bert_pool_mix": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_pool_mix_bwd": (_I, [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_rows_gather": (_I, [_P, _I, _P, _LL, _P, _LL, _I, _P, _LL, _P, _LL, _I, _P, _LL, _P, _LL, _I, _P]),
