@@ -522,24 +522,35 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
     const int tn = min(64, k1 - kt);
     __syncthreads();
     {
-      frag_t kh[2], kl[2], vh[2], vl[2];
-      if (srow < tn) {
-        const float* kp = qkv + (size_t)(kt + srow) * ld + H + h * 64 + sc0 * 8;
+      // staging K and V: lane -> (row 16 wave + 4 i + lane / 16, 16-byte piece lane % 16): one load instruction covers four whole
+      // 256-byte row slices (8 cache lines, every byte used) where the first form - a lane taking 64 contiguous bytes in four
+      // loads - touched 32 lines per instruction, four times over
+      const int prow = lane >> 4, piece = lane & 15;
+      f32x4_t kx[4], vx[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          split_f16x8(load4(kp + c * 8), load4(kp + c * 8 + 4), kh[c], kl[c]);
-          split_f16x8(load4(kp + H + c * 8), load4(kp + H + c * 8 + 4), vh[c], vl[c]);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) kh[c] = kl[c] = vh[c] = vl[c] = (frag_t){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 16 + i * 4 + prow;
+        const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
+        kx[i] = load4(kp);
+        vx[i] = load4(kp + H);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        *reinterpret_cast<frag_t*>(Kh + srow * RS + (sc0 + c) * 16) = kh[c];
-        *reinterpret_cast<frag_t*>(Kl + srow * RS + (sc0 + c) * 16) = kl[c];
-        *reinterpret_cast<frag_t*>(Vh + srow * RS + (sc0 + c) * 16) = vh[c];
-        *reinterpret_cast<frag_t*>(Vl + srow * RS + (sc0 + c) * 16) = vl[c];
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 16 + i * 4 + prow;
+        if (row >= tn) kx[i] = vx[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};       // rows past the window: zero keys / values
+        f16x4_t kh4, kl4, vh4, vl4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kh4[e] = (f16_t)kx[i][e];
+          kl4[e] = (f16_t)(kx[i][e] - (float)kh4[e]);
+          vh4[e] = (f16_t)vx[i][e];
+          vl4[e] = (f16_t)(vx[i][e] - (float)vh4[e]);
+        }
+        const int off = row * RS + piece * 8;
+        *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
+        *reinterpret_cast<f16x4_t*>(Kl + off) = kl4;
+        *reinterpret_cast<f16x4_t*>(Vh + off) = vh4;
+        *reinterpret_cast<f16x4_t*>(Vl + off) = vl4;
       }
       if (tid < 64) {
         const bool in = tid < tn;

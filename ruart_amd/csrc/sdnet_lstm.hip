@@ -276,13 +276,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (!(RUART_LSTM_ABL & 8)) {
+      // (consecutive MFMAs never touch the same accumulator: a dependent pair stalls for the matrix pipe's latency)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[i] = mfma_16x16x32(wl[i][ks], hh[ks], acc[i]);       // small terms first
-          acc[i] = mfma_16x16x32(wh[i][ks], hl[ks], acc[i]);
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = mfma_16x16x32(wl[i][ks], hh[ks], acc[i]);       // small terms first
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = mfma_16x16x32(wh[i][ks], hl[ks], acc[i]);
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -353,29 +354,34 @@ __global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(const float* __restr
 __global__ __launch_bounds__(512) void lstm_bwd_mfma_kernel(const float* __restrict__ grad_y, const float* __restrict__ w_hh,
                                                             const float* __restrict__ gates, const float* __restrict__ cells,
                                                             float* __restrict__ grad_xproj, int B, int T, int h, int ndir) {
-  __shared__ __attribute__((aligned(16))) char daimg[2][2][LRB * LDS_DA];    // [buffer][hi | lo], 66 KB
+  // dh_{t-1} (16 rows x 128 positions) = da_t (16 x 512 positions) . W^T.  Each wave contracts over ITS OWN 64 positions - whose da it
+  // has just computed, in registers: the second MFMA operand of k-step j is the lane's own da of gate types 2j and 2j + 1 for its four
+  // units, no LDS image of da at all - for ALL 128 output positions (8 tiles), and the eight waves' partial sums meet in LDS: 8 KB
+  // written and 8 KB read per wave and step (the first form had every wave read the whole 32 KB da image: 256 KB of LDS reads per step).
+  __shared__ __attribute__((aligned(16))) float part[2][8][8][64 * 4];      // [buffer][producer wave][output tile][lane x 4], 128 KB
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int G = 4 * h;
-  // W_hh^T fragments: first operand of k-step ks (16 of them) = output position (w, fr) -> unit(w, fr); contraction index
-  // p = 32 ks + 8 fq + e = 64 w' + 16 type + m  <->  gate row type*h + unit(w', m); duplicate positions (w', m) carry zero weights
-  bf16x8_t wh[16], wl[16];
+  // W_hh^T fragments: first operand of (output tile t8, k-step j) = output position (t8, fr) -> unit(t8, fr); contraction element e of
+  // lane group fq = gate type 2j + (e >> 2) of this wave's position 4 fq + (e & 3); duplicate contraction positions carry zero weights
+  bf16x8_t wh[8][2], wl[8][2];
   {
-    const int unit = lstm_unit(w, fr, h);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
+    for (int t8 = 0; t8 < 8; ++t8) {
+      const int unit = lstm_unit(t8, fr, h);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int p = ks * 32 + fq * 8 + e;
-        const int wp = p >> 6, type = (p >> 4) & 3, m = p & 15;
-        const int gu = lstm_unit(wp, m, h);
-        const bool counted = lstm_counted(16 * wp + m, h);
-        const float v = counted ? w_hh[((size_t)d * G + (size_t)type * h + gu) * h + unit] : 0.f;
-        bf16_t a, b;
-        split_bf16_(v, a, b);
-        wh[ks][e] = a;
-        wl[ks][e] = b;
-      }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int type = 2 * j + (e >> 2), m = 4 * fq + (e & 3);
+          const int gu = lstm_unit(w, m, h);
+          const float v = lstm_counted(16 * w + m, h) ? w_hh[((size_t)d * G + (size_t)type * h + gu) * h + unit] : 0.f;
+          bf16_t a, b;
+          split_bf16_(v, a, b);
+          wh[t8][j][e] = a;
+          wl[t8][j][e] = b;
+        }
+    }
   }
   const int b = min((int)blockIdx.x * LRB + fr, B - 1);
   const int u0 = min(16 * w + 4 * fq, h - 4);
@@ -405,8 +411,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_mfma_kernel(const float* __restr
   StepIn in, nxt;
   load_step(T > 1, in);
   nxt = in;
-  int cur = 0;
-  for (int s = 0; s < T; ++s, cur ^= 1) {
+  for (int s = 0; s < T; ++s) {
     gp += sx;
     cp_ += sy;
     gyp += sy;
@@ -424,39 +429,47 @@ __global__ __launch_bounds__(512) void lstm_bwd_mfma_kernel(const float* __restr
       da[3][r] = dh * tc * in.og[r] * (1.f - in.og[r]);
       dc_next[r] = dc * in.fg[r];
     }
-    // da as the second MFMA operand: row fr, position p = 64 w + 16 type + 4 fq + r
+    // da as the second MFMA operand of k-step j: [type 2j: units 0..3 | type 2j + 1: units 0..3] of this lane, hi and lo
+    bf16x8_t dh_[2], dl_[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16x4_t vh, vl;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int e = 0; e < 8; ++e) {
         bf16_t a, bb;
-        split_bf16_(da[i][r], a, bb);
-        vh[r] = a;
-        vl[r] = bb;
+        split_bf16_(da[2 * j + (e >> 2)][e & 3], a, bb);
+        dh_[j][e] = a;
+        dl_[j][e] = bb;
       }
-      const int off = fr * LDS_DA + (64 * w + 16 * i + 4 * fq) * 2;
-      *reinterpret_cast<bf16x4_t*>(&daimg[cur][0][off]) = vh;
-      *reinterpret_cast<bf16x4_t*>(&daimg[cur][1][off]) = vl;
+    f32x4_t acc[8];
+#pragma unroll
+    for (int t8 = 0; t8 < 8; ++t8) acc[t8] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                     // (consecutive MFMAs never touch the same accumulator)
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8) acc[t8] = mfma_16x16x32(wl[t8][j], dh_[j], acc[t8]);       // small terms first
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8) acc[t8] = mfma_16x16x32(wh[t8][j], dl_[j], acc[t8]);
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8) acc[t8] = mfma_16x16x32(wh[t8][j], dh_[j], acc[t8]);
+    float* mine = &part[s & 1][w][0][lane * 4];
+#pragma unroll
+    for (int t8 = 0; t8 < 8; ++t8) *reinterpret_cast<f32x4_t*>(mine + t8 * 256) = acc[t8];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next step's operands in registers before this step's stores are issued
     in = nxt;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_u*>(gx + (size_t)i * h) = (f32x4_u){da[i][0], da[i][1], da[i][2], da[i][3]};
     gx += sx;
-    __syncthreads();                                   // (double-buffered: the next step writes the other image)
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                   // (double-buffered: the next step writes the other half)
+    // dh of this wave's output tile: the eight waves' partial sums, in wave order
+    f32x4_t sum = *reinterpret_cast<const f32x4_t*>(&part[s & 1][0][w][lane * 4]);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const bf16x8_t dh_ = *reinterpret_cast<const bf16x8_t*>(&daimg[cur][0][fr * LDS_DA + (ks * 32 + fq * 8) * 2]);
-      const bf16x8_t dl_ = *reinterpret_cast<const bf16x8_t*>(&daimg[cur][1][fr * LDS_DA + (ks * 32 + fq * 8) * 2]);
-      acc2 = mfma_16x16x32(wl[ks], dh_, acc2);         // the two small products in their own accumulator ...
-      acc2 = mfma_16x16x32(wh[ks], dl_, acc2);
-      acc = mfma_16x16x32(wh[ks], dh_, acc);
-    }
+    for (int pw = 1; pw < 8; ++pw) sum += *reinterpret_cast<const f32x4_t*>(&part[s & 1][pw][w][lane * 4]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dh_rec[r] = acc[r] + acc2[r];     // ... added last
+    for (int r = 0; r < 4; ++r) dh_rec[r] = sum[r];
   }
 }
 
