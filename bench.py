@@ -138,6 +138,7 @@ def cpu_baseline(opt, cfg, n_samples, seed=1033):
             "sample": "%d sample(s) of the bench workload (q=30, ocr=100, obj=36, bert-base), fwd+loss+bwd: 1 warm-up run, median of 3 "
                       "(%.1f / %.1f / %.1f s)" % (n_samples, times[0], times[1], times[2]),
             "reference_itself": {"value": 0.312, "unit": "samples/s", "threads": 8, "samples": 4,
+                                 "measured": "once, in the build container, round 1 - a constant of this file, NOT timed in this run",
                                  "where": "build container - the reference cannot travel to the GPU box; the oracle ran 0.374 samples/s "
                                           "beside it, outputs equal to 1.7e-6", "source": "oracle/time_reference.py"}}
 
@@ -173,6 +174,8 @@ def bert512_measure(a, device, lib, precision, batch=64, steps=None, warmup=None
     warmup = a.warmup if warmup is None else warmup
     cfg = synth.bert_config()
     W = BertEncoderWeights(synth.make_bert_weights(cfg, seed=1033, w_std=0.02), cfg, device, precision)
+    if os.environ.get("RUART_TILE_ORDER"):              # experiments: GROUP_M of the encoder GEMM's tile walk
+        hip.check(lib.ruart_gemm_set_tile_order(int(os.environ["RUART_TILE_ORDER"])), "set_tile_order")
     L = a.seq_len
     ids = torch.randint(1000, cfg["vocab_size"], (batch, L))
     flops = batch * L * (169869312 + 36864 * L)
