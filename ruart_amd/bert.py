@@ -48,7 +48,10 @@ def split_f16c(x, lo_shift=None, hi_shift=None):
 class BertEncoderWeights:
     """Device-resident encoder weights in the layout ruart_bert_forward expects."""
 
-    def __init__(self, state, cfg, device, dtype="fp16"):
+    def __init__(self, state, cfg, device, dtype="fp16", check_range=True):
+        """``check_range`` (fp16c): warn at load time when a projection weight exceeds the fp8 correction operand's range (one host
+        sync per matrix; off for the trainable encoder's per-step operand rebuilds)."""
+        self._check_range = check_range
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self.precision = dtype
@@ -63,7 +66,10 @@ class BertEncoderWeights:
         pre = "bert." if any(k.startswith("bert.") for k in state) else ""
 
         def f32(name):
-            return torch.as_tensor(_np(state[pre + name]), dtype=torch.float32).to(self.device).contiguous()
+            t = state[pre + name]
+            if isinstance(t, torch.Tensor) and t.is_cuda:      # live parameters of the trainable encoder: no host round trip
+                return t.detach().to(self.device, torch.float32).contiguous()
+            return torch.as_tensor(_np(t), dtype=torch.float32).to(self.device).contiguous()
 
         def gemm_w(t):
             return t.to(wdtype).contiguous()
@@ -71,7 +77,8 @@ class BertEncoderWeights:
         def gemm_w8(t):
             """(out, 2 in) e4m3 companion of a weight matrix: [fp8(f16(w) 2^7) | fp8((w - f16(w)) 2^18)] (common.h)."""
             hi = t.to(torch.float16).to(torch.float32)
-            self._w_absmax = max(getattr(self, "_w_absmax", 0.0), float(t.abs().max()))      # load time: one sync per matrix
+            if self._check_range:
+                self._w_absmax = max(getattr(self, "_w_absmax", 0.0), float(t.abs().max()))      # load time: one sync per matrix
             _, _, sw_hi, sw_lo = hip.f16c_shifts()
             pair = torch.cat([hi * float(2.0 ** sw_hi), (t - hi) * float(2.0 ** sw_lo)], 1).clamp_(-448.0, 448.0)
             return pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
@@ -478,6 +485,8 @@ class Bert(nn.Module):
             # the whole encoder, forward and backward, as one autograd Function over 16-bit kernels (bert_train16.py)
             from .bert_train16 import BertModelTrainable16
             self.bert_model = BertModelTrainable16(state, cfg, self._device)
+            # passes without active dropout (evaluation, parity tests) on the frozen path's fp16c kernels: 1e-3 with the encoder unlocked
+            self.bert_model.accurate_forward = bool(self.opt.get("bert_train_accurate_fwd", True))
         else:
             # "x3": fp32-class graph (pins parity); "16gemm": the same graph with the two row-parallel products of every projection on
             # the frozen path's 16-bit MFMA GEMM

@@ -122,48 +122,85 @@ class _Run:
             out.append(w16)
             back.append(wT)
         _chk(self.lib.ruart_weight_prep_batch(items, 6, self._st()), "ruart_weight_prep_batch")      # the layer's six weights, one launch
-        self.wT.append(back)
+        self.wT[l] = back
         return out
 
-    # -- forward -------------------------------------------------------------------------------------------------------------
-    def forward(self, layer_w):
-        P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
-        pk = self.packed
-        st = self._st
+    def _layer_fwd(self, l, x16, out16):
+        """One encoder layer on the f16 kernels: x16 (Tp, H) -> out16; returns what its backward reads (QKV rows, context, both LayerNorm
+        inputs + statistics, the post-attention stream, the intermediate pre-activation) and leaves the layer's transposed bf16 weights
+        in ``self.wT[l]``.  Called by the forward - or, in recompute mode, by the backward just before the layer's own backward."""
+        P, lib, Tp, H, I = self.P, self.lib, self.Tp, self.H, self.I
+        pk, st = self.packed, self._st
         scale = 1.0 / float(np.sqrt(H // self.nh))
+        pre = "encoder.layer.%d." % l
+        a = pre + "attention.self."
+        b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0)
+        wq16, wo16, w1_16, w2_16 = self._prep_weights(l, scale)
+        qkv = self._gemm(x16, wq16, b_qkv, self._new(Tp, 3 * H, torch.float16), hip.DT_F16)
+        ctx = self._new(Tp, H, torch.float16, zero=True)
+        _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, pk.n_blocks, hip.ptr(pk.blk[0]), hip.ptr(pk.blk[1]),
+                                      hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_fwd")
+        ao = self._gemm(ctx, wo16, P[pre + "attention.output.dense.bias"], self._new(Tp, H, torch.float32), hip.DT_F16)
+        mid, pre1, st1 = self._ln_fwd(ao, x16, P[pre + "attention.output.LayerNorm.gamma"], P[pre + "attention.output.LayerNorm.beta"],
+                                      self.p_h, self._seed(l, 1))
+        h16, g16 = self._new(Tp, I, torch.float16), self._new(Tp, I, torch.float16)
+        _chk(lib.ruart_gemm_16_nt_gelu2(hip.ptr(mid), H, hip.ptr(w1_16), H, hip.ptr(P[pre + "intermediate.dense.bias"]), hip.ptr(h16), hip.ptr(g16),
+                                        I, Tp, I, H, hip.DT_F16, st()), "ruart_gemm_16_nt_gelu2")
+        ff = self._gemm(g16, w2_16, P[pre + "output.dense.bias"], ao, hip.DT_F16)           # reuses the fp32 buffer
+        del g16
+        _, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
+                                    self._seed(l, 2), out=out16)
+        return (qkv, ctx, pre1, st1, mid, h16, pre2, st2)
+
+    def _embed_fwd(self):
+        """embeddings -> LayerNorm -> dropout on the f16 kernels: (x16, LayerNorm input f16, statistics)"""
+        P, T, Tp, H, pk = self.P, self.T, self.Tp, self.H, self.packed
         ids, pos = pk.ids[:T].long(), pk.pos[:T].long()
         e = torch.zeros(Tp, H, dtype=torch.float32, device=self.dev)
         e[:T] = (F.embedding(ids, P["embeddings.word_embeddings.weight"]) + F.embedding(pos, P["embeddings.position_embeddings.weight"])) \
             + P["embeddings.token_type_embeddings.weight"][0]
-        x16, self.pre_e, self.st_e = self._ln_fwd(e, None, P["embeddings.LayerNorm.gamma"], P["embeddings.LayerNorm.beta"], self.p_h,
-                                                  self._seed(-1, 0), post=1)
-        del e
+        return self._ln_fwd(e, None, P["embeddings.LayerNorm.gamma"], P["embeddings.LayerNorm.beta"], self.p_h, self._seed(-1, 0), post=1)
+
+    # -- the accurate forward: fp16c kernels of the frozen path on the live parameters -------------------------------------------
+    def _forward_accurate(self, layer_w):
+        """A pass WITHOUT active dropout (evaluation, and the parity tests: Models/Bert/modeling.py's dropouts are identities there) is
+        the frozen encoder's computation on the current parameters - so it runs on the frozen path's kernels in its fp16c precision
+        (f16 MFMA products + fp8 correction, fp32 residual stream): the answer probabilities then hold the 1e-3 of the north star with
+        the encoder unlocked too (plain f16 operands: 1.7e-3).  Nothing but the layer outputs is kept (f16, 0.8 GB at the bench shape
+        instead of 9.9 GB): the backward recomputes each layer's activations on the f16 training kernels right before it needs them."""
+        from .bert import _Buffers, bert_encode
+        lib, T, Tp, H, NL = self.lib, self.T, self.Tp, self.H, self.NL
+        W = self.m.accurate_weights()
+        bufs = self.m.__dict__.setdefault("_acc_buffers", _Buffers())
+        layers32 = bert_encode(W, self.packed, bufs)                    # (NL, Tp, H) fp32; aliases a reusable buffer: consumed below
+        self.layers = torch.empty(NL, Tp, H, dtype=torch.float16, device=self.dev)
+        _chk(lib.ruart_cast_f32_to_16(hip.ptr(layers32), hip.ptr(self.layers), hip.DT_F16, NL * Tp * H, 1.0, self._st()), "ruart_cast_f32_to_16")
+        self.recompute = True
+        self.saved, self.wT = {}, {}
+        if layer_w is None:
+            return self.layers
+        self.lw = layer_w.detach().to(torch.float32).contiguous()
+        mixed = torch.zeros(Tp, H, dtype=torch.float32, device=self.dev)
+        for l in range(NL):
+            mixed.addcmul_(layers32[l], self.lw[l])
+        return mixed[:T]
+
+    # -- forward -------------------------------------------------------------------------------------------------------------
+    def forward(self, layer_w):
+        P, lib, T, Tp, H, I, NL = self.P, self.lib, self.T, self.Tp, self.H, self.I, self.NL
+        st = self._st
+        self.recompute = False
+        if self.p_h == 0.0 and self.p_a == 0.0 and self.m.accurate_forward:
+            return self._forward_accurate(layer_w)
+        x16, self.pre_e, self.st_e = self._embed_fwd()
         self.x_in = x16                                               # input of layer 0
         self.layers = torch.empty(NL, Tp, H, dtype=torch.float16, device=self.dev)
-        self.saved = []
-        self.wT = []
-        blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
+        self.saved = {}
+        self.wT = {}
         for l in range(NL):
-            pre = "encoder.layer.%d." % l
-            a = pre + "attention.self."
-            b_qkv = torch.cat([P[a + "query.bias"] * scale, P[a + "key.bias"], P[a + "value.bias"]], 0)
-            wq16, wo16, w1_16, w2_16 = self._prep_weights(l, scale)
-            qkv = self._gemm(x16, wq16, b_qkv, self._new(Tp, 3 * H, torch.float16), hip.DT_F16)
-            ctx = self._new(Tp, H, torch.float16, zero=True)
-            _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0), hip.ptr(blk_q1),
-                                          hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_fwd")
-            ao = self._gemm(ctx, wo16, P[pre + "attention.output.dense.bias"], self._new(Tp, H, torch.float32), hip.DT_F16)
-            mid, pre1, st1 = self._ln_fwd(ao, x16, P[pre + "attention.output.LayerNorm.gamma"], P[pre + "attention.output.LayerNorm.beta"],
-                                          self.p_h, self._seed(l, 1))
-            h16, g16 = self._new(Tp, I, torch.float16), self._new(Tp, I, torch.float16)
-            _chk(lib.ruart_gemm_16_nt_gelu2(hip.ptr(mid), H, hip.ptr(w1_16), H, hip.ptr(P[pre + "intermediate.dense.bias"]), hip.ptr(h16), hip.ptr(g16),
-                                            I, Tp, I, H, hip.DT_F16, st()), "ruart_gemm_16_nt_gelu2")
-            ff = self._gemm(g16, w2_16, P[pre + "output.dense.bias"], ao, hip.DT_F16)           # reuses the fp32 buffer
-            del g16
-            _, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
-                                        self._seed(l, 2), out=self.layers[l])
+            saved = self._layer_fwd(l, x16, self.layers[l])
             if self.keep:
-                self.saved.append((qkv, ctx, pre1, st1, mid, h16, pre2, st2))
+                self.saved[l] = saved
             x16 = self.layers[l]
         if layer_w is None:
             return self.layers                                        # frozen-encoder use: every layer output, no mix
@@ -234,11 +271,16 @@ class _Run:
         dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
         dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
         blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
+        if self.recompute:                                                               # (accurate forward: only layer outputs were kept)
+            self.x_in, self.pre_e, self.st_e = self._embed_fwd()
+            scratch = self._new(Tp, H, torch.float16)
         for l in range(NL - 1, -1, -1):
             pre = "encoder.layer.%d." % l
             a = pre + "attention.self."
-            qkv, ctx, pre1, st1, mid, h16, pre2, st2 = self.saved[l]
             x16 = self.layers[l - 1] if l > 0 else self.x_in
+            if self.recompute:
+                self.saved[l] = self._layer_fwd(l, x16, scratch)      # this layer's activations again, on the f16 kernels
+            qkv, ctx, pre1, st1, mid, h16, pre2, st2 = self.saved[l]
             # ---- output LayerNorm (+ the layer-mix gradient of this layer's output) and the FFN
             d_res2, d_g2, dg2, db2, dbias2 = self._ln_bwd(dX, G, self.lw[l:l + 1], pre2, st2, P[pre + "output.LayerNorm.gamma"], self.p_h,
                                                           self._seed(l, 2))
@@ -275,7 +317,8 @@ class _Run:
             grads[a + "query.weight"], grads[a + "key.weight"], grads[a + "value.weight"] = self._dw(
                 dqkv, self._bf16(x16), row_scales=[(H, scale), (H, 1.0), (H, 1.0)])
             dX = self._gemm(dqkv, w_qkv_t, None, self._new(Tp, H, torch.float32), hip.DT_BF16, res=d_res1)
-            self.saved[l] = self.wT[l] = None                                             # release this layer's activations
+            self.saved.pop(l, None)                                                       # release this layer's activations
+            self.wT.pop(l, None)
         # ---- embeddings: dropout(LayerNorm(word + position + type))
         d_e, _, dge, dbe, _ = self._ln_bwd(dX, None, None, self.pre_e, self.st_e, P["embeddings.LayerNorm.gamma"], self.p_h, self._seed(-1, 0), post=1)
         grads["embeddings.LayerNorm.gamma"], grads["embeddings.LayerNorm.beta"] = dge, dbe
@@ -321,8 +364,27 @@ class BertModelTrainable16(BertModelTrainable):
         if missing:
             raise ValueError("checkpoint lacks encoder tensors: %s" % missing[:3])
 
+    accurate_forward = True          # passes without active dropout run the frozen path's fp16c kernels (bert.Bert.unlock sets it from opt)
+
+    def accurate_weights(self):
+        """The live parameters as the frozen path's operand set (f16 + e4m3 companions), rebuilt only when a parameter has changed."""
+        from .bert import BertEncoderWeights
+        key = tuple(self._p[n]._version for n in self._order) + tuple(self._p[n].data_ptr() for n in self._order[:2])
+        ent = self.__dict__.get("_acc_weights")
+        if ent is None or ent[0] != key:
+            state = {n: self._p[n] for n in self._p}
+            dev = self._p[self._order[0]].device
+            ent = (key, BertEncoderWeights(state, self.cfg, dev, "fp16c", check_range=False))
+            self.__dict__["_acc_weights"] = ent
+        return ent[1]
+
     def supports(self, packed):
         return packed.n_long_blocks == 0 and packed.max_len <= 64 and packed.bias_host is None and packed.Tp % 256 == 0
+
+    def supports_forward_only(self, packed, training):
+        """no gradient wanted and no dropout active: the accurate forward takes any packed stream the frozen fp16c path takes"""
+        no_drop = not training or (self.p_hidden == 0.0 and self.p_attn == 0.0)
+        return self.accurate_forward and no_drop and packed.n_long_blocks == 0 and packed.bias_host is None and packed.Tp % 256 == 0
 
     @torch.no_grad()
     def layers_nograd(self, packed, training=False):
@@ -334,9 +396,9 @@ class BertModelTrainable16(BertModelTrainable):
         return _Run(self, packed, training, [self._p[n] for n in self._order], keep=False).forward(None)
 
     def forward_mixed(self, packed, layer_w, training=False):
-        if not self.supports(packed):
-            from .bert_train import mix_layers
-            return mix_layers(layer_w, self.forward(packed, training=training))
         params = [self._p[n] for n in self._order]
         keep = torch.is_grad_enabled() and (layer_w.requires_grad or any(p.requires_grad for p in params))
+        if not self.supports(packed) and not (not keep and self.supports_forward_only(packed, training)):
+            from .bert_train import mix_layers
+            return mix_layers(layer_w, self.forward(packed, training=training))
         return _Encoder16.apply(self, packed, training, keep, layer_w, *params)

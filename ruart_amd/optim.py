@@ -121,6 +121,12 @@ class FusedAdamax:
         hip.check(lib.ruart_adamax_step(hip.ptr(ptrs[0]), hip.ptr(pl["gptr"]), hip.ptr(ptrs[1]), hip.ptr(ptrs[2]), hip.ptr(ct), hip.ptr(cs),
                                         hip.ptr(cc), n, hip.ptr(coef), hip.ptr(clr_dev), float(g0["betas"][0]), float(g0["betas"][1]),
                                         float(g0["eps"]), st), "ruart_adamax_step")
+        # the kernel wrote the parameters through raw pointers: tell torch (version counters feed autograd's saved-tensor checks and
+        # the trainable encoder's operand cache, bert_train16.accurate_weights)
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        if bump is not None:
+            for p in live:
+                bump(p)
 
     def step(self):
         self.clip_and_step(None)

@@ -484,7 +484,7 @@ def _unlocked(z, precision, **extra):
 
 
 @pytest.mark.parametrize("precision,tol_p,tol_g,tol_trunk", [("fp32", 5e-5, 2e-3, 2e-3), ("x3", 2e-4, 3e-2, 3e-2), ("x3+16gemm", 3e-3, 1.5e-1, 1.5e-1),
-                                                             ("x3+16", 3e-3, 3e-2, 6e-2)])
+                                                             ("x3+16", 1e-3, 3e-2, 6e-2)])
 def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_g, tol_trunk):
     """Conf without LOCK_BERT: the trainable encoder (bert_train.py) under the reference's parameter names; scores, loss and the
     gradient norm of every parameter - 197 BERT tensors included - against the reference's backward, plus gradient slices.
@@ -495,7 +495,8 @@ def test_unlocked_bert_gradients_vs_reference(golden_dir, precision, tol_p, tol_
     import ruart_amd.layers as L
     z = np.load(os.path.join(golden_dir, "sdnet_e2e_unlocked.npz"))
     # "x3+16": the 16-bit trainable encoder (bert_train16.py: one autograd Function over f16 / bf16 kernels, opt['bert_train_gemm'] =
-    # '16').  Its 197 BERT tensors are held to the 3 % of the round-1 verdict (measured: 0.7 % worst, 0.14 % median).  The trunk runs the
+    # '16').  Round 3: a pass without active dropout - this one - runs its FORWARD on the frozen path's fp16c kernels (probabilities within
+    # 1e-3, the north-star bound, with the encoder unlocked) and recomputes each layer's activations on the f16 kernels in the backward.  Its 197 BERT tensors are held to the 3 % of the round-1 verdict (measured: 0.7 % worst, 0.14 % median).  The trunk runs the
     # same fp32-class kernels as in "x3", but on an encoder output computed from f16 operands: the answer probabilities move by up to
     # 1.7e-3 (bound 3e-3), and the gradient of the no-answer branch (get_answer.noanswer_*, norm 1e-4) is proportional to
     # p(no answer) - y with p(no answer) ~ 0.04, i.e. it moves by dp / p ~ 4 %.  That is the forward tolerance seen through a small
