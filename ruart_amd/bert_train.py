@@ -96,10 +96,16 @@ class BertModelTrainable(nn.Module):
             q, k, v = (g[i].reshape(N * nh, Lg, hd) for i in range(3))
             km = mask.view(N, 1, Lg).expand(N, nh, Lg).reshape(N * nh, Lg)
             drop = training and self.p_attn > 0
-            if Lg > 384:                                   # beyond the fused kernel's key panel
-                s = torch.bmm(q, k.transpose(1, 2)).masked_fill(~km.bool().unsqueeze(1), float("-inf"))
-                p = F.dropout(torch.softmax(s, dim=-1), self.p_attn, training)
-                ctx = torch.bmm(p, v)
+            if Lg > 384:
+                # Beyond the fused kernel's key panel (385..512 word pieces in ONE sequence: the reference's windows are at most 512,
+                # Models/Bert/Bert.py:96-99).  Rare enough to be served slice by slice - but not by the vendor's batched GEMM: every
+                # product of a step stays on this repository's kernels (ops.py; the stream-K solutions of the library are what hung
+                # round 1's three-stream trunk), so each (sequence, head) takes two ruart_gemm_x3 products around a torch softmax.
+                ctxs = []
+                for n in range(N * nh):
+                    s = ops.matmul2d(q[n], k[n].t()).masked_fill(~km[n].bool().unsqueeze(0), float("-inf"))
+                    ctxs.append(ops.matmul2d(F.dropout(torch.softmax(s, dim=-1), self.p_attn, training), v[n]))
+                ctx = torch.stack(ctxs, 0)
             else:
                 ps = None
                 if drop:

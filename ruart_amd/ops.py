@@ -361,6 +361,28 @@ class _AddMM(torch.autograd.Function):
         return (gy if ctx.needs_input_grad[0] else None), gx, gw
 
 
+class _MatMul2D(torch.autograd.Function):
+    """a (M, K) . b (K, N) for two fp32 device matrices, both differentiable, every product on ruart_gemm_x3."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm
+        return mm(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = mm(g, b.t(), mode=ctx.mode) if ctx.needs_input_grad[0] else None
+        gb = mm(a.t(), g, mode=ctx.mode) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def matmul2d(a, b):
+    return _MatMul2D.apply(a, b)
+
+
 def addmm(base, x, w):
     """base (M, N) + x (M, K) . w (N, K)^T."""
     if trunk_gemm != "x3":             # exact-fp32 validation mode

@@ -347,3 +347,50 @@ def test_attention_train_dropout_is_consistent():
     assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dO.to(DEV)), H, hip.ptr(dqkv2), 3 * H, *args, p, 99, None, _st()) == 0
     rhs2 = float((dqkv2[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
     assert abs(lhs - rhs2) > 5 * abs(lhs - rhs)                                    # another seed: another mask
+
+
+def test_trainable_encoder_long_sequence_stays_off_the_vendor_gemm():
+    """A sequence of 385..512 word pieces is beyond the fused attention kernel's key panel: the fp32-class trainable encoder serves
+    it slice by slice on ruart_gemm_x3 (bert_train.py) - never torch.bmm - and agrees with a plain torch attention, values and
+    gradients."""
+    import torch.nn.functional as F
+    from ruart_amd import synth
+    from ruart_amd.bert import PackedTokens
+    from ruart_amd.bert_train import BertModelTrainable
+    dev = torch.device("cuda:0")
+    cfg = synth.bert_config(vocab_size=300, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                            hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModelTrainable(synth.make_bert_weights(cfg, seed=3, w_std=0.05), cfg, dev)
+    g = torch.Generator().manual_seed(0)
+    L = 400
+    ids = torch.randint(5, 300, (2, L), generator=g)
+    mask = torch.ones(2, L, dtype=torch.bool)
+    mask[1, 390:] = False
+    ids[1, 390:] = 0
+    packed = PackedTokens([(ids, mask)], dev, mfma_long=False)
+    calls = {"bmm": 0}
+    orig = torch.bmm
+    torch.bmm = lambda *a, **k: (calls.__setitem__("bmm", calls["bmm"] + 1), orig(*a, **k))[1]
+    try:
+        out = m(packed, training=False)                        # (1, T, H)
+        out.sum().backward()
+    finally:
+        torch.bmm = orig
+    assert calls["bmm"] == 0
+    assert out.shape == (1, packed.T, 128) and torch.isfinite(out).all()
+    # reference: the same layer with torch ops on the padded layout
+    P = {n: p.detach().double().cpu() for n, p in m._p.items()}
+    x = (P["embeddings.word_embeddings.weight"][ids] + P["embeddings.position_embeddings.weight"][torch.arange(L)].unsqueeze(0)
+         + P["embeddings.token_type_embeddings.weight"][0])
+    ln = lambda t, pre: F.layer_norm(t, (128,), P[pre + ".gamma"], P[pre + ".beta"], 1e-12)
+    x = ln(x, "embeddings.LayerNorm")
+    pre = "encoder.layer.0."
+    lin = lambda t, n: t @ P[pre + n + ".weight"].t() + P[pre + n + ".bias"]
+    q, k, v = (lin(x, "attention.self." + n).view(2, L, 2, 64).transpose(1, 2) for n in ("query", "key", "value"))
+    s = (q @ k.transpose(-1, -2)) / 8.0 + (~mask).double().view(2, 1, 1, L) * -1e9
+    ctx = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(2, L, 128)
+    x = ln(lin(ctx, "attention.output.dense") + x, pre + "attention.output.LayerNorm")
+    h = F.gelu(lin(x, "intermediate.dense"))
+    x = ln(lin(h, "output.dense") + x, pre + "output.LayerNorm")
+    ref = torch.cat([x[0], x[1, :390]], 0)
+    assert float((out[0].double().cpu() - ref).abs().max()) < 2e-4
