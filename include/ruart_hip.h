@@ -296,6 +296,20 @@ int ruart_whole_ln_fwd(const float* x, float* y, float* stats, float* ws, long l
 int ruart_whole_ln_bwd(const float* y, const float* grad_y, const float* stats, float* grad_x, float* ws, long long n,
                        void* stream);
 
+/* Fused answer scorer: Models/Layers.py:352-432 (GetFinalScores with useES and no_answer, the two BilinearSeqAttn :435-468 and
+ * get_single_score :421-432) for x (B, L, D) fp32 and per-sample vectors u1 (scores the OCR slots i >= ES), u2 (the first ES slots),
+ * uh (the no-answer attention) (B, D) - the caller's three small projections of h0, variational-dropout masks of x folded in -,
+ * w (D) / bna (1) the no-answer read-out, mask (B, L) uint8 (0 = masked slot; the candidate scores are masked only with mask_flag,
+ * the no-answer attention always):  probs (B, L + 1) = softmax([x_i . u(i), w . (softmax(x . uh) . x) + bna]).  a_out (B, L): the
+ * no-answer attention, kept for the backward.  One workgroup per sample, fixed summation orders.  D % 4 == 0, L <= 1024. */
+int ruart_scorer_fwd(const float* x, const float* u1, const float* u2, const float* uh, const float* w, const float* bna,
+                     const unsigned char* mask, float* probs, float* a_out, int B, int L, int D, int ES, int mask_flag, void* stream);
+/* gradients of the above for gprobs (B, L + 1): gx (B, L, D), gu1 / gu2 / guh (B, D), and per-sample partials gw_part (B, D), gb_part (B)
+ * whose sums over the batch are d w, d bna. */
+int ruart_scorer_bwd(const float* x, const float* u1, const float* u2, const float* uh, const float* w, const float* probs,
+                     const float* a_in, const float* gprobs, float* gx, float* gu1, float* gu2, float* guh, float* gw_part,
+                     float* gb_part, int B, int L, int D, int ES, void* stream);
+
 /* LSTM recurrence (what Layers.py:166 delegates to nn.LSTM), BOTH directions of one layer per call
  * (grid = B x ndir), gate order i,f,g,o, zero initial state, padding not masked.
  *   xproj : (B, T, ndir*4h)  x W_ih^T + b_ih + b_hh, direction d at column offset d*4h (one GEMM by the caller)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libruart_hip.so")
-SOURCES = ["gemm.hip", "gemm_corr.hip", "gemm_tn.hip", "bert_kernels.hip", "bert_train_kernels.hip", "bert_train_attn.hip", "bert_forward.hip", "sdnet_attention.hip", "sdnet_lstm.hip", "sdnet_gemm.hip", "sdnet_optim.hip", "phoc.hip"]
+SOURCES = ["gemm.hip", "gemm_corr.hip", "gemm_tn.hip", "bert_kernels.hip", "bert_train_kernels.hip", "bert_train_attn.hip", "bert_forward.hip", "sdnet_attention.hip", "sdnet_lstm.hip", "sdnet_gemm.hip", "sdnet_optim.hip", "sdnet_scorer.hip", "phoc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", INC, "-I", CSRC, "-Wno-unused-result", "-Wno-pass-failed"]
 
 

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "ruart_attn_bwd_pscale": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_whole_ln_fwd": (_I, [_P, _P, _P, _P, _LL, _F, _P]),
     "ruart_whole_ln_bwd": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
+    "ruart_scorer_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_scorer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_set_variant": (_I, [_I]),
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

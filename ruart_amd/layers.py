@@ -4,6 +4,8 @@ normalisation step runs on the hand-written HIP kernels of libruart_hip.so (ruar
 
 Module-global dropout state mirrors Models/Layers.py:15-21 (``set_dropout_prob`` / ``set_seq_dropout``).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -13,6 +15,8 @@ from . import ops
 
 dropout_p = 0.0
 do_seq_dropout = False
+# GetFinalScores on the fused kernel (csrc/sdnet_scorer.hip); False / RUART_FUSED_SCORER=0: the op-by-op form (A/B runs, tests)
+fused_scorer_enabled = os.environ.get("RUART_FUSED_SCORER", "1") != "0"
 
 
 def set_dropout_prob(p):
@@ -293,6 +297,9 @@ class GetFinalScores(nn.Module):
         self.attn2 = BilinearSeqAttn(x_size, h_size)
 
     def forward(self, x, h0, x_mask, ES_len, mask_flag=None):
+        if (self.useES and self.no_answer and x.is_cuda and ops.trunk_gemm == "x3" and x.dim() == 3 and x.size(2) % 4 == 0
+                and x.size(1) <= 1024 and 0 < ES_len < x.size(1) and fused_scorer_enabled):
+            return self._forward_fused(x, h0, x_mask, ES_len, mask_flag)
         if self.useES:
             score_ocr = self.attn(x[:, ES_len:], h0, x_mask[:, ES_len:], mask_flag=mask_flag)
             score_es = self.attn2(x[:, :ES_len], h0, x_mask[:, :ES_len], mask_flag=mask_flag)
@@ -303,6 +310,20 @@ class GetFinalScores(nn.Module):
             h0 = dropout(h0, p=dropout_p, training=self.training)
             score_s = torch.cat([score_s, self.get_single_score(x, h0, x_mask, self.noanswer_linear, self.noanswer_w)], dim=-1)
         return F.softmax(score_s, dim=-1)
+
+    def _forward_fused(self, x, h0, x_mask, ES_len, mask_flag):
+        """The same computation with the (B, L, D) work in ONE kernel per direction (ops.fused_scorer).  The three projections of h0 stay
+        small GEMMs; the variational-dropout masks BilinearSeqAttn draws for its x (one (B, D) mask per call, :456-457) are folded into
+        the projected vectors - (x o m) . u == x . (m o u) - in the order the unfused code draws them (attn, then attn2)."""
+        def proj(attn, x_part):
+            m = seq_dropout_mask(x_part, p=dropout_p, training=self.training)          # the call's dropout of x
+            u = ops.linear(dropout(h0, p=dropout_p, training=self.training), attn.linear.weight, attn.linear.bias)
+            return u if m is None else u * m
+        u1 = proj(self.attn, x[:, ES_len:])
+        u2 = proj(self.attn2, x[:, :ES_len])
+        hd = dropout(h0, p=dropout_p, training=self.training)
+        uh = ops.linear(hd, self.noanswer_linear.weight, self.noanswer_linear.bias)
+        return ops.fused_scorer(x, u1, u2, uh, self.noanswer_w.weight, self.noanswer_w.bias, x_mask, ES_len, bool(mask_flag))
 
     def get_single_score(self, x, h, x_mask, linear, w):
         """:421-432: w . (softmax(mask(x . W h)) . x) + b - one fused-attention launch with a single query row."""

@@ -103,6 +103,47 @@ def fused_attention(a, k, v, mask, diag=None, relu=False, prob_scale=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
+class _FusedScorer(torch.autograd.Function):
+    """probs (B, L + 1) = softmax([x_i . u(i), w . (softmax(mask(x . uh)) . x) + b])  - Models/Layers.py:352-432 in one launch per
+    direction (csrc/sdnet_scorer.hip).  u1 scores the slots i >= ES, u2 the first ES; all three (B, D)."""
+
+    @staticmethod
+    def forward(ctx, x, u1, u2, uh, w, b, mask, ES, mask_flag):
+        lib = hip.load()
+        for t in (x, u1, u2, uh, w, b):
+            hip.require_gpu(t, torch.float32)
+        nan_flag.ensure(x.device)
+        B, L, D = x.shape
+        probs = torch.empty(B, L + 1, dtype=torch.float32, device=x.device)
+        a = torch.empty(B, L, dtype=torch.float32, device=x.device)
+        hip.check(lib.ruart_scorer_fwd(hip.ptr(x), hip.ptr(u1), hip.ptr(u2), hip.ptr(uh), hip.ptr(w), hip.ptr(b), hip.ptr(mask), hip.ptr(probs),
+                                       hip.ptr(a), B, L, D, int(ES), int(bool(mask_flag)), hip.stream_ptr()), "ruart_scorer_fwd")
+        ctx.save_for_backward(x, u1, u2, uh, w, probs, a)
+        ctx.ES = int(ES)
+        return probs
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = hip.load()
+        x, u1, u2, uh, w, probs, a = ctx.saved_tensors
+        B, L, D = x.shape
+        gp = gp.contiguous()
+        gx = torch.empty_like(x)
+        gu1, gu2, guh, gwp = (torch.empty(B, D, dtype=torch.float32, device=x.device) for _ in range(4))
+        gbp = torch.empty(B, dtype=torch.float32, device=x.device)
+        hip.check(lib.ruart_scorer_bwd(hip.ptr(x), hip.ptr(u1), hip.ptr(u2), hip.ptr(uh), hip.ptr(w), hip.ptr(probs), hip.ptr(a), hip.ptr(gp),
+                                       hip.ptr(gx), hip.ptr(gu1), hip.ptr(gu2), hip.ptr(guh), hip.ptr(gwp), hip.ptr(gbp), B, L, D, ctx.ES,
+                                       hip.stream_ptr()), "ruart_scorer_bwd")
+        return gx, gu1, gu2, guh, colsum(gwp).view_as(w), gbp.sum().view(1), None, None, None
+
+
+def fused_scorer(x, u1, u2, uh, w, b, mask, ES, mask_flag):
+    """x (B, L, D), u1 / u2 / uh (B, D), w (D,) or (1, D), b (1,), mask (B, L): see _FusedScorer.  D % 4 == 0, L <= 1024."""
+    return _FusedScorer.apply(x.contiguous(), u1.contiguous(), u2.contiguous(), uh.contiguous(), w.contiguous().view(-1), b.contiguous().view(1),
+                              mask.to(torch.uint8).contiguous(), ES, mask_flag)
+
+
+# ---------------------------------------------------------------------------------------------------------
 class _WholeLayerNorm(torch.autograd.Function):
     """F.layer_norm(x, x.size()) - normalisation over the WHOLE tensor, no affine (Models/Layers.py:167-168)."""
 

@@ -11,5 +11,5 @@ for f in gemm gemm_corr gemm_tn; do
     -c ruart_amd/csrc/$f.hip -o build/${f}_$name.o 2>/dev/null
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libruart_hip_$name.so build/gemm_$name.o build/gemm_corr_$name.o build/gemm_tn_$name.o \
-  ruart_amd/csrc/bert_kernels.o ruart_amd/csrc/bert_forward.o ruart_amd/csrc/sdnet_attention.o ruart_amd/csrc/sdnet_lstm.o ruart_amd/csrc/sdnet_gemm.o ruart_amd/csrc/sdnet_optim.o ruart_amd/csrc/phoc.o ruart_amd/csrc/bert_train_kernels.o ruart_amd/csrc/bert_train_attn.o
+  ruart_amd/csrc/bert_kernels.o ruart_amd/csrc/bert_forward.o ruart_amd/csrc/sdnet_attention.o ruart_amd/csrc/sdnet_lstm.o ruart_amd/csrc/sdnet_gemm.o ruart_amd/csrc/sdnet_optim.o ruart_amd/csrc/sdnet_scorer.o ruart_amd/csrc/phoc.o ruart_amd/csrc/bert_train_kernels.o ruart_amd/csrc/bert_train_attn.o
 echo built build/libruart_hip_$name.so

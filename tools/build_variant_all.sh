@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/$name
 objs=""
-for f in gemm gemm_corr gemm_tn bert_kernels bert_train_kernels bert_train_attn bert_forward sdnet_attention sdnet_lstm sdnet_gemm sdnet_optim phoc; do
+for f in gemm gemm_corr gemm_tn bert_kernels bert_train_kernels bert_train_attn bert_forward sdnet_attention sdnet_lstm sdnet_gemm sdnet_optim sdnet_scorer phoc; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -I ruart_amd/csrc -Wno-unused-result -Wno-pass-failed "$@" \
     -c ruart_amd/csrc/$f.hip -o build/$name/$f.o 2>/dev/null &
   objs="$objs build/$name/$f.o"
