@@ -275,6 +275,10 @@ def main():
     if a.mode == "bert512":
         return bert512(a, device, lib, out_stream)
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
+    if os.environ.get("RUART_DP_PINNED_SCALAR"):          # experiments: the one-scalar form of the re-pinned rows' clip-norm share (dp.py)
+        opt["dp_pinned_scalar"] = True
+    if os.environ.get("RUART_DP_OVERLAP"):                # experiments: bucket exchange overlapped with backward (dp.py)
+        opt["dp_overlap_backward"] = True
     if a.graph_trunk is not None:
         opt["ruart_graph_trunk"] = bool(a.graph_trunk)
     if a.frozen_dropout:

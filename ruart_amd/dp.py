@@ -21,16 +21,24 @@ asks for.  Design, for 8 MI355X on a fully connected xGMI mesh:
       - ``opt['dp_skip_pinned_rows']`` (older switch) exchanges the head rows and zeroes the rest, dropping them from the norm.
     A sparse exchange (ids + rows of the touched pinned rows) was considered and dropped: at the bench shape a rank looks up
     ~19 k words per step, i.e. most of a 20 k vocabulary - the "sparse" all-gather would move MORE than the dense all-reduce;
-  * gradients are packed into a few large flat buckets (default 16 MB: on point-to-point xGMI links large messages
-    win; there is no NVSwitch-style in-network reduction to amortise small ones) in reverse parameter order.  The buckets
-    are allocated once; when the last gradient of a bucket has been produced, ONE multi-tensor copy moves the bucket's
-    gradients into it and its all-reduce is launched asynchronously (strictly in bucket order, so all ranks issue identical
-    collective sequences), overlapping the rest of backward; ``average_gradients`` waits, scales each bucket by 1/world in
-    one launch and points every parameter's ``.grad`` at its slice of the bucket (no copy back);
-  * stream order: the trunk runs its question / object / OCR branches on three streams, so the gradients of one bucket are
-    accumulated on different streams, and autograd joins those streams only at the END of backward.  Every hook therefore
-    notes the stream its gradient was accumulated on, and the launching hook's stream waits for all of them (an event recorded at
-    launch time covers every accumulation enqueued before the hook ran) before the copy and the collective;
+  * gradients are packed into large flat buckets, allocated once (on point-to-point xGMI links large messages win; there is
+    no NVSwitch-style in-network reduction to amortise small ones).  DEFAULT: the exchange runs AFTER ``backward()``, on the
+    caller's stream, as synchronous collectives - one multi-tensor copy into the bucket, one all-reduce, one scale, and every
+    parameter's ``.grad`` is pointed at its slice of the bucket (no copy back).  A synchronous c10d collective is enqueued on the
+    CURRENT stream, so the whole exchange costs no cross-stream event at all, and it is not dead time for the GPU: the next
+    batch's frozen encoder keeps running on its own stream (bert.py) while RCCL moves the ~80 MB.  That is the overlap this step
+    offers - it beats the textbook one below on this workload: measured on one MI355X under a world-size-1 RCCL group
+    (tools/dp_overhead2.py, 64-sample step) 25.1 ms against 25.0 without DP, where the overlapped mode costs 28.1-29.5 ms;
+  * ``opt['dp_overlap_backward']`` (the round-2 default): 16 MB buckets in reverse parameter order; when the last gradient of a
+    bucket has been produced (post-accumulate hooks) its copy and an ASYNCHRONOUS all-reduce are enqueued on a communication
+    stream, strictly in bucket order, overlapping the rest of backward; ``average_gradients`` waits.  The trunk runs its
+    question / object / OCR branches on three streams and autograd joins them only at the END of backward, so every hook notes
+    the stream its gradient was accumulated on and the communication stream waits for all of them.  Those waits are what is
+    expensive here, not the payload: with the copy, the collective and the allocator bookkeeping all removed and ONLY the 14
+    ``wait_stream`` calls per step left, the step is still 28.0 ms against 25.0 (an event hop itself is 17 us,
+    tools/stream_hop.py; the rest is the branches' and the encoder stream's interleaving being disturbed - every variant that
+    makes a second stream wait on a trunk stream in mid-backward pays it, including c10d's own internal stream when the
+    collective is asynchronous).  Worth it only when the payload is large against the step (the unlocked encoder's 440 MB);
   * works unchanged on the gloo backend (CPU tensors) - that is how the N>1 path is tested without GPUs.
 """
 import os
@@ -56,12 +64,17 @@ def init_process_group(device, backend="nccl", **kw):
 
 
 class GradSync:
-    def __init__(self, network, opt, group=None, bucket_bytes=16 << 20, pinned_scalar=False):
-        """``pinned_scalar``: opt-in approximation - the caller's optimizer takes ``pinned_sq`` (FusedAdamax.clip_and_step(extra_sq=)) and
+    def __init__(self, network, opt, group=None, bucket_bytes=None, pinned_scalar=False, overlap=None):
+        """``overlap``: exchange bucket by bucket during backward (hooks + a communication stream) instead of after it; default
+        ``opt['dp_overlap_backward']``, off (module docstring).  ``bucket_bytes``: default 16 MB when overlapping, 256 MB otherwise.
+        ``pinned_scalar``: opt-in approximation - the caller's optimizer takes ``pinned_sq`` (FusedAdamax.clip_and_step(extra_sq=)) and
         the re-pinned embedding rows are represented by one scalar instead of being exchanged (see the module docstring: exact only
         when the ranks touch disjoint pinned rows).  Default: whole tables exchanged, exact clip norm."""
         self.group = group
         self.world = dist.get_world_size(group)
+        self.overlap = bool(opt.get("dp_overlap_backward", False)) if overlap is None else bool(overlap)
+        if bucket_bytes is None:
+            bucket_bytes = (16 << 20) if self.overlap else (256 << 20)
         self.network = network
         tp = None
         self.mode = "full"
@@ -107,7 +120,8 @@ class GradSync:
         for bi, b in enumerate(self.buckets):
             for (_, p, _) in b:
                 self._bucket_of[p] = bi
-                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+                if self.overlap:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
         self.payload_bytes = sum(f.numel() * 4 for f in self._flat) + (4 if self.mode == "scalar" else 0)
         self._reset()
 
@@ -142,14 +156,42 @@ class GradSync:
             out.append(g[:rows] if rows is not None else g)
         return out
 
+    def _comm_stream(self, device):
+        """Overlapped mode: the stream the bucket copies and collectives are enqueued from.  NOT one of the trunk's streams - the
+        stream a hook happens to run on would have to wait for the other two (``wait_stream`` = everything enqueued there so far,
+        far more than this bucket's gradients), serialising the three branches of the backward at every bucket."""
+        st = self.__dict__.get("_comm")
+        if st is None or st.device != device:
+            st = self.__dict__["_comm"] = torch.cuda.Stream(device=device, priority=-1)
+        return st
+
+    def _exchange_now(self, bi):
+        """Default mode, after backward(): copy, collective and scale of one bucket on the caller's stream (a synchronous c10d
+        collective runs on the current stream - no event, no second stream)."""
+        flat = self._flat[bi]
+        torch._foreach_copy_(self._slices[bi], self._grads(bi))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.mode == "scalar" and bi == len(self.buckets) - 1:
+            parts = [p.grad[rows:].float().pow(2).sum() for (_, p, rows) in self._pinned if p.grad is not None and p.grad.shape[0] > rows]
+            self._sq = torch.stack(parts).sum().reshape(1) if parts else torch.zeros(1, device=flat.device)
+            dist.all_reduce(self._sq, op=dist.ReduceOp.SUM, group=self.group)
+
     def _launch(self, bi):
         flat = self._flat[bi]
+        grads = self._grads(bi)
         if flat.is_cuda:
-            cur = torch.cuda.current_stream(flat.device)
-            for s in self._streams[bi]:
-                if s != cur:
-                    cur.wait_stream(s)      # everything enqueued on s so far - the accumulations of this bucket included
-        torch._foreach_copy_(self._slices[bi], self._grads(bi))
+            comm = self._comm_stream(flat.device)
+            for s in self._streams[bi] | {torch.cuda.current_stream(flat.device)}:
+                comm.wait_stream(s)         # everything enqueued on s so far - the accumulations of this bucket included
+            for g in grads:
+                g.record_stream(comm)
+            with torch.cuda.stream(comm):
+                torch._foreach_copy_(self._slices[bi], grads)
+                self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.mode == "scalar" and bi == len(self.buckets) - 1:
+                    self._launch_pinned_scalar()
+            return
+        torch._foreach_copy_(self._slices[bi], grads)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.mode == "scalar" and bi == len(self.buckets) - 1:
             self._launch_pinned_scalar()
@@ -178,12 +220,15 @@ class GradSync:
     def average_gradients(self):
         """Call after ``loss.backward()``: finishes the outstanding bucket all-reduces and writes the averaged
         gradients back in place."""
-        while self._next < len(self.buckets):       # gradients that never fired a hook (unused on this batch): still in order
+        while self.overlap and self._next < len(self.buckets):   # gradients that never fired a hook (unused on this batch): still in order
             self._launch(self._next)
             self._next += 1
         inv = 1.0 / self.world
         for bi in range(len(self.buckets)):
-            self._work[bi].wait()
+            if self.overlap:
+                self._work[bi].wait()
+            else:
+                self._exchange_now(bi)
             flat = self._flat[bi]
             if self.world > 1:
                 flat.mul_(inv)                         # one launch per bucket
@@ -194,8 +239,9 @@ class GradSync:
                     p.grad[:rows].copy_(sl)
                     if self.mode == "zero":
                         p.grad[rows:].zero_()
-        if self._sq_work is not None:
-            self._sq_work.wait()
+        if self._sq_work is not None or (self._sq is not None and not self.overlap):
+            if self._sq_work is not None:
+                self._sq_work.wait()
             self.pinned_sq = self._sq.mul_(inv * inv) if self.world > 1 else self._sq
         self._reset()
 

@@ -38,6 +38,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     opt = default_opt(vocab_size=1500, cuda=True, DROPOUT=0.0, dropout_emb=0.0)
+    opt["dp_overlap_backward"] = len(sys.argv) > 6 and sys.argv[6] == "overlap"     # default: exchange after backward (dp.py)
     cfg = synth.bert_config(vocab_size=2000)
     opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=1033), cfg
     sw = synth.make_sdnet_weights(opt, seed=1033)

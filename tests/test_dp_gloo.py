@@ -34,7 +34,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, skip_pinned, out):
+def _worker(rank, world, port, skip_pinned, overlap, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ruart_amd.dp import GradSync
@@ -43,7 +43,7 @@ def _worker(rank, world, port, skip_pinned, out):
     opt = {"TUNE_PARTIAL": True, "tune_partial": 5}
     if skip_pinned:
         opt["dp_skip_pinned_rows"] = True
-    gs = GradSync(net, opt, bucket_bytes=64)             # tiny buckets => several of them
+    gs = GradSync(net, opt, bucket_bytes=64, overlap=overlap)   # tiny buckets => several of them
     gs.broadcast_parameters()
     ids = torch.tensor([[1, 2, 7], [3, 9, 11]]) if rank == 0 else torch.tensor([[0, 4, 8], [10, 2, 6]])
     sgd = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
@@ -65,11 +65,12 @@ def _worker(rank, world, port, skip_pinned, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("skip_pinned", [False, True])
-def test_gradsync_two_ranks(tmp_path, skip_pinned):
+@pytest.mark.parametrize("skip_pinned,overlap", [(False, False), (True, False), (False, True), (True, True)])
+def test_gradsync_two_ranks(tmp_path, skip_pinned, overlap):
+    """overlap=False: the default exchange after backward(); True: opt['dp_overlap_backward'], hooks + asynchronous collectives."""
     world = 2
     out = str(tmp_path / "r%d.pt")
-    mp.spawn(_worker, args=(world, _free_port(), skip_pinned, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), skip_pinned, overlap, out), nprocs=world, join=True)
     r = [torch.load(out % i) for i in range(world)]
     assert r[0]["n_buckets"] > 1
     assert not any(n.startswith("get_answer.rnn") for n in r[0]["names"]) and "frozen" not in r[0]["names"]
@@ -88,13 +89,13 @@ def test_gradsync_two_ranks(tmp_path, skip_pinned):
         assert torch.equal(r[0]["params"][name], r[1]["params"][name]), name
 
 
-def _shared_rows_worker(rank, world, port, scalar, out):
+def _shared_rows_worker(rank, world, port, scalar, overlap, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ruart_amd.dp import GradSync
     torch.manual_seed(3)
     net = Toy()
-    gs = GradSync(net, {"TUNE_PARTIAL": True, "tune_partial": 5}, bucket_bytes=64, pinned_scalar=scalar)
+    gs = GradSync(net, {"TUNE_PARTIAL": True, "tune_partial": 5, "dp_overlap_backward": overlap}, bucket_bytes=64, pinned_scalar=scalar)
     gs.broadcast_parameters()
     # both ranks look up the pinned rows 7 and 9 (frequent out-of-head words): their gradients are strongly correlated
     ids = torch.tensor([[1, 2, 7], [3, 9, 7]]) if rank == 0 else torch.tensor([[0, 7, 7], [9, 9, 6]])
@@ -107,15 +108,15 @@ def _shared_rows_worker(rank, world, port, scalar, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scalar", [False, True])
-def test_clip_norm_when_ranks_share_pinned_rows(tmp_path, scalar):
+@pytest.mark.parametrize("scalar,overlap", [(False, False), (True, False), (True, True)])
+def test_clip_norm_when_ranks_share_pinned_rows(tmp_path, scalar, overlap):
     """Models/SDNetTrainer.py:366 clips by the norm of THE gradient - under data parallelism the averaged one.  Default mode: the
     tables are exchanged whole and the norm every rank computes is exactly that.  opt['dp_pinned_scalar']: the pinned rows enter as
     sum_r |g_r|^2 / world^2, which drops the cross terms between ranks - equal to the exact norm only for disjoint rows; here (shared
     rows, positively correlated gradients) it is an under-estimate, bounded by sqrt(world)."""
     world, tp = 2, 5
     out = str(tmp_path / "s%d.pt")
-    mp.spawn(_shared_rows_worker, args=(world, _free_port(), scalar, out), nprocs=world, join=True)
+    mp.spawn(_shared_rows_worker, args=(world, _free_port(), scalar, overlap, out), nprocs=world, join=True)
     r = [torch.load(out % i) for i in range(world)]
     names = list(r[0]["local"])
     exact_sq = sum(float(((r[0]["local"][n] + r[1]["local"][n]) / 2).double().pow(2).sum()) for n in names)
@@ -159,7 +160,7 @@ def _real_worker(rank, world, port, out):
     sw = synth.make_sdnet_weights(opt, seed=7)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
     net = sdnet_mod.SDNet(opt, {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
-    gs = GradSync(net, opt, pinned_scalar=True)                   # what the trainer passes with the fused optimizer
+    gs = GradSync(net, opt, pinned_scalar=True, bucket_bytes=16 << 20)   # the one-scalar form; several buckets
     g = torch.Generator().manual_seed(1000 + rank)
     local = {}
     for name, p in net.named_parameters():

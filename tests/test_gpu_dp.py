@@ -99,11 +99,11 @@ def _free_port():
     return port
 
 
-def _run_two_ranks(backend, devices):
+def _run_two_ranks(backend, devices, mode="post"):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_two_rank_worker.py")
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, backend, str(devices[r])], env=env,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, backend, str(devices[r]), mode], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
     try:
@@ -119,12 +119,15 @@ def _run_two_ranks(backend, devices):
         assert "rank %d ok" % r in out, out[-2000:]
 
 
-def test_two_rank_gloo_step_on_one_gpu():
-    """Two processes, both on cuda:0, collectives on gloo (RCCL refuses two ranks on one device)."""
-    _run_two_ranks("gloo", (0, 0))
+@pytest.mark.parametrize("mode", ["post", "overlap"])
+def test_two_rank_gloo_step_on_one_gpu(mode):
+    """Two processes, both on cuda:0, collectives on gloo (RCCL refuses two ranks on one device).  post: the default exchange after
+    backward(); overlap: opt['dp_overlap_backward'], hooks + asynchronous collectives from a communication stream."""
+    _run_two_ranks("gloo", (0, 0), mode)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one RCCL rank per GPU)")
 def test_two_rank_rccl_step():
     """The N > 1 path over RCCL / xGMI as the driver's scaling runs use it."""
     _run_two_ranks("nccl", (0, 1))
+    _run_two_ranks("nccl", (0, 1), "overlap")
