@@ -277,6 +277,8 @@ def main():
     opt = default_opt(vocab_size=20000, cuda=True, device=device, bert_precision=a.precision, max_od_num=36, batch_size=a.batch)
     if os.environ.get("RUART_DP_PINNED_SCALAR"):          # experiments: the one-scalar form of the re-pinned rows' clip-norm share (dp.py)
         opt["dp_pinned_scalar"] = True
+    if os.environ.get("RUART_STREAMS"):                   # experiments: 0 = the trunk's three branches on ONE stream
+        opt["ruart_streams"] = os.environ["RUART_STREAMS"] != "0"
     if os.environ.get("RUART_DP_OVERLAP"):                # experiments: bucket exchange overlapped with backward (dp.py)
         opt["dp_overlap_backward"] = True
     if a.graph_trunk is not None:

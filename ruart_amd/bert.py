@@ -522,8 +522,8 @@ class Bert(nn.Module):
 
     # -- encoder pipelining across steps ---------------------------------------------------------------------
     # BERT is frozen, so the encoder pass of batch t+1 depends on nothing step t produces.  ``prefetch`` launches it on a
-    # separate normal-priority stream while step t's SDNet trunk (hundreds of small, latency-bound kernels on high-priority
-    # streams) runs: the big MFMA GEMMs fill the CUs the trunk leaves idle.  Two buffer sets alternate so the layer outputs
+    # separate stream (CU-masked to 240 of the 256 CUs) while step t's SDNet trunk (hundreds of small, latency-bound kernels on
+    # three streams of the same priority) runs beside it.  Two buffer sets alternate so the layer outputs
     # step t's backward still reads (pool_mix_bwd) are not overwritten.
     def _init_pipeline(self):
         self._bufsets = [_Buffers(), _Buffers()]

@@ -494,7 +494,8 @@ class SDNet(nn.Module):
     def _side_streams(self, dev):
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != dev:
-            st = (torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev, priority=-1))
+            pr = int(os.environ.get("RUART_TRUNK_PRIORITY", 0))      # same priority as the step stream (trainer.update)
+            st = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
             self._streams = st
         return st
 

@@ -221,13 +221,15 @@ class SDNetTrainer(BaseTrainer):
     # -- one optimizer step -----------------------------------------------------------------------------------
     def update(self, batch, batch_i=0, next_batch=None):
         """One optimizer step.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
-        concurrently with this step's SDNet trunk; the whole step itself runs on a high-priority stream so the trunk's small
-        kernels are dispatched ahead of the encoder's big GEMM workgroups."""
+        concurrently with this step's SDNet trunk, on its own stream.  The step runs on a stream of its own too, at NORMAL priority
+        (``RUART_TRUNK_PRIORITY`` to experiment): since the MFMA recurrences the encoder pass is the longer of the two, and a
+        high-priority trunk - the round-1/2 setting, from when the trunk was - takes the CUs first at every GEMM's start and
+        delays single tiles of its one-round grids (25.5 -> 24.5 ms per step)."""
         dev = self.device
         unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
         if dev.type == "cuda" and not unlocked:          # (a trainable encoder: nothing runs ahead, plain stream)
             if getattr(self, "_step_stream", None) is None:
-                self._step_stream = torch.cuda.Stream(device=dev, priority=-1)
+                self._step_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RUART_TRUNK_PRIORITY", 0)))
             self._step_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._step_stream):
                 out = self._update(batch, batch_i, next_batch)
