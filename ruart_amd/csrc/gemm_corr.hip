@@ -37,23 +37,28 @@ typedef int i32x8_t __attribute__((ext_vector_type(8)));
 #define CBN 256
 #define CBKB 128   // bytes of one row of one K-tile (64 f16 or 128 fp8)
 
-// erf for the GELU of this mode: Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): the logistic-polynomial form of the plain 16-bit
-// epilogue (3.4e-6) would be the largest error of the whole layer here.
-__device__ __forceinline__ float erf_as7(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
-  const float r = fmaf(-p * t, e, 1.0f);
-  return copysignf(r, x);
+// GELU of this mode: x Phi(x) with Phi(x) = 0.5 erfc(-x / sqrt 2) taken as  r = exp2(P7(|x|)),  Phi = x < 0 ? r : 1 - r,  where P7 is a
+// degree-7 fit of log2(0.5 erfc(a / sqrt 2)) on a in [0, 7.07] (weighted by erfc, so the ABSOLUTE error of Phi is what is minimised:
+// 7e-8; beyond 7.07 Phi is 0 or 1 to 1e-12 and |x| is clamped).  |GELU error| <= 5.0e-7 over [-12, 12], rms 7.6e-8 on [-4, 4] -
+// the level of the Abramowitz-Stegun 7.1.26 erf this replaces (4.6e-7 / 1.2e-7) with ONE transcendental per element instead of two
+// (v_rcp + v_exp run at a quarter of the fma rate; the epilogue of the FFN intermediate dense was ~15 us of a 56 us tile, most
+// of it these).  The logistic-polynomial form of the plain 16-bit epilogue (3.4e-6) would be the largest error of the whole layer here.
+__device__ __forceinline__ float gelu_erfc7(float x) {
+  const float a = fminf(fabsf(x), 7.0710678f);
+  float p = fmaf(8.470145706e-06f, a, -5.390352871e-05f);
+  p = fmaf(p, a, -4.212367312e-04f);
+  p = fmaf(p, a, 7.389273853e-03f);
+  p = fmaf(p, a, -5.269111326e-02f);
+  p = fmaf(p, a, -4.591531477e-01f);
+  p = fmaf(p, a, -1.151110943e+00f);
+  p = fmaf(p, a, -9.999998964e-01f);
+  const float r = __builtin_amdgcn_exp2f(p);
+  return x * (x < 0.f ? r : 1.0f - r);
 }
 __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
   f32x4_t r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = v[i] * 0.5f * (1.0f + erf_as7(v[i] * 0.70710678118654752440f));
+  for (int i = 0; i < 4; ++i) r[i] = gelu_erfc7(v[i]);
   return r;
 }
 
@@ -258,16 +263,22 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restri
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+#ifndef RUART_ABL_NOGELU            // (diagnostic builds: the epilogue without its GELU / without its fp8 stores)
     if (EPI == 2) {
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4_as(v[rr]);
     }
+#endif
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const size_t row = (size_t)(mrow + rr * 4);
       if (EPI == 1) v[rr] += res[rr];
       if (EPI == 2)
+#ifdef RUART_ABL_NOFP8
+        *reinterpret_cast<f16x4_t*>(reinterpret_cast<f16_t*>(C) + row * ldc + ncol) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
+#else
         store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+#endif
       else
         store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
     }

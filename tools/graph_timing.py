@@ -9,8 +9,8 @@ from ruart_amd import synth
 from ruart_amd.arguments import default_opt
 
 dev = torch.device("cuda:0")
-for graph in (False, True):
-    opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_size=64, ruart_graph_trunk=graph)
+for graph, streams in ((False, True), (False, False), (True, True), (True, False)):
+    opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_size=64, ruart_graph_trunk=graph, ruart_streams=streams)
     cfg = synth.bert_config()
     tr, _ = bench.build_trainer(opt, cfg, dev)
     batches = [tr.ToCUDA(synth.synthetic_batch(opt, 64, seed=7 + i, n_q=30, n_ocr=100, n_od=36)) for i in range(2)]
@@ -40,6 +40,6 @@ for graph in (False, True):
     for i in range(6):
         step(i)
     r = np.array([step(i)[0] for i in range(10)])
-    print("graph=%s  host ms: fwd %.2f  bwd %.2f  opt %.2f | wait-for-GPU %.2f | total %.2f   (loss %.5f)" %
-          ((graph,) + tuple(r.mean(0)) + (step(0)[1],)), flush=True)
+    print("graph=%s three-streams=%s  host ms: fwd %.2f  bwd %.2f  opt %.2f | wait-for-GPU %.2f | total %.2f   (loss %.5f)" %
+          ((graph, streams) + tuple(r.mean(0)) + (step(0)[1],)), flush=True)
     del tr, net
