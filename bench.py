@@ -279,6 +279,8 @@ def main():
         opt["dp_pinned_scalar"] = True
     if os.environ.get("RUART_STREAMS"):                   # experiments: 0 = the trunk's three branches on ONE stream
         opt["ruart_streams"] = os.environ["RUART_STREAMS"] != "0"
+    if os.environ.get("RUART_DEFER_READBACK"):            # experiments: loss / NaN readback one step late (default: trained encoder only)
+        opt["ruart_defer_readback"] = os.environ["RUART_DEFER_READBACK"] != "0"
     if os.environ.get("RUART_DP_OVERLAP"):                # experiments: bucket exchange overlapped with backward (dp.py)
         opt["dp_overlap_backward"] = True
     if a.graph_trunk is not None:

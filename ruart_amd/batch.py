@@ -349,7 +349,7 @@ class BatchIndex:
             if self._n_last == 0:
                 last_start = [np.zeros(0, dtype=np.int32)] * len(spans)
             self._spans_host = (np.concatenate([np.concatenate(list(t[:3]) + [ls]) for t, ls in zip(spans, last_start)] + [last_rows]).astype(np.int32),
-                                [(len(t[0]), t[3]) for t in spans])
+                                [(len(t[0]), t[3], int(np.asarray(t[1], dtype=np.int64).sum())) for t in spans])
             if "LOCK_BERT" in opt and not opt.get("bert_frozen_dropout"):
                 self.packed.group_index = None         # (N, L) maps were only needed for the spans: keep the pickle small
                                                        # (the trainable encoder pads its attention per group from them)
@@ -423,7 +423,8 @@ class BatchIndex:
             o = 0
             self.spans = []
             n_last = getattr(self, "_n_last", 0)
-            for W, rows in shapes:
+            self.span_pieces = [n_pieces for _, _, n_pieces in shapes]     # host-side sum of each group's span lengths
+            for W, rows, _ in shapes:
                 last = dev[o + 3 * W:o + 4 * W] if n_last else None
                 self.spans.append((dev[o:o + W], dev[o + W:o + 2 * W], dev[o + 2 * W:o + 3 * W], rows, last))
                 o += (4 if n_last else 3) * W

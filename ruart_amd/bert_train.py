@@ -178,14 +178,16 @@ def mix_layers(layer_w, layers):
     return (layers * layer_w.to(layers.dtype).view(-1, 1, 1)).sum(0)
 
 
-def pool_words(mixed, span_start, span_len, dst_row, n_rows):
-    """Average every word's piece span of the mixed stream (Bert.py:149-165); rows without a word stay zero."""
+def pool_words(mixed, span_start, span_len, dst_row, n_rows, n_pieces=None):
+    """Average every word's piece span of the mixed stream (Bert.py:149-165); rows without a word stay zero.
+    ``n_pieces``: sum(span_len) when the host knows it (batch.BatchIndex.span_pieces) - without it ``repeat_interleave`` has to read
+    the sum back from the device, a host sync in the middle of the step (7 ms each at B = 64: the host waits for the encoder)."""
     W = span_start.numel()
     out = mixed.new_zeros(n_rows, mixed.size(1))
     if W == 0:
         return out
     ln = span_len.long()
-    word_of_piece = torch.repeat_interleave(torch.arange(W, device=ln.device), ln)
+    word_of_piece = torch.repeat_interleave(torch.arange(W, device=ln.device), ln, output_size=n_pieces)
     first = torch.cumsum(ln, 0) - ln
     piece = span_start.long()[word_of_piece] + (torch.arange(word_of_piece.numel(), device=ln.device) - first[word_of_piece])
     rows = mixed.index_select(0, piece) / ln[word_of_piece].unsqueeze(1).to(mixed.dtype)

@@ -287,14 +287,20 @@ class SDNet(nn.Module):
             self.Bert.prefetch(self.prepare(*nxt).packed)
 
     def _use_streams(self):
-        """Question / object / OCR branches on three streams - with a frozen encoder.  With a trainable encoder the step stays on one
-        stream: the fp32-class graph's first version (library GEMMs of extreme shape on the three streams at once) stopped completing
-        steps at B = 64, and for the 16-bit encoder the three-stream trunk was measured again in round 2 - 1 189
-        to 1 201 samples/s against 1 192 to 1 205 on one stream: the whole trunk is already queued behind the encoder's backward, so
-        there is no gap for the overlap to fill."""
+        """Question / object / OCR branches on three streams.  With a trainable encoder: only its 16-bit form (bert_train16.py: every
+        product on this library's kernels).  The fp32-class graph stays on one stream - its first version (library GEMMs of extreme
+        shape on the three streams at once) stopped completing steps at B = 64.  For the 16-bit encoder round
+        2 measured no difference (1 189-1 201 samples/s against 1 192-1 205 on one stream) because the trunk phase was bound by the
+        host's enqueue rate either way; with the loss readback one step late (trainer._readback_later) the host is ahead of the
+        device and the trunk phase is as long as its kernels take - three streams shorten that."""
         if ops.trunk_gemm != "x3":          # exact-fp32 validation mode: its projections are library GEMMs (stream-K solutions that
             return False                     # need all their workgroups resident) - never beside other streams' kernels
-        return bool(self.opt.get("ruart_streams", True)) and ("BERT" not in self.opt or getattr(self.Bert, "bert_model", None) is None)
+        if not bool(self.opt.get("ruart_streams", True)):
+            return False
+        model = getattr(self.Bert, "bert_model", None) if "BERT" in self.opt else None
+        if model is None:
+            return True
+        return bool(self.opt.get("ruart_streams_trained_encoder", type(model).__name__ == "BertModelTrainable16"))
 
     def _layer_weights(self):
         """softmax(alpha)_l * gamma - the scalar each BERT layer is mixed with (SDNet.py:574-576)."""
@@ -423,7 +429,7 @@ class SDNet(nn.Module):
         def pooled(g):
             s_, l_, dst, rows, s_last = bi.spans[g]
             if trainable:
-                return bert_train.pool_words(mixed, s_, l_, dst, rows)
+                return bert_train.pool_words(mixed, s_, l_, dst, rows, n_pieces=bi.span_pieces[g])
             return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last)
 
         def front(items, idx, mix):

@@ -604,7 +604,11 @@ def test_unlocked_bert_trains_with_the_fused_optimizer(train_gemm):
     assert n_bert > 80e6
     w0 = dict(tr.network.named_parameters())["Bert.bert_model.encoder.layer.3.output.dense.weight"].detach().clone()
     batch = tr.ToCUDA(synth.synthetic_batch(opt, 3, seed=31, n_q=10, n_ocr=14, n_od=5, bert_vocab=2000, ragged=True))
-    losses = [tr.update(batch, i) for i in range(6)]
+    raw = [tr.update(batch, i) for i in range(6)]
+    assert type(raw[0]).__name__ == "_PendingLoss"                        # trained encoder: the readback trails by one step
+    assert tr.train_loss.count == 5                                       # ... so five steps have been resolved by now
+    losses = [float(v) for v in raw]
+    assert tr.train_loss.count == 6 and tr.train_loss.val == losses[-1]
     assert all(np.isfinite(losses)), losses
     assert min(losses[3:]) < losses[0], losses                            # the same batch six times: the loss comes down
     if train_gemm == "16":
@@ -621,6 +625,43 @@ def test_unlocked_bert_trains_with_the_fused_optimizer(train_gemm):
     path = "/tmp/ruart_ckpt_unlocked.pt"
     tr.save_for_predict(path)
     assert not any(k.startswith("Bert") for k in torch.load(path, map_location="cpu")["state_dict"]["network"])
+
+
+def test_deferred_readback_changes_nothing_but_the_moment_of_the_asserts():
+    """Trained encoder: ``update`` reads the loss and the NaN flag of step t back at the end of step t+1 (trainer._readback_later).
+    Same losses, same running mean as with the per-step sync; a NaN still stops the run - one step late, and before predict /
+    save can look at the weights."""
+    from ruart_amd.trainer import SDNetTrainer
+    cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bert_state = synth.make_bert_weights(cfg, seed=7, w_std=0.02)
+
+    def make(defer):
+        opt = default_opt(vocab_size=600, cuda=True, DROPOUT=0.0, dropout_emb=0.0, lr=2e-4, bert_train_gemm="16")
+        opt.pop("LOCK_BERT")
+        opt["bert_state"], opt["bert_config"] = bert_state, cfg
+        if defer is not None:
+            opt["ruart_defer_readback"] = defer
+        sw = synth.make_sdnet_weights(opt, seed=7)
+        tr = SDNetTrainer(opt, device="cuda:0")
+        tr.setup_model({"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})
+        return tr, tr.ToCUDA(synth.synthetic_batch(opt, 3, seed=31, n_q=10, n_ocr=14, n_od=5, bert_vocab=2000, ragged=True))
+
+    tr_a, batch = make(False)
+    la = [tr_a.update(batch, i) for i in range(4)]
+    assert all(isinstance(v, float) for v in la)
+    tr_b, batch_b = make(None)                                            # default with a trained encoder: deferred
+    lb = [tr_b.update(batch_b, i) for i in range(4)]
+    assert tr_b.train_loss.count == 3
+    assert tr_b.flush_readback() == la[3] and tr_b.flush_readback() is None
+    assert [float(v) for v in lb] == la and tr_b.train_loss.avg == tr_a.train_loss.avg and tr_b.train_loss.count == 4
+    assert "%.4f" % lb[0] == "%.4f" % la[0]
+    # a NaN: the step that produces it returns; the next update (or predict, or close) raises
+    with torch.no_grad():
+        tr_b.network.get_answer.attn.linear.weight[0, 0] = float("nan")
+    tr_b.update(batch_b, 4)
+    with pytest.raises(AssertionError):
+        tr_b.predict(batch_b)
+    tr_a.close()
 
 
 @pytest.mark.parametrize("precision,tol_l,tol_d", [("fp32", 2e-4, 5e-3), ("fp16", 2e-2, 8e-2)])

@@ -276,12 +276,13 @@ def test_packed_tokens_dedup_and_last_layer_rows():
         socr["bert_offsets"][r] = socr["bert_offsets"][sent[0]]
     a, b = BatchIndex(sq, socr, sod, opt), BatchIndex(sq, socr, sod, dict(opt, bert_dedup=False))
     assert a.packed.n_seq == b.packed.n_seq - (4 - 1) and a.packed.T < b.packed.T
-    W = [n for n, _ in bi._spans_host[1]]
+    W = [n for n, _, _ in bi._spans_host[1]]
     flat = bi._spans_host[0]
     o, covered = 0, np.zeros(bi.packed.T, dtype=bool)
     starts, lasts = [], []
-    for w in W:
+    for w, (_, _, n_pieces) in zip(W, bi._spans_host[1]):
         s_, l_, ls = flat[o:o + w], flat[o + w:o + 2 * w], flat[o + 3 * w:o + 4 * w]
+        assert n_pieces == int(l_.sum())               # what the trainable encoder's pooling gets instead of a device readback
         for a, n in zip(s_, l_):
             covered[a:a + n] = True
         starts.append(s_)
