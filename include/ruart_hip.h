@@ -332,6 +332,13 @@ int ruart_lstm_fwd(const float* xproj, const float* w_hh, float* y, float* gates
 int ruart_lstm_bwd(const float* grad_y, const float* w_hh, const float* gates, const float* cells, float* grad_xproj, int B,
                    int T, int h, int ndir, void* stream);
 
+/* The operands of one BIDIRECTIONAL nn.LSTM layer (Models/Layers.py:124-180 via nn.LSTM; torch's parameter layout, G = 4h gate rows) in
+ * one launch: w (2G, K) = [w_ih ; w_ih_reverse] for the input projection of both directions, b (2G) = [b_ih + b_hh ; the reverse pair],
+ * whh (2, G, h) = the recurrent matrices as ruart_lstm_fwd takes them.  All fp32, contiguous. */
+int ruart_lstm_pack_params(const float* w_ih, const float* w_ih_r, const float* b_ih, const float* b_hh, const float* b_ih_r,
+                           const float* b_hh_r, const float* w_hh, const float* w_hh_r, float* w, float* b, float* whh, int G, int K, int h,
+                           void* stream);
+
 /* Pointwise part of ONE step of a wide LSTM over a ragged, length-sorted batch (the `multi2one` LSTM, Models/SDNet.py:137,
  * 269-271: hidden 300, 1-3 real words per item).  pre (n_active, 4h) = x W_ih^T + b + h_prev W_hh^T from the caller's GEMMs;
  * rows < n_active are advanced (acts (n_active,4h) = post-activation i,f,g,o saved for backward), rows >= n_active of

@@ -506,39 +506,67 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   const bool qvalid = tq < q1;
   const int lo_tok = tok_lo[qvalid ? tq : q0];
 
-  frag_t qh[2], ql[2];
+  // staging K and V: lane -> (row 16 wave + 4 i + lane / 16, 16-byte piece lane % 16): one load instruction covers four whole
+  // 256-byte row slices (8 cache lines, every byte used) where the first form - a lane taking 64 contiguous bytes in four
+  // loads - touched 32 lines per instruction, four times over.  The loads of a key tile are issued BEFORE anything waits: the
+  // first tile's ahead of the query rows' split (a window of <= 64 tokens has one tile: its whole input is then in flight at
+  // once instead of in two dependent round trips), a later tile's ahead of the barrier that frees the LDS images.
+  const int prow = lane >> 4, piece = lane & 15;
+  f32x4_t kx[4], vx[4];
+  int ls_v = -1;
+  float bs_v = 0.f;
+  auto load_kv = [&](int kt, int tn) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 16 + i * 4 + prow;
+      const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
+      kx[i] = load4(kp);
+      vx[i] = load4(kp + H);
+    }
+    if (tid < 64) {
+      const bool in = tid < tn;
+      ls_v = in ? tok_lo[kt + tid] : -1;
+      bs_v = (in && key_bias) ? key_bias[kt + tid] : 0.f;
+    }
+  };
+  f32x4_t qx[4];
   {
     const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) split_f16x8(load4(qp + ks * 32), load4(qp + ks * 32 + 4), qh[ks], ql[ks]);
+    for (int ks = 0; ks < 2; ++ks) {
+      qx[2 * ks] = load4(qp + ks * 32);
+      qx[2 * ks + 1] = load4(qp + ks * 32 + 4);
+    }
   }
+  load_kv(k0, min(64, k1 - k0));
+  frag_t qh[2], ql[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) split_f16x8(qx[2 * ks], qx[2 * ks + 1], qh[ks], ql[ks]);
   float m = -1e30f, l = 0.f;
   f32x4_t o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int srow = tid >> 2, sc0 = (tid & 3) * 2;       // staging: row 0..63, two 8-element chunks
   for (int kt = k0; kt < k1; kt += 64) {
     const int tn = min(64, k1 - kt);
-    __syncthreads();
+    if (kt != k0) {
+      load_kv(kt, tn);
+      __syncthreads();                  // every wave is done reading the previous tile's images
+    }
     {
-      // staging K and V: lane -> (row 16 wave + 4 i + lane / 16, 16-byte piece lane % 16): one load instruction covers four whole
-      // 256-byte row slices (8 cache lines, every byte used) where the first form - a lane taking 64 contiguous bytes in four
-      // loads - touched 32 lines per instruction, four times over
-      const int prow = lane >> 4, piece = lane & 15;
-      f32x4_t kx[4], vx[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wave * 16 + i * 4 + prow;
-        const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
-        kx[i] = load4(kp);
-        vx[i] = load4(kp + H);
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 16 + i * 4 + prow;
         if (row >= tn) kx[i] = vx[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};       // rows past the window: zero keys / values
         f16x4_t kh4, kl4, vh4, vl4;
+#ifdef RUART_ABL_ATTN_NOSPLIT        // diagnostic build: the loaded bytes go to LDS as they are (wrong numbers; the time of a kernel whose
+        {                            // producer had written the hi / lo pair itself: 136.9 -> 132.5 us - the split is not what costs)
+          union { f32x4_t f; struct { f16x4_t a, b; } h; } uk, uv;
+          uk.f = kx[i];
+          uv.f = vx[i];
+          kh4 = uk.h.a; kl4 = uk.h.b; vh4 = uv.h.a; vl4 = uv.h.b;
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           kh4[e] = (f16_t)kx[i][e];
@@ -546,6 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
           vh4[e] = (f16_t)vx[i][e];
           vl4[e] = (f16_t)(vx[i][e] - (float)vh4[e]);
         }
+#endif
         const int off = row * RS + piece * 8;
         *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
         *reinterpret_cast<f16x4_t*>(Kl + off) = kl4;
@@ -553,9 +582,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
         *reinterpret_cast<f16x4_t*>(Vl + off) = vl4;
       }
       if (tid < 64) {
-        const bool in = tid < tn;
-        Ls[tid] = in ? tok_lo[kt + tid] : -1;
-        Bs[tid] = (in && key_bias) ? key_bias[kt + tid] : 0.f;
+        Ls[tid] = ls_v;
+        Bs[tid] = bs_v;
       }
     }
     __syncthreads();

@@ -535,6 +535,45 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 
 extern int* ruart_nan_flag_ptr;
 
+// The operands one bidirectional nn.LSTM layer's kernels take, assembled from its eight parameter tensors in ONE launch (torch: two
+// cats, two adds and a stack - five launches per layer and step, 55 of a step's ~900):
+//   w (2 G, K) = [w_ih ; w_ih_r],  b (2 G) = [b_ih + b_hh ; b_ih_r + b_hh_r],  whh (2, G, h) = [w_hh , w_hh_r]      (G = 4 h)
+__global__ void lstm_pack_params_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_ih_r, const float* __restrict__ b_ih,
+                                        const float* __restrict__ b_hh, const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r,
+                                        const float* __restrict__ w_hh, const float* __restrict__ w_hh_r, float* __restrict__ w,
+                                        float* __restrict__ b, float* __restrict__ whh, long long n_w, long long n_hh, int G) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n_w + 2 * n_hh + 2 * G; i += stride) {
+    if (i < n_w) {
+      w[i] = w_ih[i];
+    } else if (i < 2 * n_w) {
+      w[i] = w_ih_r[i - n_w];
+    } else if (i < 2 * n_w + n_hh) {
+      whh[i - 2 * n_w] = w_hh[i - 2 * n_w];
+    } else if (i < 2 * n_w + 2 * n_hh) {
+      whh[i - 2 * n_w] = w_hh_r[i - 2 * n_w - n_hh];
+    } else {
+      const int j = (int)(i - 2 * n_w - 2 * n_hh);
+      b[j] = j < G ? b_ih[j] + b_hh[j] : b_ih_r[j - G] + b_hh_r[j - G];
+    }
+  }
+}
+
+extern "C" int ruart_lstm_pack_params(const float* w_ih, const float* w_ih_r, const float* b_ih, const float* b_hh, const float* b_ih_r,
+                                      const float* b_hh_r, const float* w_hh, const float* w_hh_r, float* w, float* b, float* whh, int G,
+                                      int K, int h, void* stream) {
+  RUART_ENTRY();
+  if (G <= 0 || K <= 0 || h <= 0 || !w_ih || !w_ih_r || !b_ih || !b_hh || !b_ih_r || !b_hh_r || !w_hh || !w_hh_r || !w || !b || !whh)
+    return (int)hipErrorInvalidValue;
+  const long long n_w = (long long)G * K, n_hh = (long long)G * h;
+  const long long total = 2 * n_w + 2 * n_hh + 2 * G;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(lstm_pack_params_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r, w_hh,
+                     w_hh_r, w, b, whh, n_w, n_hh, G);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
 static int g_lstm_variant = 1;       // 1: 16 batch rows per workgroup on the matrix cores (default); 0: one workgroup per row, fp32 VALU
 extern "C" int ruart_lstm_set_variant(int v) {
   if (v != 0 && v != 1) return (int)hipErrorInvalidValue;

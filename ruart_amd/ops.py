@@ -579,15 +579,52 @@ class _LstmRecurrence(torch.autograd.Function):
         return gx, gw, None
 
 
+class _LstmPackParams(torch.autograd.Function):
+    """(w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r, w_hh, w_hh_r) -> (w, b, whh) as lstm_layer's kernels take them
+    (ruart_lstm_pack_params); the backward hands out slices of the incoming gradients - no launch."""
+
+    @staticmethod
+    def forward(ctx, w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r, w_hh, w_hh_r):
+        G, K = w_ih.shape
+        h = w_hh.shape[1]
+        if not (w_ih_r.shape == (G, K) and w_hh.shape == w_hh_r.shape == (G, h)
+                and b_ih.shape == b_hh.shape == b_ih_r.shape == b_hh_r.shape == (G,)):
+            raise ValueError("lstm_layer: the two directions must have the same shapes")
+        w = torch.empty(2 * G, K, dtype=torch.float32, device=w_ih.device)
+        b = torch.empty(2 * G, dtype=torch.float32, device=w_ih.device)
+        whh = torch.empty(2, G, h, dtype=torch.float32, device=w_ih.device)
+        hip.check(hip.load().ruart_lstm_pack_params(hip.ptr(w_ih), hip.ptr(w_ih_r), hip.ptr(b_ih), hip.ptr(b_hh), hip.ptr(b_ih_r), hip.ptr(b_hh_r),
+                                                    hip.ptr(w_hh), hip.ptr(w_hh_r), hip.ptr(w), hip.ptr(b), hip.ptr(whh), G, K, h,
+                                                    hip.stream_ptr(w_ih.device)), "ruart_lstm_pack_params")
+        ctx.G = G
+        return w, b, whh
+
+    @staticmethod
+    def backward(ctx, gw, gb, gwhh):
+        G = ctx.G
+        gw0 = gw1 = gb0 = gb1 = gh0 = gh1 = None
+        if gw is not None:
+            gw0, gw1 = gw[:G], gw[G:]
+        if gb is not None:
+            gb0, gb1 = gb[:G], gb[G:]
+        if gwhh is not None:
+            gh0, gh1 = gwhh[0], gwhh[1]
+        return gw0, gw1, gb0, gb0, gb1, gb1, gh0, gh1
+
+
 def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None, mask=None):
     """One nn.LSTM layer (batch_first, zero state), uni- or bidirectional, on the persistent HIP recurrence.
     Parameters use torch's nn.LSTM layout so checkpoints load unchanged."""
     bidir = w_ih_r is not None
     wparts = None
     if bidir:
-        w = torch.cat([w_ih, w_ih_r], 0)
-        b = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r], 0)
-        whh = torch.stack([w_hh, w_hh_r], 0)
+        params = (w_ih, w_ih_r, b_ih, b_hh, b_ih_r, b_hh_r, w_hh, w_hh_r)
+        if trunk_gemm == "x3" and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in params):
+            w, b, whh = _LstmPackParams.apply(*params)          # one launch instead of two cats, two adds and a stack
+        else:
+            w = torch.cat([w_ih, w_ih_r], 0)
+            b = torch.cat([b_ih + b_hh, b_ih_r + b_hh_r], 0)
+            whh = torch.stack([w_hh, w_hh_r], 0)
         if isinstance(w_ih, torch.nn.Parameter) and isinstance(w_ih_r, torch.nn.Parameter):
             wparts = [(w_ih, 0, w_ih.shape[0]), (w_ih_r, w_ih.shape[0], w.shape[0])]
     else:

@@ -752,7 +752,9 @@ def test_last_layer_rows_and_dedup_are_result_neutral(golden, precision):
     for k in range(3):
         assert torch.equal(outs["all"][k], outs["last"][k]), k
     assert float((outs["both"][0] - outs["all"][0]).abs().max()) < 2e-5
-    assert torch.allclose(outs["both"][1], outs["all"][1], rtol=1e-3, atol=1e-5 if precision == "fp16" else 1e-7)
+    # (entries of the alpha gradient that cancel to ~1e-5 of the largest one move by a few 1e-7: absolute bound at 1e-4 of the scale)
+    scale = float(outs["all"][1].abs().max())
+    assert torch.allclose(outs["both"][1], outs["all"][1], rtol=1e-3, atol=max(1e-5 if precision == "fp16" else 1e-7, 1e-4 * scale))
 
 
 def test_deferred_weight_gradients_are_bitwise_the_same(golden):
