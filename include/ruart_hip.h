@@ -441,8 +441,8 @@ int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const float* B, long 
 
 /* A HIP stream restricted to ``n_cus`` compute units (the mask enables the first n_cus bits).  Optional knob for the encoder
  * pass that runs one step ahead beside the SDNet trunk (opt["bert_prefetch_cus"]): the CUs left out of the mask stay free for
- * the trunk's short kernels.  Off by default - it did not pay on MI355X.  n_cus <= 0 or >= the device's CU count creates an
- * ordinary stream.  ruart_stream_destroy drops it early; never call that from an atexit hook (teardown order
+ * the trunk's short kernels (240 of 256 in the fp16c schedule).  n_cus = 0 or |n_cus| >= the device's CU count creates an
+ * ordinary stream; n_cus < 0 enables the LAST |n_cus| bits instead (experiments).  ruart_stream_destroy drops it early; never call that from an atexit hook (teardown order
  * of the runtime / profiler is not under the caller's control) - process exit releases the stream. */
 int ruart_stream_create_cu_masked(int n_cus, void** stream_out);
 int ruart_stream_destroy(void* stream);

@@ -615,7 +615,12 @@ extern "C" int ruart_stream_create_cu_masked(int n_cus, void** stream_out) {
   if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -2;
   hipStream_t s = nullptr;
   hipError_t e;
-  if (n_cus <= 0 || n_cus >= total) {
+  if (n_cus < 0 && -n_cus < total) {
+    // the LAST |n_cus| bits (experiments: a second set of streams kept off most of the CUs a prefix-masked stream uses)
+    uint32_t mask[16] = {0};
+    for (int i = total + n_cus; i < total && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+  } else if (n_cus <= 0 || n_cus >= total) {
     e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   } else {
     // the FIRST n_cus bits.  Measured on MI355X (fp16c bench, encoder stream masked): n_cus = 240 / 224 of 256 -> 25.8 ms per step

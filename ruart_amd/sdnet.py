@@ -501,7 +501,11 @@ class SDNet(nn.Module):
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != dev:
             pr = int(os.environ.get("RUART_TRUNK_PRIORITY", 0))      # same priority as the step stream (trainer.update)
-            st = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
+            ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))          # experiments: see trainer.update
+            if ncu != 0:
+                st = (hip.cu_masked_stream(ncu, dev), hip.cu_masked_stream(ncu, dev))
+            else:
+                st = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
             self._streams = st
         return st
 

@@ -251,7 +251,12 @@ class SDNetTrainer(BaseTrainer):
         unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
         if dev.type == "cuda" and not unlocked:          # (a trainable encoder: nothing runs ahead, plain stream)
             if getattr(self, "_step_stream", None) is None:
-                self._step_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RUART_TRUNK_PRIORITY", 0)))
+                ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))         # experiments: the trunk's streams limited to n CUs
+                if ncu != 0:
+                    from . import hip
+                    self._step_stream = hip.cu_masked_stream(ncu, dev)
+                else:
+                    self._step_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RUART_TRUNK_PRIORITY", 0)))
             self._step_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._step_stream):
                 out = self._update(batch, batch_i, next_batch)
