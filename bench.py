@@ -312,7 +312,7 @@ def main():
     if a.include_h2d:                            # what a loader worker produces: tensors on the host + the numpy batch index
         from ruart_amd.batch import BatchIndex
         host_batches = []
-        for i in range(max(a.n_batches, 3)):     # three objects in rotation: current, lookahead, and the one just retired
+        for i in range(max(a.n_batches, 4)):     # four objects in rotation: current, lookahead, the one being staged, the one just retired
             hb = synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank + i, n_q=30, n_ocr=n_ocr, n_od=n_od)
             hb[0]["_ruart_host_index"] = BatchIndex(hb[0], hb[1], hb[2], opt)
             if not os.environ.get("RUART_BENCH_PAGEABLE"):       # what DataLoader(pin_memory=True) does on its pinning thread
@@ -342,13 +342,18 @@ def main():
 
     def step(i):
         b = staged.pop(i, None) or fresh(i)
-        if host_batches is not None and not a.no_prefetch:
+        if host_batches is not None and not a.no_prefetch and i + 1 not in staged:
             staged[i + 1] = fresh(i + 1)           # the lookahead batch has to be on the device for its encoder pass
         if a.mode == "train":
             # steady-state pipeline: the frozen encoder pass of the NEXT batch overlaps this step's trunk; every timed step
             # still launches exactly one encoder pass and one full trunk forward/backward/optimizer step
             nb = None if a.no_prefetch else (staged[i + 1] if host_batches is not None else batches[(i + 1) % len(batches)])
-            tr.update(b, i, next_batch=nb)
+            if host_batches is not None and not a.no_prefetch:
+                # as SDNetTrainer.train does: the batch after next is shipped inside update(), where the host waits for the step anyway
+                tr.update(b, i, next_batch=nb, stage_next=lambda: fresh(i + 2))
+                staged[i + 2] = tr.staged
+            else:
+                tr.update(b, i, next_batch=nb)
         else:
             tr.network.eval()
             tr.network.drop_emb = False

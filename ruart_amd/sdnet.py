@@ -497,10 +497,23 @@ class SDNet(nn.Module):
         return ent["fn"]
 
     # -- stream plumbing -----------------------------------------------------------------------------------
+    def trunk_stream_priority(self):
+        """Priority of the step's streams (the trainer's step stream and the two branch streams): NORMAL beside a CU-masked encoder
+        stream - the fp16c schedule, where the encoder pass is the longer of the two and a high-priority trunk delays single tiles of
+        its GEMM grids (25.5 -> 24.5 ms per step) - and HIGH otherwise: beside an unmasked encoder stream of equal priority the
+        trunk's small kernels wait behind 256-workgroup GEMM rounds (plain f16: 21.2 ms against 18.6).  RUART_TRUNK_PRIORITY
+        overrides (experiments)."""
+        env = os.environ.get("RUART_TRUNK_PRIORITY")
+        if env is not None:
+            return int(env)
+        bert = getattr(self, "Bert", None)
+        masked = int(os.environ.get("RUART_PREFETCH_CUS", getattr(bert, "_opt_prefetch_cus", 0) or 0)) > 0
+        return 0 if masked else -1
+
     def _side_streams(self, dev):
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != dev:
-            pr = int(os.environ.get("RUART_TRUNK_PRIORITY", 0))      # same priority as the step stream (trainer.update)
+            pr = self.trunk_stream_priority()                       # same priority as the step stream (trainer.update)
             ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))          # experiments: see trainer.update
             if ncu != 0:
                 st = (hip.cu_masked_stream(ncu, dev), hip.cu_masked_stream(ncu, dev))

@@ -160,6 +160,7 @@ class SDNetTrainer(BaseTrainer):
     # -- model / optimizer ------------------------------------------------------------------------------------
     def setup_model(self, vocab_embedding):
         self.train_loss = AverageMeter()
+        self.staged = None                 # what update(stage_next=...) staged last
         opt = dict(self.opt)
         opt["device"] = self.device
         self.network = SDNet(opt, vocab_embedding).to(self.device)
@@ -241,12 +242,13 @@ class SDNetTrainer(BaseTrainer):
         return loss
 
     # -- one optimizer step -----------------------------------------------------------------------------------
-    def update(self, batch, batch_i=0, next_batch=None):
-        """One optimizer step.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
-        concurrently with this step's SDNet trunk, on its own stream.  The step runs on a stream of its own too, at NORMAL priority
-        (``RUART_TRUNK_PRIORITY`` to experiment): since the MFMA recurrences the encoder pass is the longer of the two, and a
-        high-priority trunk - the round-1/2 setting, from when the trunk was - takes the CUs first at every GEMM's start and
-        delays single tiles of its one-round grids (25.5 -> 24.5 ms per step)."""
+    def update(self, batch, batch_i=0, next_batch=None, stage_next=None):
+        """One optimizer step.  ``stage_next`` (optional callable): run once after the whole step has been enqueued and BEFORE the
+        host waits for its loss - the place to fetch the batch after next from the loader and ship it (``ToCUDA``): that costs
+        0.5-0.7 ms of host time per step, which delays the next encoder launch by as much when it sits between two ``update`` calls and
+        nothing when it sits where the host waits anyway.  Its return value is kept in ``self.staged``.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
+        concurrently with this step's SDNet trunk, on its own stream.  The step runs on a stream of its own too, whose priority ``SDNet.trunk_stream_priority``
+        chooses (normal beside the CU-masked encoder stream of the fp16c schedule, high otherwise)."""
         dev = self.device
         unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
         if dev.type == "cuda" and not unlocked:          # (a trainable encoder: nothing runs ahead, plain stream)
@@ -256,15 +258,15 @@ class SDNetTrainer(BaseTrainer):
                     from . import hip
                     self._step_stream = hip.cu_masked_stream(ncu, dev)
                 else:
-                    self._step_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RUART_TRUNK_PRIORITY", 0)))
+                    self._step_stream = torch.cuda.Stream(device=dev, priority=self.network.trunk_stream_priority())
             self._step_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self._step_stream):
-                out = self._update(batch, batch_i, next_batch)
+                out = self._update(batch, batch_i, next_batch, stage_next)
             torch.cuda.current_stream(dev).wait_stream(self._step_stream)
             return out
-        return self._update(batch, batch_i, next_batch)
+        return self._update(batch, batch_i, next_batch, stage_next)
 
-    def _update(self, batch, batch_i, next_batch):
+    def _update(self, batch, batch_i, next_batch, stage_next=None):
         self.network.train()
         self.network.drop_emb = True
         q_list, ocr_list, od_list, targets, extra_info = batch
@@ -292,7 +294,10 @@ class SDNetTrainer(BaseTrainer):
             if "GLOVE" in self.opt:
                 self.network.glove_embed.weight.data[tp:] = self.network.fixed_embedding_glove
         if self._defer_readback():
-            return self._readback_later(loss)
+            lazy = self._readback_later(loss, stage_next)
+            return lazy
+        if stage_next is not None:
+            self.staged = stage_next()
         # the reference's NaN contract (SDNetTrainer.py:339-359 + the asserts inside forward): one sync, here
         loss_val = loss.item()
         self.network.check_nan()
@@ -314,7 +319,7 @@ class SDNetTrainer(BaseTrainer):
             d = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
         return bool(d) and self.device.type == "cuda"
 
-    def _readback_later(self, loss):
+    def _readback_later(self, loss, stage_next=None):
         from . import ops
         slots = self.__dict__.setdefault("_rb_slots", [torch.empty(2, dtype=torch.float32).pin_memory() for _ in range(2)])
         host = slots[self.updates & 1]
@@ -329,6 +334,8 @@ class SDNetTrainer(BaseTrainer):
         ev.record(torch.cuda.current_stream(self.device))
         prev, self._rb_pending = self.__dict__.get("_rb_pending"), {"host": host, "event": ev, "value": None}
         lazy = _PendingLoss(self, self._rb_pending)
+        if stage_next is not None:
+            self.staged = stage_next()
         if prev is not None:
             self._resolve(prev)
         return lazy
@@ -478,16 +485,22 @@ class SDNetTrainer(BaseTrainer):
             train_loader = self._loader(train_data, sampler, workers=self.opt.get("num_worker", 0))
             val_loader = VQA_Dataset(self._records("val"), self.opt)
         it = iter(train_loader)
-        nxt = next(it, None)
-        nxt = self.ToCUDA(nxt) if nxt is not None else None
+
+        def stage():                                                  # the next batch of the loader, shipped to the device (or None)
+            b = next(it, None)
+            return self.ToCUDA(b) if b is not None else None
+
+        batch, nxt = stage(), None
+        if batch is not None:
+            nxt = stage()                                             # one batch of lookahead feeds the BERT prefetch
         batch_i = batch_st
-        while nxt is not None:
-            batch = nxt
-            nxt = next(it, None)
-            nxt = self.ToCUDA(nxt) if nxt is not None else None       # one batch of lookahead feeds the BERT prefetch
+        while batch is not None:
             if val_loader is not None and batch_i % eval_every == 0:
                 self.evaluate(val_loader, batch_i)
-            loss = self.update(batch, batch_i, next_batch=nxt)
+            # the batch after next is fetched and shipped inside update(), where the host waits for the step anyway
+            loss = self.update(batch, batch_i, next_batch=nxt, stage_next=stage if nxt is not None else None)
+            batch, nxt = nxt, (self.staged if nxt is not None else None)
+            self.staged = None
             if batch_i % log_every == 0:
                 log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
             batch_i += 1
