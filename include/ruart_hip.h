@@ -102,6 +102,10 @@ int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const fl
  * The only entry points that synchronise or allocate; never call them inside a timed or captured region. */
 int ruart_prof_enable(int on);
 int ruart_prof_read(double* total_ms, long long* launches, double* flops);
+/* Diagnostics on the same record pool: ruart_prof_mark puts a marker (flops = -tag) on any stream; ruart_prof_timeline returns every
+ * record's begin / end time in ms relative to the first record (it synchronises on the events; the pool is left as it is). */
+int ruart_prof_mark(int tag, void* stream);
+int ruart_prof_timeline(float* begin_ms, float* end_ms, double* flops, int max_records, int* n_records);
 
 /* ---- BERT row kernels ------------------------------------------------------------------------------------ */
 /* Models/Bert/modeling.py:185-199: out[r] = LN(word[ids[r]] + pos[pos_ids[r]] + type[0]). */

@@ -778,6 +778,32 @@ void ruart_prof_end_(void* rec, hipStream_t s) {
   if (rec) hipEventRecord(((ProfRec*)rec)->b, s);
 }
 
+// Diagnostics (tools/step_timeline.py): a marker record on any stream (flops = -tag) and the recorded launches' begin / end times in ms
+// relative to the first record - one time base for the encoder's GEMM launches and for points of the step stream.
+extern "C" int ruart_prof_mark(int tag, void* stream) {
+  RUART_ENTRY();
+  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return 0;
+  ProfRec* rec = &g_prof_pool[g_prof_used++];
+  rec->flops = -(double)tag;
+  hipEventRecord(rec->a, (hipStream_t)stream);
+  hipEventRecord(rec->b, (hipStream_t)stream);
+  return 0;
+}
+extern "C" int ruart_prof_timeline(float* begin_ms, float* end_ms, double* flops, int max_records, int* n_records) {
+  RUART_ENTRY();
+  if (!begin_ms || !end_ms || !flops || !n_records) return (int)hipErrorInvalidValue;
+  int n = 0;
+  for (size_t i = 0; i < g_prof_used && n < max_records; ++i, ++n) {
+    hipError_t e = hipEventSynchronize(g_prof_pool[i].b);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipEventElapsedTime(&begin_ms[n], g_prof_pool[0].a, g_prof_pool[i].a)) != hipSuccess) return (int)e;
+    if ((e = hipEventElapsedTime(&end_ms[n], g_prof_pool[0].a, g_prof_pool[i].b)) != hipSuccess) return (int)e;
+    flops[n] = g_prof_pool[i].flops;
+  }
+  *n_records = n;
+  return 0;
+}
+
 extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* flops) {
   RUART_ENTRY();
   double ms = 0.0, fl = 0.0;

@@ -130,6 +130,8 @@ _SIGNATURES = {
     "ruart_gemm_set_variant": (_I, [_I]),
     "ruart_prof_enable": (_I, [_I]),
     "ruart_prof_read": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong), POINTER(ctypes.c_double)]),
+    "ruart_prof_mark": (_I, [_I, _P]),
+    "ruart_prof_timeline": (_I, [_P, _P, _P, _I, _P]),
 }
 
 _lib = None
