@@ -19,6 +19,7 @@
 // (Measured alternative: the last workgroup of a tile to finish adds the slices in the same launch, agent-scope release /
 // acquire around a ticket counter.  Correct, but every workgroup pays the L2 write-back of the release: 39 -> 76 us on the
 // 6400 x 250 x 1800 projection, 20 -> 35 us on 2560 x 250 x 800.  The second launch costs 5-9 us.)
+#include <cstdlib>
 #include "common.h"
 #include "ruart_hip.h"
 
@@ -360,9 +361,11 @@ struct Plan { int tm, tiles, splitk; };
 // small output and a long reduction (weight gradients) are split along K, at least 4 steps of 32 per slice.
 Plan make_plan(int M, int N, int K, int amode, int bmode) {
   const int ksteps = (K + XBK - 1) / XBK;
+  static const int fill = [] { const char* e = getenv("RUART_X3_FILL"); return e ? atoi(e) : 448; }();        // (experiments)
+  static const int nosplit = [] { const char* e = getenv("RUART_X3_NOSPLIT_TILES"); return e ? atoi(e) : 160; }();
   auto split_for = [&](int tiles) {
-    if (tiles >= 160 || ksteps < 16) return 1;
-    int s = (448 + tiles - 1) / tiles;                 // aim at ~2 workgroups of the small tile per CU
+    if (tiles >= nosplit || ksteps < 16) return 1;
+    int s = (fill + tiles - 1) / tiles;                // aim at ~2 workgroups of the small tile per CU
     if (s > ksteps / 4) s = ksteps / 4;
     if (s > 64) s = 64;
     return s < 1 ? 1 : s;
