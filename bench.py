@@ -360,8 +360,11 @@ def main():
             if not a.no_prefetch:                 # same pipeline as training: the next batch's encoder pass beside this trunk
                 nb = staged[i + 1] if host_batches is not None else batches[(i + 1) % len(batches)]
                 tr.network.prefetch_bert(nb[0], nb[1], nb[2])
-            with torch.no_grad():
-                tr.network(b[0], b[1], b[2])
+            def fwd_only():
+                with torch.no_grad():
+                    scores, _ = tr.network(b[0], b[1], b[2])
+                scores.sum().item()               # as SDNetTrainer.predict: the host waits for every batch's scores (loss, decode)
+            tr.on_step_stream(fwd_only)           # ... on the trainer's non-blocking step stream, as predict() runs (trainer.on_step_stream)
 
     def sync():
         torch.cuda.synchronize()

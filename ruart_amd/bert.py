@@ -531,7 +531,16 @@ class Bert(nn.Module):
         self._in_use = 1                     # set whose layer outputs the current step's forward/backward reads
         # CUs the prefetch pass may occupy; the rest stay free for the trunk (0 = all, the default).
         self._pf_cus = int(os.environ.get("RUART_PREFETCH_CUS", self._opt_prefetch_cus))
-        self._pf_stream = None
+        self._pf_streams = {}                # CU count (0 = all) -> stream
+
+    def prefetch_cus(self):
+        """CUs the run-ahead pass may use NOW: the configured mask (240 in the fp16c schedule) in training - the trunk is on the
+        device for 85 % of a training step and needs CUs no GEMM workgroup can take - and all of them in evaluation, where the trunk's
+        forward is gone after a quarter of the step and the mask only costs (forward-only steps: 24.0 ms masked, 20.5 unmasked).
+        RUART_PREFETCH_CUS_EVAL overrides the evaluation value (experiments)."""
+        if self.training:
+            return self._pf_cus
+        return int(os.environ.get("RUART_PREFETCH_CUS_EVAL", 0))
 
     def prefetch(self, packed, after_stream=None):
         """Encode ``packed`` asynchronously into the buffer set the current step does NOT use; ``layers_for`` returns the
@@ -540,11 +549,10 @@ class Bert(nn.Module):
         if getattr(packed, "_layers", None) is not None or getattr(self, "bert_model", None) is not None or self._frozen_dropout_active():
             return                           # (a trainable encoder changes every step, a dropout pass is drawn per step: nothing to run ahead)
         dev = self._device
-        if self._pf_stream is None or self._pf_stream.device != dev:
-            # an ordinary stream by default; a CU-masked one (ruart_stream_create_cu_masked) only on request - measured on
-            # MI355X, keeping 32-96 CUs out of the encoder's reach did not shorten the step
-            self._pf_stream = hip.cu_masked_stream(self._pf_cus, dev) if self._pf_cus > 0 else torch.cuda.Stream(device=dev)
-        st = self._pf_stream
+        cus = self.prefetch_cus()
+        st = self._pf_streams.get(cus)
+        if st is None or st.device != dev:
+            st = self._pf_streams[cus] = hip.cu_masked_stream(cus, dev) if cus > 0 else torch.cuda.Stream(device=dev)
         # the set being recycled was last read by the step BEFORE the current one: waiting for the point where the current
         # step picked up its own layers (layers_for) is enough, wherever in the step the prefetch is launched
         if after_stream is not None:
@@ -563,8 +571,8 @@ class Bert(nn.Module):
 
     def close(self):
         """Release the CU-masked run-ahead stream (see hip.destroy_stream); a later prefetch creates a new one."""
-        st, self._pf_stream = getattr(self, "_pf_stream", None), None
-        if st is not None:
+        streams, self._pf_streams = getattr(self, "_pf_streams", {}), {}
+        for st in streams.values():
             if self._pending is not None:
                 self._pending._layers = None
                 self._pending = None

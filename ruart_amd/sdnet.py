@@ -507,19 +507,20 @@ class SDNet(nn.Module):
         if env is not None:
             return int(env)
         bert = getattr(self, "Bert", None)
-        masked = int(os.environ.get("RUART_PREFETCH_CUS", getattr(bert, "_opt_prefetch_cus", 0) or 0)) > 0
+        masked = bert is not None and hasattr(bert, "prefetch_cus") and bert.prefetch_cus() > 0
         return 0 if masked else -1
 
     def _side_streams(self, dev):
-        st = getattr(self, "_streams", None)
+        pr = self.trunk_stream_priority()                           # same priority as the step stream (trainer.on_step_stream)
+        cache = self.__dict__.setdefault("_streams", {})
+        st = cache.get(pr)
         if st is None or st[0].device != dev:
-            pr = self.trunk_stream_priority()                       # same priority as the step stream (trainer.update)
-            ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))          # experiments: see trainer.update
+            ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))          # experiments: see trainer.on_step_stream
             if ncu != 0:
                 st = (hip.cu_masked_stream(ncu, dev), hip.cu_masked_stream(ncu, dev))
             else:
                 st = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
-            self._streams = st
+            cache[pr] = st
         return st
 
     def check_nan(self):

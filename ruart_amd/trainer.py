@@ -249,22 +249,36 @@ class SDNetTrainer(BaseTrainer):
         nothing when it sits where the host waits anyway.  Its return value is kept in ``self.staged``.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
         concurrently with this step's SDNet trunk, on its own stream.  The step runs on a stream of its own too, whose priority ``SDNet.trunk_stream_priority``
         chooses (normal beside the CU-masked encoder stream of the fp16c schedule, high otherwise)."""
+        self.network.train()                      # (the step stream's priority depends on the mode: set it before choosing)
+        return self.on_step_stream(self._update, batch, batch_i, next_batch, stage_next)
+
+    def on_step_stream(self, fn, *args):
+        """Run ``fn(*args)`` - a training step or an evaluation forward - with the trainer's step stream current, and join it with the
+        caller's stream on both sides.  Needed for the encoder pass that runs one batch ahead to overlap anything: its CU-masked stream
+        (hipExtStreamCreateWithCUMask takes no flags) is a BLOCKING stream, i.e. every launch on the legacy default stream - torch's
+        current stream unless told otherwise - waits for all of the encoder's enqueued work and the two run strictly one after the
+        other (forward-only steps: 27 ms = 20 + 7, `tools/step_timeline.py --fwd`).  The step stream is a non-blocking pool stream.
+        (A trainable encoder: nothing runs ahead, the caller's stream is used as it is.)"""
         dev = self.device
         unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
-        if dev.type == "cuda" and not unlocked:          # (a trainable encoder: nothing runs ahead, plain stream)
-            if getattr(self, "_step_stream", None) is None:
-                ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))         # experiments: the trunk's streams limited to n CUs
-                if ncu != 0:
-                    from . import hip
-                    self._step_stream = hip.cu_masked_stream(ncu, dev)
-                else:
-                    self._step_stream = torch.cuda.Stream(device=dev, priority=self.network.trunk_stream_priority())
-            self._step_stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._step_stream):
-                out = self._update(batch, batch_i, next_batch, stage_next)
-            torch.cuda.current_stream(dev).wait_stream(self._step_stream)
-            return out
-        return self._update(batch, batch_i, next_batch, stage_next)
+        if dev.type != "cuda" or unlocked:
+            return fn(*args)
+        pr = self.network.trunk_stream_priority()       # (differs between training and evaluation in the fp16c schedule)
+        cache = self.__dict__.setdefault("_step_streams", {})
+        st = cache.get(pr)
+        if st is None:
+            ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))         # experiments: the trunk's streams limited to n CUs
+            if ncu != 0:
+                from . import hip
+                st = hip.cu_masked_stream(ncu, dev)
+            else:
+                st = torch.cuda.Stream(device=dev, priority=pr)
+            cache[pr] = st
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            out = fn(*args)
+        torch.cuda.current_stream(dev).wait_stream(st)
+        return out
 
     def _update(self, batch, batch_i, next_batch, stage_next=None):
         self.network.train()
@@ -360,6 +374,10 @@ class SDNetTrainer(BaseTrainer):
     def predict(self, batch, all_ans=False, next_batch=None):
         """Models/SDNetTrainer.py:378-451: arg-max over VALID answer slots, ANLS / ACC when answers are known.
         ``next_batch`` (already through ToCUDA): its frozen-encoder pass is started beside this batch's trunk, as in ``update``."""
+        self.network.eval()
+        return self.on_step_stream(self._predict, batch, all_ans, next_batch)
+
+    def _predict(self, batch, all_ans=False, next_batch=None):
         self.flush_readback()                  # (a deferred training step's asserts come before anything reads the weights)
         self.network.eval()
         self.network.drop_emb = False

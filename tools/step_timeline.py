@@ -40,10 +40,31 @@ def cs(*a, **k):
 
 
 net.forward, tr.optimizer.clip_and_step = fwd, cs
+FWD = "--fwd" in sys.argv                         # forward-only steps (evaluation mode, one host wait per batch as predict() has)
+
+
+def one(i):
+    if not FWD:
+        return tr.update(batches[i % 2], i, next_batch=batches[(i + 1) % 2])
+    net.eval()
+    net.drop_emb = False
+    nb, bb = batches[(i + 1) % 2], batches[i % 2]
+    net.prefetch_bert(nb[0], nb[1], nb[2])
+
+    def f():
+        with torch.no_grad():
+            sc, _ = net(bb[0], bb[1], bb[2])
+        sc.sum().item()
+    f() if "--default-stream" in sys.argv else tr.on_step_stream(f)
+
+
+for i in range(4):
+    one(i)
+torch.cuda.synchronize()
 lib.ruart_prof_enable(1)
 N = 6
 for i in range(N):
-    tr.update(batches[i % 2], i, next_batch=batches[(i + 1) % 2])
+    one(i)
 torch.cuda.synchronize()
 M = 8192
 b, e, f, n = (ctypes.c_float * M)(), (ctypes.c_float * M)(), (ctypes.c_double * M)(), ctypes.c_int(0)
