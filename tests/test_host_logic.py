@@ -467,3 +467,31 @@ def test_sort_ids_two_level_form():
         assert (np.diff(occ) > 0).all()                             # stable: occurrences in their original order
     short = _sort_ids(np.array([3, 3, 5]), None)
     assert len(short) == 3 and short[1].tolist() == [0, 2, 3] and short[2].tolist() == [3, 5]
+
+
+def test_stream_settings_follow_the_schedule(monkeypatch):
+    """The encoder pass that runs ahead is CU-masked only in training, and the step's streams take normal priority only beside a masked
+    pass (sdnet.SDNet.trunk_stream_priority, bert.Bert.prefetch_cus) - checked on bare objects, no device needed."""
+    from ruart_amd.bert import Bert
+    from ruart_amd.sdnet import SDNet
+    for k in ("RUART_TRUNK_PRIORITY", "RUART_PREFETCH_CUS_EVAL"):
+        monkeypatch.delenv(k, raising=False)
+
+    class FakeBert:
+        prefetch_cus = Bert.prefetch_cus
+
+        def __init__(self, cus, training):
+            self._pf_cus, self.training = cus, training
+
+    class FakeNet:
+        trunk_stream_priority = SDNet.trunk_stream_priority
+
+        def __init__(self, bert):
+            self.Bert = bert
+
+    assert FakeBert(240, True).prefetch_cus() == 240 and FakeBert(240, False).prefetch_cus() == 0
+    assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 0          # fp16c schedule, training: beside the masked pass
+    assert FakeNet(FakeBert(240, False)).trunk_stream_priority() == -1        # evaluation: unmasked pass, trunk first
+    assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
+    monkeypatch.setenv("RUART_TRUNK_PRIORITY", "-1")
+    assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == -1
