@@ -135,16 +135,27 @@ def test_encoder_prefetch_is_bitwise_equivalent():
         losses = []
         for k, i in enumerate(order):
             nxt = bs[order[k + 1]] if prefetch and k + 1 < len(order) and k != 3 else None      # step 3: no lookahead
-            losses.append(tr.update(bs[i], k, next_batch=nxt))
+            if prefetch == "staged":                         # the loader hook of train(): runs inside update, its result is kept
+                losses.append(tr.update(bs[i], k, next_batch=nxt, stage_next=lambda k=k: ("staged", k)))
+                assert tr.staged == ("staged", k)
+            else:
+                losses.append(tr.update(bs[i], k, next_batch=nxt))
             if k == 4:
                 losses.append(tr.predict(bs[1])[0])          # an inline encoder pass between two prefetched steps
+                if prefetch:                                 # evaluation with its own lookahead (unmasked run-ahead stream, step stream)
+                    losses.append(tr.predict(bs[2], next_batch=bs[3])[0])
+                    losses.append(tr.predict(bs[3])[0])      # ... consumes that pass
+                else:
+                    losses.append(tr.predict(bs[2])[0])
+                    losses.append(tr.predict(bs[3])[0])
         return losses, {n: p.detach().clone() for n, p in tr.network.named_parameters() if p.requires_grad}
 
     la, pa = run(False)
     lb, pb = run(True)
-    assert la == lb, (la, lb)
+    lc, pc = run("staged")
+    assert la == lb == lc, (la, lb, lc)
     for n in pa:
-        assert torch.equal(pa[n], pb[n]), n
+        assert torch.equal(pa[n], pb[n]) and torch.equal(pa[n], pc[n]), n
 
 
 def test_host_index_from_collate_gives_the_same_forward(golden):
