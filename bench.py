@@ -281,6 +281,9 @@ def main():
         opt["ruart_streams"] = os.environ["RUART_STREAMS"] != "0"
     if os.environ.get("RUART_DEFER_READBACK"):            # experiments: loss / NaN readback one step late (default: trained encoder only)
         opt["ruart_defer_readback"] = os.environ["RUART_DEFER_READBACK"] != "0"
+    if os.environ.get("RUART_TILE_ORDER_TRAIN"):          # experiments: one GROUP_M for every encoder GEMM of the training step
+        from ruart_amd import hip as _hip
+        _hip.check(_hip.load().ruart_gemm_set_tile_order(int(os.environ["RUART_TILE_ORDER_TRAIN"])), "set_tile_order")
     if os.environ.get("RUART_TRUNK_GRAD_GEMM"):           # experiments: x1 = one bf16 product for the trunk's gradient GEMMs
         opt["ruart_trunk_grad_gemm"] = os.environ["RUART_TRUNK_GRAD_GEMM"]
     if os.environ.get("RUART_DP_OVERLAP"):                # experiments: bucket exchange overlapped with backward (dp.py)
