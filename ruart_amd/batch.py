@@ -335,7 +335,9 @@ class BatchIndex:
             self._n_last = 0
             last_rows = np.zeros(0, dtype=np.int32)
             last_start = [np.zeros(0, dtype=np.int32)] * len(spans)
-            if frozen and opt.get("bert_last_rows", True) and T > 0:
+            # (the C side compacts only when a layer precedes the last one, bert_forward.hip last_layer_rows: same rule here, so the
+            # compacted starts are never paired with an uncompacted layer)
+            if frozen and opt.get("bert_last_rows", True) and T > 0 and int((opt.get("bert_config") or {}).get("num_hidden_layers", 12)) >= 2:
                 mark = np.zeros(T + 1, dtype=np.int64)
                 for (s_, l_, _, _) in spans:
                     np.add.at(mark, s_, 1)

@@ -561,17 +561,23 @@ class Bert(nn.Module):
             st.wait_event(self._pickup_event)
         else:
             st.wait_stream(torch.cuda.current_stream(dev))
+        # the previous run-ahead pass - consumed or dropped, on this stream or on the other CU mask's - wrote the same two buffer
+        # sets: this pass starts behind it (a no-op on the same stream; train -> evaluate switches streams, and a dropped pass
+        # may still be running on the masked one)
+        if getattr(self, "_last_pf_event", None) is not None:
+            st.wait_event(self._last_pf_event)
         if self._pending is not None and self._pending is not packed:
             self._pending._layers = None     # only one pass can be in flight: an older unconsumed one is dropped
         self._pending = packed
         with torch.cuda.stream(st):
             packed._set = self._in_use ^ 1
             packed._layers = bert_encode(self.weights, packed, self._bufsets[packed._set])
-            packed._event = st.record_event()
+            packed._event = self._last_pf_event = st.record_event()
 
     def close(self):
         """Release the CU-masked run-ahead stream (see hip.destroy_stream); a later prefetch creates a new one."""
         streams, self._pf_streams = getattr(self, "_pf_streams", {}), {}
+        self._last_pf_event = None
         for st in streams.values():
             if self._pending is not None:
                 self._pending._layers = None

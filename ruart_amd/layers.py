@@ -298,7 +298,10 @@ class GetFinalScores(nn.Module):
 
     def forward(self, x, h0, x_mask, ES_len, mask_flag=None):
         if (self.useES and self.no_answer and x.is_cuda and ops.trunk_gemm == "x3" and x.dim() == 3 and x.size(2) % 4 == 0
-                and x.size(1) <= 1024 and 0 < ES_len < x.size(1) and fused_scorer_enabled):
+                and x.size(1) <= 1024 and 0 < ES_len < x.size(1) and fused_scorer_enabled
+                # the fused form models the dropout of x only as the variational (B, D) mask; without VARIATIONAL_DROPOUT the
+                # reference drops x element-wise (Layers.py:32-39, 454): those configurations take the op-by-op form below
+                and (do_seq_dropout or not self.training or dropout_p == 0)):
             return self._forward_fused(x, h0, x_mask, ES_len, mask_flag)
         if self.useES:
             score_ocr = self.attn(x[:, ES_len:], h0, x_mask[:, ES_len:], mask_flag=mask_flag)

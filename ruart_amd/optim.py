@@ -124,9 +124,11 @@ class FusedAdamax:
         # the kernel wrote the parameters through raw pointers: tell torch (version counters feed autograd's saved-tensor checks and
         # the trainable encoder's operand cache, bert_train16.accurate_weights)
         bump = getattr(torch.autograd.graph, "increment_version", None)
-        if bump is not None:
-            for p in live:
-                bump(p)
+        if bump is None:
+            raise RuntimeError("torch.autograd.graph.increment_version is missing: caches keyed on parameter versions "
+                               "(bert_train16.accurate_weights) would go stale after this step")
+        for p in live:
+            bump(p)
 
     def step(self):
         self.clip_and_step(None)
