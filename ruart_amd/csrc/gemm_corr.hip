@@ -64,9 +64,17 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
   return r;
 }
 
+// Diagnostic builds (tools/build_variant.sh v224 -DRUART_GEMM_VGPR_HALF=112): cap the kernel at 2 x N architectural VGPRs (hipcc doubles
+// an amdgpu_num_vgpr request on the unified register file of gfx90a+), so that 2 waves per SIMD leave registers for a co-resident small
+// wave of another kernel.  At 224 the compiler spills inside the K loop: not a product setting.
+#ifdef RUART_GEMM_VGPR_HALF
+#define RUART_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RUART_GEMM_VGPR_HALF)))
+#else
+#define RUART_VGPR_ATTR
+#endif
 // EPI: 0 fp32 out; 1 fp32 out + fp32 residual; 2 GELU, split out (C = f16 rows, C8 = fp8 rows of 2N bytes)
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restrict__ A16, const char* __restrict__ A8, int pitch_a,
+__global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restrict__ A16, const char* __restrict__ A8, int pitch_a,
                                                             const char* __restrict__ W16, const char* __restrict__ W8, int pitch_w,
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             void* __restrict__ C, int ldc, unsigned char* __restrict__ C8, int M, int N,
