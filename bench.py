@@ -109,9 +109,10 @@ def build_trainer(opt, cfg, device, seed=1033, process_group=None):
     return tr, sw
 
 
-def cpu_baseline(opt, cfg, n_samples, seed=1033):
+def cpu_baseline(opt, cfg, n_samples, seed=1033, runs=3):
     """Time the CPU oracle's forward + loss + backward on `n_samples` samples of the bench workload: one warm-up run on one
-    sample, then the median of three runs."""
+    sample, then the median of `runs` runs (the stress shapes - bert-large, 300 OCR items - take one run of one
+    sample: ~20 s of 16 cores)."""
     from oracle import ruart_oracle as O          # CPU baseline leg: allowed importer
     from ruart_amd import synth
     try:
@@ -132,15 +133,18 @@ def cpu_baseline(opt, cfg, n_samples, seed=1033):
         return time.perf_counter() - t0
 
     run(1, 98)
-    times = sorted(run(n_samples, 99 + i) for i in range(3))
-    dt = times[1]
-    return {"value": round(n_samples / dt, 4), "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d sample(s) of the bench workload (q=30, ocr=100, obj=36, bert-base), fwd+loss+bwd: 1 warm-up run, median of 3 "
-                      "(%.1f / %.1f / %.1f s)" % (n_samples, times[0], times[1], times[2]),
-            "reference_itself": {"value": 0.312, "unit": "samples/s", "threads": 8, "samples": 4,
-                                 "measured": "once, in the build container, round 1 - a constant of this file, NOT timed in this run",
-                                 "where": "build container - the reference cannot travel to the GPU box; the oracle ran 0.374 samples/s "
-                                          "beside it, outputs equal to 1.7e-6", "source": "oracle/time_reference.py"}}
+    times = sorted(run(n_samples, 99 + i) for i in range(runs))
+    dt = times[len(times) // 2]
+    out = {"value": round(n_samples / dt, 4), "unit": "samples/s", "cores": int(torch.get_num_threads()), "kind": "port",
+           "sample": "%d sample(s) of the bench workload (q=30, ocr=%d, obj=%d, %s), fwd+loss+bwd: 1 warm-up run, median of %d (%s s)"
+                     % (n_samples, opt["max_ocr_num"], opt["max_od_num"], "bert-large" if cfg["hidden_size"] == 1024 else "bert-base", runs,
+                        " / ".join("%.1f" % t for t in times))}
+    if cfg["hidden_size"] == 768 and opt["max_ocr_num"] == 100:      # the reference was timed on the headline workload only
+        out["reference_itself"] = {"value": 0.312, "unit": "samples/s", "threads": 8, "samples": 4,
+                                   "measured": "once, in the build container, round 1 - a constant of this file, NOT timed in this run",
+                                   "where": "build container - the reference cannot travel to the GPU box; the oracle ran 0.374 samples/s "
+                                            "beside it, outputs equal to 1.7e-6", "source": "oracle/time_reference.py"}
+    return out
 
 
 def live_parity(tr, opt, batch, golden):
@@ -174,6 +178,7 @@ def bert512_measure(a, device, lib, precision, batch=64, steps=None, warmup=None
     warmup = a.warmup if warmup is None else warmup
     cfg = synth.bert_config()
     W = BertEncoderWeights(synth.make_bert_weights(cfg, seed=1033, w_std=0.02), cfg, device, precision)
+    W.c_model.tail_cus = int(os.environ.get("RUART_TAIL_CUS", 0))       # experiments: tail split of the GEMMs (off: DESIGN.md section 5, round 4)
     if os.environ.get("RUART_TILE_ORDER"):              # experiments: GROUP_M of the encoder GEMM's tile walk
         hip.check(lib.ruart_gemm_set_tile_order(int(os.environ["RUART_TILE_ORDER"])), "set_tile_order")
     L = a.seq_len
@@ -302,7 +307,6 @@ def main():
         opt.update(BERT_LARGE=True, BERT_large_model_file="unused", max_ocr_num=300, max_od_num=100)
         cfg = synth.bert_config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
         n_ocr, n_od = 300, 100
-        a.no_roofline = a.no_cpu_baseline = True
     note("building model")
     tr, _ = build_trainer(opt, cfg, device, process_group=dist.group.WORLD if a.force_dp else None)
     dp = world > 1 or a.force_dp
@@ -423,7 +427,7 @@ def main():
             ach_t = fl_t / (ms_t * 1e-3) / 1e12
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")       # PMC passes cannot run inside this process:
-            if os.path.exists(tf) and a.batch == 64:                            # the committed rocprofv3 summary of this shape
+            if os.path.exists(tf) and a.batch == 64 and not a.stress:           # the committed rocprofv3 summary of this shape
                 traffic = json.load(open(tf)).get(GEMM_KERNEL[a.precision], {}).get("avg_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": GEMM_KERNEL[a.precision], "achieved": round(ach_t, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach_t / PEAK_TFLOPS, 4), "traffic": traffic, "launches": n_t,
@@ -465,7 +469,7 @@ def main():
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle) ...")
-            out["cpu_baseline"] = cpu_baseline(opt, cfg, a.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(opt, cfg, 1, runs=1) if a.stress else cpu_baseline(opt, cfg, a.cpu_samples)
         print(json.dumps(out), file=out_stream, flush=True)
     if dp:
         dist.barrier()

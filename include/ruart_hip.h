@@ -44,6 +44,12 @@ const char* ruart_version(void);
 int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
                      int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
                      void* stream);
+/* ruart_gemm_16_nt with the TAIL SPLIT of ruart_gemm_16c_nt_ws (below): tail_ws = ruart_gemm_16_tail_ws_bytes(M, N, K, cus) bytes of scratch,
+ * cus = the CU count the plan is made for; NULL / too small / cus <= 0: the single launch.  Takes effect on the 256 x 256 four-phase kernel. */
+size_t ruart_gemm_16_tail_ws_bytes(int M, int N, int K, int cus);
+int ruart_gemm_16_nt_ws(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, int residual_dtype,
+                        void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype, void* tail_ws, size_t tail_ws_bytes, int cus,
+                        void* stream);
 /* The same projections in the "f16 + fp8 correction" precision mode (csrc/gemm_corr.hip):
  *   C = act(A16 . W16^T + 2^-18 * A8 . W8^T + bias) [+ residual]
  * A16 (M, K) f16 and A8 (M, 2K) e4m3 bytes with the SAME row pitch in bytes (2 * lda): A8 row = [fp8((a - f16(a)) * 2^11), K bytes |
@@ -63,6 +69,15 @@ int ruart_f16c_shifts(int* out4);
  * (a plain f16 product through this kernel).  corr 1 / 2 need K % 256 == 0. */
 int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                           const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr, void* stream);
+/* The same product with a TAIL SPLIT: a 256 x 256 tile per CU runs a product in whole rounds of `cus` tiles, and the tiles of the last,
+ * partial round (e.g. 21 of 501 on a 240-CU stream: 2.09 -> 3 rounds) idle most of the chip for a full tile time.  With a workspace
+ * of ruart_gemm_16c_tail_ws_bytes(M, N, K, cus) bytes those tiles are cut along K into 2 .. 8 slices (short workgroups dispatched behind
+ * the full tiles) and a second small launch adds a tile's slices in slice order and runs its epilogue: deterministic, and a function of
+ * (M, N, K, cus) only.  tail_ws NULL / too small, cus <= 0, or corr != 3: exactly ruart_gemm_16c_nt_sel. */
+size_t ruart_gemm_16c_tail_ws_bytes(int M, int N, int K, int cus);
+int ruart_gemm_16c_nt_ws(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                         const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr, void* tail_ws,
+                         size_t tail_ws_bytes, int cus, void* stream);
 /* Training forward of the intermediate dense (Models/Bert/modeling.py:287-288): G16 = gelu(A . W^T + bias) and the pre-activation H16, both
  * (M x N) in the operands' 16-bit type, row stride ldc.  M, N % 256 == 0, K % 128 == 0. */
 int ruart_gemm_16_nt_gelu2(const void* A, int lda, const void* W, int ldw, const float* bias, void* H16, void* G16, int ldc, int M, int N, int K,
@@ -85,7 +100,8 @@ int ruart_gemm_16_nt_splitk(const void* A, int lda, const void* W, int ldw, floa
  * M, N % 256 == 0, T % 128 == 0, tchunk % 128 == 0; rows past the real tokens must be zero in at least one operand and finite in both. */
 int ruart_gemm_16_tn_splitk(const void* P, int ldp, const void* Q, int ldq, float* part, int ldc, int M, int N, int T, int tchunk,
                             int in_dtype, void* stream);
-/* Tuning knob: GROUP_M of the L2-friendly tile walk used by ruart_gemm_16_nt (0 = plain row-major, default 8). */
+/* Tuning knob: pins GROUP_M of the L2-friendly tile walk of ruart_gemm_16_nt / ruart_gemm_16c_nt (0 = plain row-major; 1 .. 64); -1 returns
+ * to the default, a per-problem rule in the tile counts and K (csrc/gemm_shared.h, ruart_tile_group_m). */
 int ruart_gemm_set_tile_order(int group_m);
 /* Tile variant of ruart_gemm_16_nt: 5 (default) = 256x256 tile, four phases per K-tile with the prefetch in flight across
  * barriers (needs M, N % 256 == 0 and K % 128 == 0); 3 = 256x256 tile, plain two-stage loop (M, N % 256 == 0); 0 = 128x128
@@ -242,6 +258,9 @@ typedef struct {
   const void* const* w8_ao;
   const void* const* w8_ff1;
   const void* const* w8_ff2;
+  int tail_cus;   /* CU count the encoder GEMMs plan their TAIL SPLIT for (ruart_gemm_16c_nt_ws / ruart_gemm_16_nt_ws): the CUs of the stream's
+                     mask, or of the device; 0 = single-launch products.  The plan depends on (rows, N, K, tail_cus) only, so passes on
+                     different streams of one model agree bit for bit.  Enlarges ruart_bert_workspace_bytes by tail_cus x 256 KB. */
 } ruart_bert_model;
 
 typedef struct {

@@ -171,6 +171,78 @@ def gen_layers():
     save("layers", **out)
 
 
+def gen_layers_extra():
+    """Per-op vectors for the two composite steps that had end-to-end coverage only: a9 DeepAttention
+    (Models/Layers.py:471-524, forward with return_bef_rnn and every gradient) and a5 SDNet.get_prealign_emb (Models/SDNet.py:495-551:
+    the reference's re-packing loops around the pre-align Attention), called on a stand-in object that carries only what the method
+    reads (opt, pre_align) - the method itself is the reference's."""
+    import types
+    import Models.Layers as L
+    import Models.SDNet as RS
+    L.set_dropout_prob(0.0)
+    L.set_seq_dropout(True)
+    g = np.random.default_rng(23)
+    out = {}
+
+    def rnd(*s, scale=1.0):
+        return (g.standard_normal(s) * scale).astype(np.float32)
+
+    # ---- DeepAttention: 2 abstraction levels + the high-level one on the question side -------------------------------------
+    B, L1, L2, Wd, Hh, HL, per = 3, 11, 6, 7, 4, 5, 8
+    opt = {"hidden_size": Hh, "highlvl_hidden_size": HL}
+    m = L.DeepAttention(opt, abstr_list_cnt=2, deep_att_hidden_size_per_abstr=per, correlation_func=3, word_hidden_size=Wd)
+    for n_, p in m.named_parameters():
+        a = g.uniform(-0.3, 0.3, tuple(p.shape)).astype(np.float32)
+        p.data = T(a)
+        out["deep_w_" + n_] = a
+    x1_word = [T(rnd(B, L1, Wd)).requires_grad_()]
+    x1_abstr = [T(rnd(B, L1, 2 * Hh)).requires_grad_() for _ in range(2)]
+    x2_word = [T(rnd(B, L2, Wd)).requires_grad_()]
+    x2_abstr = [T(rnd(B, L2, 2 * Hh)).requires_grad_() for _ in range(2)] + [T(rnd(B, L2, 2 * HL)).requires_grad_()]   # + high level
+    m1 = np.ones((B, L1), dtype=np.uint8)
+    m1[1, 8:] = 0
+    m2 = np.ones((B, L2), dtype=np.uint8)
+    m2[0, 4:] = 0
+    m2[2, 2:] = 0
+    h, pre = m(x1_word, x1_abstr, x2_word, x2_abstr, T(m1), T(m2), return_bef_rnn=True)
+    gh, gpre = T(rnd(*h.shape)), T(rnd(*pre.shape))
+    ((h * gh).sum() + (pre * gpre).sum()).backward()
+    out.update(deep_dims=np.array([B, L1, L2, Wd, Hh, HL, per]), deep_m1=m1, deep_m2=m2, deep_h=h.detach().numpy(),
+               deep_pre=pre.detach().numpy(), deep_gh=gh.numpy(), deep_gpre=gpre.numpy())
+    for name, lst in (("x1_word", x1_word), ("x1_abstr", x1_abstr), ("x2_word", x2_word), ("x2_abstr", x2_abstr)):
+        for i, t in enumerate(lst):
+            out["deep_%s_%d" % (name, i)] = t.detach().numpy()
+            out["deep_g_%s_%d" % (name, i)] = t.grad.numpy()
+    for n_, p in m.named_parameters():
+        out["deep_g_" + n_] = p.grad.numpy()
+
+    # ---- get_prealign_emb on a small ragged batch (the layout VQA_collate_fun produces; word vectors are 300-d in the method) ------
+    opt = default_opt(vocab_size=400, cuda=False)
+    Bp = 3
+    q, ocr, od, _, _ = synth.synthetic_batch(opt, Bp, seed=31, n_q=7, n_ocr=14, n_od=5, bert_vocab=500, ragged=True)
+    pa = L.Attention(300, 6, correlation_func=3, do_similarity=True)
+    wpa = g.uniform(-0.1, 0.1, tuple(pa.scoring.linear.weight.shape)).astype(np.float32)
+    pa.scoring.linear.weight.data = T(wpa)
+    stand_in = types.SimpleNamespace(opt=opt, pre_align=pa)
+    key_o, key_q = ("fasttext" if "fasttext" in opt["ocr_embedding"] else "glove"), ("fasttext" if "fasttext" in opt["q_embedding"] else "glove")
+    embs = {}
+    for name, lst, key in (("q", q, key_q), ("ocr", ocr, key_o), ("od", od, key_o)):
+        ids = lst[key]
+        e = T(rnd(ids.shape[0], ids.shape[1], 300, scale=0.5)).requires_grad_()
+        lst[key + "_emb"] = e
+        embs[name] = e
+    ocr_pa, od_pa = RS.SDNet.get_prealign_emb(stand_in, q, ocr, od, Bp)
+    g_ocr, g_od = T(rnd(*ocr_pa.shape)), T(rnd(*od_pa.shape))
+    ((ocr_pa * g_ocr).sum() + (od_pa * g_od).sum()).backward()
+    out.update(pre_B=np.array(Bp), pre_seed=np.array(31), pre_args=np.array([7, 14, 5, 500, 400]), pre_w=wpa, pre_diag=pa.scoring.diagonal.detach().numpy(),
+               pre_q_emb=embs["q"].detach().numpy(), pre_ocr_emb=embs["ocr"].detach().numpy(), pre_od_emb=embs["od"].detach().numpy(),
+               pre_ocr_out=ocr_pa.detach().numpy(), pre_od_out=od_pa.detach().numpy(), pre_g_ocr=g_ocr.numpy(), pre_g_od=g_od.numpy(),
+               pre_gq=embs["q"].grad.numpy(), pre_gocr=embs["ocr"].grad.numpy(), pre_god=embs["od"].grad.numpy(),
+               pre_gw=pa.scoring.linear.weight.grad.numpy(),
+               pre_ocr_num_cnt=np.array(ocr["num_cnt"]), pre_od_num_cnt=np.array(od["num_cnt"]))
+    save("layers_extra", **out)
+
+
 # ----------------------------------------------------------------------------------
 def gen_bert():
     """BertModel.forward: a small config stored with weights, and bert-base dims
@@ -860,9 +932,11 @@ def gen_update():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["layers", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc", "predict", "update"]
+    which = sys.argv[1:] or ["layers", "layers_extra", "bert", "e2e", "e2e_phoc", "e2e_unlocked", "host", "dataset", "phoc", "predict", "update"]
     if "layers" in which:
         gen_layers()
+    if "layers_extra" in which:
+        gen_layers_extra()
     if "bert" in which:
         gen_bert()
     if "e2e" in which:

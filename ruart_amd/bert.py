@@ -472,6 +472,12 @@ class Bert(nn.Module):
         # CUs out of the encoder's reach took the step from 26.7 to 25.8 ms.  The plain 16-bit modes gain nothing (round 1).
         self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 240 if precision == "fp16c" else 0))
         self._init_pipeline()
+        # Tail split of the encoder GEMMs (csrc/gemm_corr.hip, gemm.hip; opt['bert_tail_cus'] = the CU count the split is planned for, one
+        # value per model so that every pass computes the same bits).  OFF by default: measured on the bench batch (round 4, DESIGN.md
+        # section 5) it pays on the long-K output dense alone (-8 %) and the whole pass does not get shorter - a nearly empty last round
+        # of tiles runs at a higher clock and with the memory system to itself, it costs far less than a full tile time.
+        tail = opt.get("bert_tail_cus", os.environ.get("RUART_TAIL_CUS", 0))
+        self.weights.c_model.tail_cus = max(0, int(tail))
 
     def unlock(self):
         """Confs without LOCK_BERT (Models/SDNet.py:88-94): the encoder's parameters become fp32 ``nn.Parameter``s under the

@@ -38,11 +38,14 @@ static size_t corr_workspace_bytes(size_t R, size_t H, size_t I) {
   return t;
 }
 
+// slabs of the GEMMs' tail split (gemm_corr.hip / gemm.hip): at most tail_cus slices of 256 x 256 fp32 per product, one product at a time
+static size_t tail_bytes(const ruart_bert_model* m) { return m->tail_cus > 0 ? (size_t)m->tail_cus * 256 * 256 * 4 : 0; }
+
 extern "C" size_t ruart_bert_workspace_bytes(const ruart_bert_model* m, int n_rows) {
   const size_t es = m->dtype == RUART_DT_F32 ? 4 : 2;
   const size_t R = (size_t)n_rows, H = (size_t)m->hidden, I = (size_t)m->intermediate;
-  if (m->corr8) return corr_workspace_bytes(R, H, I);
-  size_t t = 0;
+  if (m->corr8) return corr_workspace_bytes(R, H, I) + align_up(tail_bytes(m), 256);
+  size_t t = align_up(tail_bytes(m), 256);   // (carved last)
   t += align_up(R * H * es, 256);       // x0   embedding output
   t += align_up(R * 3 * H * es, 256);   // qkv
   t += align_up(R * H * es, 256);       // ctx
@@ -90,6 +93,9 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
   void* mid8 = c.take((size_t)R * H * 2);
   void* ffn16 = c.take((size_t)R * I * 2);
   void* ffn8 = c.take((size_t)R * I * 2);
+  const size_t tws_bytes = tail_bytes(m);
+  void* tws = tws_bytes ? c.take(tws_bytes) : nullptr;
+  const int cus = m->tail_cus;
   int rc = ruart_bert_embed_ln_split(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, m->ln_eps, x32,
                                      x16, x8, H, R, H, stream);
   if (rc) return rc;
@@ -100,8 +106,8 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
     float* out = (float*)layers_out + (size_t)l * R * H;
     const bool on = (g_corr_layers >> (l & 63)) & 1ull;
     const int c_qkv = on ? g_corr_site[0] : 0, c_ao = on ? g_corr_site[1] : 0, c_ff1 = on ? g_corr_site[2] : 0, c_ff2 = on ? g_corr_site[3] : 0;
-    if ((rc = ruart_gemm_16c_nt_sel(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
-                                    RUART_ACT_NONE, c_qkv, stream)))
+    if ((rc = ruart_gemm_16c_nt_ws(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
+                                   RUART_ACT_NONE, c_qkv, tws, tws_bytes, cus, stream)))
       return rc;
     if ((rc = ruart_bert_attention_split(qkv, 3 * H, ctx16, ctx8, H, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
                                          b->tok_lo, b->tok_hi, b->key_bias, stream)))
@@ -121,15 +127,15 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
       res = qkv;
       ruart_prof_real_rows = n_last;
     }
-    if ((rc = ruart_gemm_16c_nt_sel(a16, a8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, Rl, H, H, RUART_ACT_NONE,
-                                    c_ao, stream)))
+    if ((rc = ruart_gemm_16c_nt_ws(a16, a8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, Rl, H, H, RUART_ACT_NONE,
+                                   c_ao, tws, tws_bytes, cus, stream)))
       return rc;
     if ((rc = ruart_rows_layernorm_split(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid32, mid16, mid8, H, Rl, H, stream))) return rc;
-    if ((rc = ruart_gemm_16c_nt_sel(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, Rl, I, H,
-                                    RUART_ACT_GELU, c_ff1, stream)))
+    if ((rc = ruart_gemm_16c_nt_ws(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, Rl, I, H,
+                                   RUART_ACT_GELU, c_ff1, tws, tws_bytes, cus, stream)))
       return rc;
-    if ((rc = ruart_gemm_16c_nt_sel(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, Rl, H, I,
-                                    RUART_ACT_NONE, c_ff2, stream)))
+    if ((rc = ruart_gemm_16c_nt_ws(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, Rl, H, I,
+                                   RUART_ACT_NONE, c_ff2, tws, tws_bytes, cus, stream)))
       return rc;
     // (the last layer's GEMM-operand copies go to the dead context buffers: x16 / x8 may hold its compacted inputs)
     if ((rc = ruart_rows_layernorm_split(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, Rl == R ? x16 : ctx16, Rl == R ? x8 : ctx8, H, Rl, H,
@@ -166,9 +172,11 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
                                dt, R, H, stream);
   if (rc) return rc;
 
+  const size_t tws_bytes = dt != RUART_DT_F32 ? tail_bytes(m) : 0;
+  void* tws = tws_bytes ? c.take(tws_bytes) : nullptr;
   auto gemm = [&](const void* A, int K, const void* W, const float* bias, const void* res, void* C, int out_dt, int N, int act, int rows) {
     if (dt != RUART_DT_F32)
-      return ruart_gemm_16_nt(A, K, W, K, bias, res, N, dt, C, N, out_dt, rows, N, K, act, dt, stream);
+      return ruart_gemm_16_nt_ws(A, K, W, K, bias, res, N, dt, C, N, out_dt, rows, N, K, act, dt, tws, tws_bytes, m->tail_cus, stream);
     if (m->f32_gemm == 1)                                        // fp32 storage, split-bf16 products (no K split at these sizes)
       return ruart_gemm_x3((const float*)A, K, 1, (const float*)W, 1, K, bias, (const float*)res, N, act, (float*)C, N, rows, N, K,
                            nullptr, 0, nullptr, nullptr, nullptr, 1, stream);

@@ -272,6 +272,102 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
   }
 }
 
+// Epilogue of one 256 x 256 tile of gemm_16_nt_256p8 through LDS, eight rows per pass; shared with the fix-up kernel of its split tail
+// tiles (gemm_16_fixup).  `smem`: >= 8 x 32 x 272 bytes no wave reads as operand tiles any more.
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__device__ __forceinline__ void p8_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, int tm, const float* __restrict__ bias,
+                                            const void* __restrict__ R, int ldr, void* __restrict__ C, int ldc, int N,
+                                            void* __restrict__ C2, float* __restrict__ colpart, int hh0 = 0, int hh1 = 4) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  constexpr int ERS = 272;
+  char* my = smem + wave * (32 * ERS);
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + wn * 64 + rcol;
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) {
+    if (hh < hh0 || hh >= hh1) continue;           // (the fix-up kernel runs one 32-row pass per workgroup)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
+    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
+    f32x4_t v[8], res[8];
+    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    if (RES != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    if (ACT == 3) {
+      // backward through the GELU (R = the f16 pre-activation H): C = acc * gelu'(H) - the gradient at the intermediate dense output -,
+      // C2 = gelu(H) again (the X operand of the next weight gradient), colsum += this pass's rows of C before their rounding
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const f32x4_t hv = load4(reinterpret_cast<const f16_t*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
+        f32x2_t g0, d0, g1, d1;
+        gelu_fwd_bwd_pk((f32x2_t){hv[0], hv[1]}, g0, d0);
+        gelu_fwd_bwd_pk((f32x2_t){hv[2], hv[3]}, g1, d1);
+        v[rr] *= (f32x4_t){d0.x, d0.y, d1.x, d1.y};
+        colsum += v[rr];
+        store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, (f32x4_t){g0.x, g0.y, g1.x, g1.y});
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+      }
+      continue;
+    }
+    if (ACT == 2) {                                          // training forward: the pre-activation is kept for the backward pass
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+    }
+    if (ACT != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      if (RES != 0) v[rr] += res[rr];
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+    }
+  }
+  if (ACT == 3 && colpart) {
+    // the wave's 128 rows: lanes l, l + 16, l + 32, l + 48 hold the same four columns
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      colsum[r] += __shfl_xor(colsum[r], 16, 64);
+      colsum[r] += __shfl_xor(colsum[r], 32, 64);
+    }
+    if (lane < 16) store4(colpart + (size_t)(tm * 2 + wm) * N + ncol, colsum);
+  }
+}
+
+// (tm, tn) of logical tile `id` under the GROUP_M walk (groups of `order` row panels, column-major inside a group)
+__device__ __forceinline__ void p8_tile_of(int id, int ntm, int ntn, int order, int& tm, int& tn) {
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 256x256x64, four phases per K-tile with the prefetch in flight ACROSS barriers (the "8-phase" schedule of the CDNA4
 // playbook: 2 K-tiles = 8 phases per loop iteration).  Same tile, wave layout, swizzle and epilogue as gemm_16_nt_256sq.
@@ -296,7 +392,8 @@ template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
                                                            void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk,
-                                                           void* __restrict__ C2, float* __restrict__ colpart
+                                                           void* __restrict__ C2, float* __restrict__ colpart, int n_full, int S,
+                                                           float* __restrict__ slabs
 #ifdef RUART_P8_STAMPS
                                                            , unsigned long long* __restrict__ stamps
 #endif
@@ -330,19 +427,24 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   // K-tile, 4 no stagger, 16 prefetch issued between the MFMAs instead of in the read segment.  0 in production.
   constexpr int ab = RUART_P8_ABLATE;
   const int ntn = N / BN4, ntm = M / BM4;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  if (order == 0) {
-    tm = id / ntn;
-    tn = id % ntn;
+  // Workgroups [0, n_full) own whole tiles (XCD-contiguous walk); the rest of the grid are the K slices of the last tiles - the tail
+  // split of the launcher (p8_tail_plan, as in gemm_corr.hip): S workgroups per tile, dispatched last, each over nt / S K-tiles,
+  // parking its partial sums in `slabs` for gemm_16_fixup.  n_full == gridDim.x: no split (every other caller).
+  const int bid = blockIdx.x;
+  int id, slice = -1;
+  if (bid < n_full) {
+    id = xcd_remap(bid, n_full);
   } else {
-    const int per_group = order * ntn;
-    const int g = id / per_group, first = g * order;
-    const int gsz = min(ntm - first, order);
-    const int r = id - g * per_group;
-    tm = first + r % gsz;
-    tn = r / gsz;
+    const int p = bid - n_full;
+    id = n_full + p / S;
+    slice = p - (p / S) * S;
   }
+  id = __builtin_amdgcn_readfirstlane(id);           // (integer division runs on the vector ALU; dma16's operands must be scalar)
+  slice = __builtin_amdgcn_readfirstlane(slice);
+  int tm, tn;
+  p8_tile_of(id, ntm, ntn, order, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm);
+  tn = __builtin_amdgcn_readfirstlane(tn);
   const int m0 = tm * BM4, n0 = tn * BN4;
 
   // staging: wave w fills local rows 16w .. 16w+15 of a half-tile (two 1 KB pieces of 8 rows x 128 B, lane-linear)
@@ -524,22 +626,28 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   using Ff = std::false_type;
 
   const int nt = K / BK;                         // even, >= 2
-  stage_w(0, 0, 0);
-  stage_a(0, 0, 0);
-  stage_w(0, 1, 0);
-  stage_a(0, 1, 0);
-  stage_w(1, 0, 1);
-  stage_a(1, 0, 1);
-  stage_w(1, 1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile 0 landed (this wave's share)
+  int kb = 0, ke = nt;                           // K-tiles of this workgroup: all, or slice `slice` of S (nt / S even, >= 2)
+  if (slice >= 0) {
+    const int L = __builtin_amdgcn_readfirstlane(nt / S);
+    kb = slice * L;
+    ke = kb + L;
+  }
+  stage_w(0, 0, kb);
+  stage_a(0, 0, kb);
+  stage_w(0, 1, kb);
+  stage_a(0, 1, kb);
+  stage_w(1, 0, kb + 1);
+  stage_a(1, 0, kb + 1);
+  stage_w(1, 1, kb + 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile kb landed (this wave's share)
   RUART_BAR();
   P8_STAMP(1);
 #if RUART_P8_BALANCED
   read_w(0, 0, wf0);
 #endif
   if (wave >= 4 && !(ab & 4)) RUART_BAR();   // stagger: waves 4-7 run one barrier behind
-  int t = 0;
-  for (; t + 2 < nt; t += 2) {
+  int t = kb;
+  for (; t + 2 < ke; t += 2) {
     tile(I0{}, Tt{}, Tt{}, t);
     tile(I1{}, Tt{}, Tt{}, t + 1);
   }
@@ -549,75 +657,16 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   RUART_BAR();                                                  // every wave is done reading operand tiles
   P8_STAMP(2);
 
-  constexpr int ERS = 272;
-  char* my = smem + wave * (32 * ERS);
-  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-  const int ncol = n0 + wn * 64 + rcol;
-  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
-  f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int hh = 0; hh < 4; ++hh) {
+  if (slice >= 0) {
+    // partial sums of this slice, thread-major ([i][j][tid] x 4 floats: 16-byte coalesced stores, read back the same way)
+    float* slab = slabs + ((size_t)(id - n_full) * S + slice) * (BM4 * BN4);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
-    // eight independent rows per pass, each stage over all eight before the next: the residual loads are all in flight
-    // before the first LDS read returns, and the GELU chains (2 transcendentals deep) interleave instead of running back to back
-    f32x4_t v[8], res[8];
-    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
-    if (RES != 0) {
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
-        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
-    if (ACT == 3) {
-      // backward through the GELU (R = the f16 pre-activation H): C = acc * gelu'(H) - the gradient at the intermediate dense output -,
-      // C2 = gelu(H) again (the X operand of the next weight gradient), colsum += this pass's rows of C before their rounding
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const f32x4_t hv = load4(reinterpret_cast<const f16_t*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
-        f32x2_t g0, d0, g1, d1;
-        gelu_fwd_bwd_pk((f32x2_t){hv[0], hv[1]}, g0, d0);
-        gelu_fwd_bwd_pk((f32x2_t){hv[2], hv[3]}, g1, d1);
-        v[rr] *= (f32x4_t){d0.x, d0.y, d1.x, d1.y};
-        colsum += v[rr];
-        store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, (f32x4_t){g0.x, g0.y, g1.x, g1.y});
-        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-      }
-      continue;
-    }
-    if (ACT == 2) {                                          // training forward: the pre-activation is kept for the backward pass
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) store4(reinterpret_cast<T16*>(C2) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-    }
-    if (ACT != 0) {
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4(v[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      if (RES != 0) v[rr] += res[rr];
-      if (OUT_F32)
-        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-      else
-        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
-    }
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * 8 + j) * 512 + tid) * 4) = acc[i][j];
+    return;
   }
-  if (ACT == 3 && colpart) {
-    // the wave's 128 rows: lanes l, l + 16, l + 32, l + 48 hold the same four columns
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      colsum[r] += __shfl_xor(colsum[r], 16, 64);
-      colsum[r] += __shfl_xor(colsum[r], 32, 64);
-    }
-    if (lane < 16) store4(colpart + (size_t)(tm * 2 + wm) * N + ncol, colsum);
-  }
+  p8_epilogue<T16, OUT_F32, RES, ACT>(acc, smem, m0, n0, tm, bias, R, ldr, C, ldc, N, C2, colpart);
 #ifdef RUART_P8_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -740,7 +789,12 @@ int ruart_prof_real_rows = 0;   // set by ruart_bert_forward: algorithmic row co
 extern int g_gemm_variant;
 extern "C" int ruart_gemm_set_tile_order(int group_m) {
   RUART_ENTRY();
-  if (group_m < 0 || group_m > 64) return (int)hipErrorInvalidValue;
+  if (group_m < -1 || group_m > 64) return (int)hipErrorInvalidValue;
+  if (group_m < 0) {                 // -1: back to the per-problem rule (ruart_tile_group_m)
+    g_tile_order = 8;
+    g_tile_order_auto = 1;
+    return 0;
+  }
   g_tile_order = group_m;
   g_tile_order_auto = 0;
   return 0;
@@ -825,6 +879,80 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
 int g_gemm_variant = 5;          // 0: 128x128 2-stage (any M, N multiple of 128); 3: 256x256 2-stage; 5: 256x256 four phases per K-tile, counted
                                  // vmcnt, staggered wave groups (M, N % 256 == 0, K % 128 == 0; else 3, else 0)
 
+// ---- tail split (see gemm_corr.hip: the same scheme for the plain 16-bit product) ---------------------------------------------------
+// Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices in slice order, then the tile's epilogue.
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_16_fixup(const float* __restrict__ slabs, int S, int n_full, const float* __restrict__ bias,
+                                                        const void* __restrict__ R, int ldr, void* __restrict__ C, int ldc, int M, int N,
+                                                        int order) {
+#define TILE_OF(id_, tm_, tn_) p8_tile_of(id_, M / BM4, N / BN4, order, tm_, tn_)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x >> 2, hh = blockIdx.x & 3;       // one 32-rows-per-wave pass of the epilogue per workgroup
+  int tm, tn;
+  TILE_OF(n_full + q, tm, tn);
+  const float* slab = slabs + (size_t)q * S * (BM4 * BN4);
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int hc = 0; hc < 4; ++hc) {
+    if (hc != hh) continue;                                  // (wave-uniform; keeps the accumulator indices static)
+    // slices in slice order, two slabs (16 loads per thread) in flight; the second of a pair is clamped and masked at an odd tail
+    for (int sl = 0; sl < S; sl += 2) {
+      const bool two = sl + 1 < S;
+      const float* p0 = slab + (size_t)sl * (BM4 * BN4);
+      const float* p1 = slab + (size_t)(two ? sl + 1 : sl) * (BM4 * BN4);
+      f32x4_t a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          a[i * 2 + j] = *reinterpret_cast<const f32x4_t*>(p0 + ((i * 8 + hc * 2 + j) * 512 + tid) * 4);
+          b[i * 2 + j] = *reinterpret_cast<const f32x4_t*>(p1 + ((i * 8 + hc * 2 + j) * 512 + tid) * 4);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][hc * 2 + j] += a[i * 2 + j];
+          if (two) acc[i][hc * 2 + j] += b[i * 2 + j];
+        }
+    }
+  }
+  p8_epilogue<T16, OUT_F32, RES, ACT>(acc, smem, tm * BM4, tn * BN4, tm, bias, R, ldr, C, ldc, N, nullptr, nullptr, hh, hh + 1);
+#undef TILE_OF
+}
+
+struct P8TailPlan { int n_full, r, S; };
+static P8TailPlan p8_tail_plan(int tiles, int nt, int cus) {
+  P8TailPlan p{tiles, 0, 0};
+  if (cus <= 0 || tiles <= cus) return p;
+  const int r = tiles % cus;
+  // the second launch (slab traffic, ~10 us) pays when the last round is nearly empty, or - up to 60 % full - when a tile is long (K >= 2048)
+  if (r == 0 || (4 * r > cus && !(5 * r <= 3 * cus && nt >= 32))) return p;
+  int S = cus / r;
+  if (S > 8) S = 8;
+  while (S >= 2 && (nt % S != 0 || (nt / S) % 2 != 0 || nt / S < 2)) --S;
+  if (S < 2) return p;
+  p.n_full = tiles - r;
+  p.r = r;
+  p.S = S;
+  return p;
+}
+extern "C" size_t ruart_gemm_16_tail_ws_bytes(int M, int N, int K, int cus) {
+  if (M <= 0 || N <= 0 || K <= 0 || M % BM4 || N % BN4 || K % 128) return 0;
+  const P8TailPlan p = p8_tail_plan((M / BM4) * (N / BN4), K / BK, cus);
+  return (size_t)p.r * p.S * BM4 * BN4 * sizeof(float);
+}
+// workspace / planning CU count of the call in flight (set by ruart_gemm_16_nt_ws around launch_gemm16; the library's entry points are
+// called from one host thread per process)
+static void* g_tail_ws = nullptr;
+static size_t g_tail_ws_bytes = 0;
+static int g_tail_cus = 0;
+
 template <typename T16, bool OF, int RS, int AC>
 static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr, void* C, int ldc,
                        int M, int N, int K, hipStream_t s) {
@@ -836,13 +964,26 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     (void)done;
 #ifdef RUART_P8_STAMPS
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0, (void*)nullptr, (float*)nullptr, g_p8_stamps);
+                       g_tile_order, 0, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, g_p8_stamps);
 #else
-    // GROUP_M: 8, or 4 for the short panels of the north-star (64, 512) halves (7.13 against 7.30 ms per pass, round 3) - until
-    // ruart_gemm_set_tile_order pins a value
-    const int order = g_tile_order_auto ? (M <= 16384 ? 4 : 8) : g_tile_order;
-    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       order, 0, (void*)nullptr, (float*)nullptr);
+    // GROUP_M from the tile counts (ruart_tile_group_m, gemm_shared.h) until ruart_gemm_set_tile_order pins a value
+    const int order = g_tile_order_auto ? ruart_tile_group_m(M / BM4, N / BN4, K, false) : g_tile_order;
+    const int tiles = (M / BM4) * (N / BN4);
+    P8TailPlan tp{tiles, 0, 0};
+    void* tail_ws = g_tail_ws;
+    if (tail_ws) {
+      tp = p8_tail_plan(tiles, K / BK, g_tail_cus);
+      if ((size_t)tp.r * tp.S * BM4 * BN4 * sizeof(float) > g_tail_ws_bytes) tp = P8TailPlan{tiles, 0, 0};
+    }
+    hipLaunchKernelGGL(kern, dim3(tp.n_full + tp.r * tp.S), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
+                       order, 0, (void*)nullptr, (float*)nullptr, tp.n_full, tp.S, (float*)tail_ws);
+    if (tp.r > 0) {
+      constexpr int flds = 8 * 32 * 272;
+      auto fix = gemm_16_fixup<T16, OF, RS, AC>;
+      static bool fdone = (hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, flds), true);
+      (void)fdone;
+      hipLaunchKernelGGL(fix, dim3(4 * tp.r), dim3(512), flds, s, (const float*)tail_ws, tp.S, tp.n_full, bias, residual, ldr, C, ldc, M, N, order);
+    }
 #endif
   } else if (g_gemm_variant >= 3 && sq) {
     auto kern = gemm_16_nt_256sq<T16, OF, RS, AC>;
@@ -875,6 +1016,17 @@ static int launch_gemm16(const void* A, int lda, const void* W, int ldw, const f
 #undef LAUNCH
   RUART_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ruart_gemm_16_nt_ws(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
+                                   int residual_dtype, void* C, int ldc, int out_dtype, int M, int N, int K, int act, int in_dtype,
+                                   void* tail_ws, size_t tail_ws_bytes, int cus, void* stream) {
+  g_tail_ws = (tail_ws && cus > 0) ? tail_ws : nullptr;
+  g_tail_ws_bytes = tail_ws_bytes;
+  g_tail_cus = cus;
+  const int rc = ruart_gemm_16_nt(A, lda, W, ldw, bias, residual, ldr, residual_dtype, C, ldc, out_dtype, M, N, K, act, in_dtype, stream);
+  g_tail_ws = nullptr;
+  return rc;
 }
 
 extern "C" int ruart_gemm_16_nt(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
@@ -910,10 +1062,10 @@ static void launch_gelu2(const void* A, int lda, const void* W, int ldw, const f
   (void)done;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (unsigned long long*)nullptr);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr);
 #endif
 }
 
@@ -953,10 +1105,10 @@ extern "C" int ruart_gemm_16_nt_gelu_bwd(const void* dY_bf16, int lda, const voi
   void* rec = ruart_prof_begin_((hipStream_t)stream, M, N, K);
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
-                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (unsigned long long*)nullptr);
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
-                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart);
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr);
 #endif
   ruart_prof_end_(rec, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
@@ -975,10 +1127,10 @@ static void launch_splitk(const void* A, int lda, const void* W, int ldw, float*
   const int nz = (K + kchunk - 1) / kchunk;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr);
 #endif
 }
 

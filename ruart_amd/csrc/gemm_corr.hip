@@ -64,6 +64,75 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
   return r;
 }
 
+// Epilogue of one 256 x 256 tile through LDS, eight rows per pass (as gemm_16_nt_256p8): bias, then per EPI the residual / GELU + split
+// stores.  Shared by the GEMM kernel and by the fix-up kernel of its split tail tiles.  `smem`: >= 8 x 32 x 272 bytes, no longer read as
+// operand tiles by any wave.
+template <int EPI>
+__device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, const float* __restrict__ bias,
+                                              const float* __restrict__ R, int ldr, void* __restrict__ C, int ldc,
+                                              unsigned char* __restrict__ C8, int N, int hh0 = 0, int hh1 = 4) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  constexpr int ERS = 272;
+  char* my = smem + wave * (32 * ERS);
+  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + wn * 64 + rcol;
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) {
+    if (hh < hh0 || hh >= hh1) continue;           // (the fix-up kernel runs one 32-row pass per workgroup)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
+    f32x4_t v[8], res[8];
+    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    if (EPI == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) res[rr] = load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+#ifndef RUART_ABL_NOGELU            // (diagnostic builds: the epilogue without its GELU / without its fp8 stores)
+    if (EPI == 2) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4_as(v[rr]);
+    }
+#endif
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const size_t row = (size_t)(mrow + rr * 4);
+      if (EPI == 1) v[rr] += res[rr];
+      if (EPI == 2)
+#ifdef RUART_ABL_NOFP8
+        *reinterpret_cast<f16x4_t*>(reinterpret_cast<f16_t*>(C) + row * ldc + ncol) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
+#else
+        store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+#endif
+      else
+        store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+    }
+  }
+}
+
+// (tm, tn) of logical tile `id` under the GROUP_M walk (groups of `order` row panels, column-major inside a group)
+__device__ __forceinline__ void corr_tile_of(int id, int ntm, int ntn, int order, int& tm, int& tn) {
+  if (order == 0) {
+    tm = id / ntn;
+    tn = id % ntn;
+  } else {
+    const int per_group = order * ntn;
+    const int g = id / per_group, first = g * order;
+    const int gsz = min(ntm - first, order);
+    const int r = id - g * per_group;
+    tm = first + r % gsz;
+    tn = r / gsz;
+  }
+}
+
 // Diagnostic builds (tools/build_variant.sh v224 -DRUART_GEMM_VGPR_HALF=112): cap the kernel at 2 x N architectural VGPRs (hipcc doubles
 // an amdgpu_num_vgpr request on the unified register file of gfx90a+), so that 2 waves per SIMD leave registers for a co-resident small
 // wave of another kernel.  At 224 the compiler spills inside the K loop: not a product setting.
@@ -78,7 +147,8 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
                                                             const char* __restrict__ W16, const char* __restrict__ W8, int pitch_w,
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             void* __restrict__ C, int ldc, unsigned char* __restrict__ C8, int M, int N,
-                                                            int K, int order, int n8, int o8) {
+                                                            int K, int order, int n8, int o8, int n_full, int S,
+                                                            float* __restrict__ slabs) {
   constexpr int kHalf = 128 * CBKB;              // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -87,19 +157,25 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int ntn = N / CBN, ntm = M / CBM;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  int tm, tn;
-  if (order == 0) {
-    tm = id / ntn;
-    tn = id % ntn;
+  // Workgroups [0, n_full) own whole tiles (XCD-contiguous walk over them); the rest of the grid are the K SLICES of the last
+  // tiles - the tail split of the launcher (corr_tail_plan): S workgroups per tile, dispatched last, each over NT / S K-tiles of
+  // one phase, parking its partial sums in `slabs` for gemm_16c_fixup.
+  const int bid = blockIdx.x;
+  int id, slice = -1;
+  if (bid < n_full) {
+    id = xcd_remap(bid, n_full);
   } else {
-    const int per_group = order * ntn;
-    const int g = id / per_group, first = g * order;
-    const int gsz = min(ntm - first, order);
-    const int r = id - g * per_group;
-    tm = first + r % gsz;
-    tn = r / gsz;
+    const int p = bid - n_full;
+    id = n_full + p / S;
+    slice = p - (p / S) * S;
   }
+  // (integer division runs on the vector ALU: pin the wave-uniform results to SGPRs, dma16's operands must be scalar)
+  id = __builtin_amdgcn_readfirstlane(id);
+  slice = __builtin_amdgcn_readfirstlane(slice);
+  int tm, tn;
+  corr_tile_of(id, ntm, ntn, order, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm);
+  tn = __builtin_amdgcn_readfirstlane(tn);
   const int m0 = tm * CBM, n0 = tn * CBN;
   const int nt = K / 64;                         // K-tiles of the f16 phase; the full fp8 phase has as many (2K bytes per row)
   // n8 fp8 K-tiles starting at fp8 tile o8: (nt, 0) = both correction products (production); (nt / 2, 0) = a_lo . w_hi only,
@@ -218,113 +294,191 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   using Tt = std::true_type;
   using Ff = std::false_type;
 
-  stage_w(0, 0, 0);
-  stage_a(0, 0, 0);
-  stage_w(0, 1, 0);
-  stage_a(0, 1, 0);
-  stage_w(1, 0, 1);
-  stage_a(1, 0, 1);
-  stage_w(1, 1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile 0 landed (this wave's share)
+  // K-tiles [kb, ke) of this workgroup: everything, or slice `slice` of S (S even: a slice never straddles the f16 / fp8 boundary)
+  int kb = 0, ke = NT;
+  if (slice >= 0) {
+    const int L = __builtin_amdgcn_readfirstlane(NT / S);
+    kb = slice * L;
+    ke = kb + L;
+  }
+  stage_w(0, 0, kb);
+  stage_a(0, 0, kb);
+  stage_w(0, 1, kb);
+  stage_a(0, 1, kb);
+  stage_w(1, 0, kb + 1);
+  stage_a(1, 0, kb + 1);
+  stage_w(1, 1, kb + 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile kb landed (this wave's share)
   RUART_BAR();
   if (wave >= 4) RUART_BAR();                                 // stagger: waves 4-7 run one barrier behind
-  int t = 0;
-  if (n8 > 0) {
-    for (; t < nt; t += 2) {                                  // f16 phase (nt is even; its tiles always have two successors)
+  // The K loop as two optional runs - K-tiles [a0, a1) of the f16 phase, then [b0, b1) of the fp8 phase (each empty or an even count
+  // >= 2): the whole product is (0, nt, nt, NT), a slice lives in one of the two, the no-correction ablation is (0, nt) alone.  The
+  // last two tiles of the LAST run stop prefetching.
+  int a0 = 0, a1 = nt, b0 = nt, b1 = NT;
+  if (slice >= 0) {
+    if (kb < nt) { a0 = kb; a1 = ke; b0 = b1 = 0; }
+    else { a0 = a1 = 0; b0 = kb; b1 = ke; }
+  }
+  const bool a_last = b0 >= b1;
+  if (a0 < a1) {
+    int t = a0;
+    const int body_end = a_last ? a1 - 2 : a1;
+    for (; t < body_end; t += 2) {
       tile(Ff{}, I0{}, Tt{}, Tt{}, t);
       tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
     }
-    for (; t + 2 < NT; t += 2) {                              // fp8 phase
+    if (a_last) {
+      tile(Ff{}, I0{}, Tt{}, Ff{}, t);
+      tile(Ff{}, I1{}, Ff{}, Ff{}, t + 1);
+    }
+  }
+  if (b0 < b1) {
+    int t = b0;
+    for (; t + 2 < b1; t += 2) {
       tile(Tt{}, I0{}, Tt{}, Tt{}, t);
       tile(Tt{}, I1{}, Tt{}, Tt{}, t + 1);
     }
     tile(Tt{}, I0{}, Tt{}, Ff{}, t);
     tile(Tt{}, I1{}, Ff{}, Ff{}, t + 1);
-  } else {                                                    // no correction at all (ablation): the f16 phase ends the K loop
-    for (; t + 2 < nt; t += 2) {
-      tile(Ff{}, I0{}, Tt{}, Tt{}, t);
-      tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
-    }
-    tile(Ff{}, I0{}, Tt{}, Ff{}, t);
-    tile(Ff{}, I1{}, Ff{}, Ff{}, t + 1);
   }
   if (wave < 4) RUART_BAR();                                  // waves 0-3 pair the lagging group's last barrier
   RUART_BAR();                                                // every wave is done reading operand tiles
 
-  // epilogue through LDS, eight rows per pass (as gemm_16_nt_256p8)
-  constexpr int ERS = 272;
-  char* my = smem + wave * (32 * ERS);
-  const int rrow = lane >> 4, rcol = (lane & 15) * 4;
-  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-  const int ncol = n0 + wn * 64 + rcol;
-  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
-#pragma unroll
-  for (int hh = 0; hh < 4; ++hh) {
+  if (slice >= 0) {
+    // partial sums of this slice, thread-major ([i][j][tid] x 4 floats: 16-byte coalesced stores, read back the same way)
+    float* slab = slabs + ((size_t)(id - n_full) * S + slice) * (CBM * CBN);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
-    f32x4_t v[8], res[8];
-    const int mrow = m0 + wm * 128 + hh * 32 + rrow;
-    if (EPI == 1) {
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * 8 + j) * 512 + tid) * 4) = acc[i][j];
+    return;
+  }
+  corr_epilogue<EPI>(acc, smem, m0, n0, bias, R, ldr, C, ldc, C8, N);
+}
+
+// Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices IN SLICE ORDER (deterministic), then the
+// tile's epilogue exactly as the GEMM kernel runs it.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_16c_fixup(const float* __restrict__ slabs, int S, int n_full, const float* __restrict__ bias,
+                                                         const float* __restrict__ R, int ldr, void* __restrict__ C, int ldc,
+                                                         unsigned char* __restrict__ C8, int M, int N, int order) {
+#define TILE_OF(id_, tm_, tn_) corr_tile_of(id_, M / CBM, N / CBN, order, tm_, tn_)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x >> 2, hh = blockIdx.x & 3;       // one 32-rows-per-wave pass of the epilogue per workgroup
+  int tm, tn;
+  TILE_OF(n_full + q, tm, tn);
+  const float* slab = slabs + (size_t)q * S * (CBM * CBN);
+  f32x4_t acc[4][8];
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) res[rr] = load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
-    }
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
-#ifndef RUART_ABL_NOGELU            // (diagnostic builds: the epilogue without its GELU / without its fp8 stores)
-    if (EPI == 2) {
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) v[rr] = gelu4_as(v[rr]);
-    }
-#endif
+  for (int hc = 0; hc < 4; ++hc) {
+    if (hc != hh) continue;                                  // (wave-uniform; keeps the accumulator indices static)
+    // slices in slice order, two slabs (16 loads per thread) in flight; the second of a pair is clamped and masked at an odd tail
+    for (int sl = 0; sl < S; sl += 2) {
+      const bool two = sl + 1 < S;
+      const float* p0 = slab + (size_t)sl * (CBM * CBN);
+      const float* p1 = slab + (size_t)(two ? sl + 1 : sl) * (CBM * CBN);
+      f32x4_t a[8], b[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const size_t row = (size_t)(mrow + rr * 4);
-      if (EPI == 1) v[rr] += res[rr];
-      if (EPI == 2)
-#ifdef RUART_ABL_NOFP8
-        *reinterpret_cast<f16x4_t*>(reinterpret_cast<f16_t*>(C) + row * ldc + ncol) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
-#else
-        store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
-#endif
-      else
-        store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          a[i * 2 + j] = *reinterpret_cast<const f32x4_t*>(p0 + ((i * 8 + hc * 2 + j) * 512 + tid) * 4);
+          b[i * 2 + j] = *reinterpret_cast<const f32x4_t*>(p1 + ((i * 8 + hc * 2 + j) * 512 + tid) * 4);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][hc * 2 + j] += a[i * 2 + j];
+          if (two) acc[i][hc * 2 + j] += b[i * 2 + j];
+        }
     }
   }
+  corr_epilogue<EPI>(acc, smem, tm * CBM, tn * CBN, bias, R, ldr, C, ldc, C8, N, hh, hh + 1);
+#undef TILE_OF
 }
 
 extern int g_tile_order, g_tile_order_auto;
-// GROUP_M of the tile walk per projection shape (measured, tools/gemm_corr_order_sweep.py, 42 880 rows, three interleaved runs on one
-// box, profiles/r03_gemm_order_sweep_time.log): wide outputs want tall groups (QKV N = 2304: 269 us at 16 against 283 at 8; FF1
-// N = 3072: 405 against 413), the long-K output dense a short one (FF2 K = 3072: 327 at 6 against 331), N = K = 768 stays at 8.
-// L2-miss traffic moves the OTHER way (smallest at GROUP_M 2-3, profiles/r03_gemm_order_sweep_fetch.log): it is not what bounds
-// this kernel.  An explicit ruart_gemm_set_tile_order overrides.
-static inline int corr_tile_order(int N, int K) {
+// GROUP_M of the tile walk: ruart_tile_group_m (gemm_shared.h) unless ruart_gemm_set_tile_order pinned a value.  L2-miss traffic moves the
+// OTHER way (smallest at GROUP_M 2-3, profiles/r03_gemm_order_sweep_fetch.log): it is not what bounds this kernel.
+static inline int corr_tile_order(int M, int N, int K) {
   if (!g_tile_order_auto) return g_tile_order;
-  if (N >= 2048) return 16;
-  return K >= 2048 ? 6 : 8;
+  return ruart_tile_group_m(M / CBM, N / CBN, K, true);
 }
 void* ruart_prof_begin_(hipStream_t s, int M, int N, int K);
 void ruart_prof_end_(void* rec, hipStream_t s);
 
+// ---- tail split ------------------------------------------------------------------------------------------------------------------
+// One 256 x 256 tile per CU means a product runs in whole ROUNDS of `cus` tiles, and the encoder's shapes do not fill their last one:
+// at the bench's 167 row tiles the N = 768 products are 501 tiles - on the 240 CUs of the run-ahead stream two full rounds and a
+// third of 21 tiles (2.09 -> 3 rounds: the mask cost the attention-output / output dense 44 % of their time), on all 256 CUs 1.96; the
+// (64, 512) north-star halves are 1.5 rounds.  With a workspace, the tiles of that last partial round are cut along K into S slices
+// each, dispatched behind the full tiles: r * S short workgroups instead of r full-length ones on an otherwise idle chip, then one
+// small launch (gemm_16c_fixup) adds a tile's slices in slice order and runs its epilogue.  Deterministic; the plan depends only on
+// (M, N, K, cus) - never on the stream the call happens to run on, so a pass on the CU-masked stream and an inline pass agree bit for bit.
+struct TailPlan { int n_full, r, S; };
+static TailPlan corr_tail_plan(int tiles, int NT, int cus) {
+  TailPlan p{tiles, 0, 0};
+  if (cus <= 0 || tiles <= cus) return p;                 // (a launch that is one partial round is left alone)
+  const int r = tiles % cus;
+  // the second launch (slab traffic, ~10 us) pays when the last round is nearly empty, or - up to 60 % full - when a tile is long (K >= 2048)
+  if (r == 0 || (4 * r > cus && !(5 * r <= 3 * cus && NT >= 64))) return p;
+  int S = cus / r;
+  if (S > 8) S = 8;                                        // slabs: S x 256 KB per tile, written and read once
+  S &= ~1;                                                 // even: a slice stays inside the f16 or the fp8 phase
+  while (S >= 2 && (NT % S != 0 || (NT / S) % 2 != 0 || NT / S < 2)) S -= 2;
+  if (S < 2) return p;
+  p.n_full = tiles - r;
+  p.r = r;
+  p.S = S;
+  return p;
+}
+extern "C" size_t ruart_gemm_16c_tail_ws_bytes(int M, int N, int K, int cus) {
+  if (M <= 0 || N <= 0 || K <= 0 || M % CBM || N % CBN || K % 128) return 0;
+  const TailPlan p = corr_tail_plan((M / CBM) * (N / CBN), 2 * (K / 64), cus);
+  return (size_t)p.r * p.S * CBM * CBN * sizeof(float);
+}
+
 template <int EPI>
 static void launch_corr(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
-                        const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int corr, hipStream_t s) {
+                        const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int corr, void* tail_ws,
+                        size_t tail_ws_bytes, int cus, hipStream_t s) {
   constexpr int lds = 2 * 2 * CBM * CBKB;                // 128 KB
   const int nt = K / 64;
   const int n8 = corr == 3 ? nt : (corr ? nt / 2 : 0), o8 = corr == 2 ? nt / 2 : 0;
+  const int tiles = (M / CBM) * (N / CBN), order = corr_tile_order(M, N, K);
+  TailPlan p{tiles, 0, 0};
+  if (corr == 3 && tail_ws) {
+    p = corr_tail_plan(tiles, 2 * nt, cus);
+    if ((size_t)p.r * p.S * CBM * CBN * sizeof(float) > tail_ws_bytes) p = TailPlan{tiles, 0, 0};
+  }
   auto kern = gemm_16c_nt_256p8<EPI>;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
-  hipLaunchKernelGGL(kern, dim3((M / CBM) * (N / CBN)), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
-                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, corr_tile_order(N, K), n8, o8);
+  hipLaunchKernelGGL(kern, dim3(p.n_full + p.r * p.S), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
+                     (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, order, n8, o8, p.n_full, p.S,
+                     (float*)tail_ws);
+  if (p.r > 0) {
+    constexpr int flds = 8 * 32 * 272;                    // the epilogue's staging image
+    auto fix = gemm_16c_fixup<EPI>;
+    static bool fdone = (hipFuncSetAttribute((const void*)fix, hipFuncAttributeMaxDynamicSharedMemorySize, flds), true);
+    (void)fdone;
+    hipLaunchKernelGGL(fix, dim3(4 * p.r), dim3(512), flds, s, (const float*)tail_ws, p.S, p.n_full, bias, residual, ldr, C, ldc,
+                       (unsigned char*)C8, M, N, order);
+  }
 }
 
-extern "C" int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
-                                     const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr,
-                                     void* stream) {
+// ruart_gemm_16c_nt_sel with the tail split (above): tail_ws = ruart_gemm_16c_tail_ws_bytes(M, N, K, cus) bytes of scratch the call
+// may use until it has finished on `stream`, cus = the CU count the plan is made for (the stream's CU mask, or the device's CUs);
+// tail_ws NULL / too small or cus <= 0: the single-launch form.
+extern "C" int ruart_gemm_16c_nt_ws(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                                    const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr,
+                                    void* tail_ws, size_t tail_ws_bytes, int cus, void* stream) {
   RUART_ENTRY();
   if (corr < 0 || corr > 3 || ((corr == 1 || corr == 2) && K % 256)) return (int)hipErrorInvalidValue;
   if (M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
@@ -340,14 +494,20 @@ extern "C" int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, c
   hipStream_t s = (hipStream_t)stream;
   void* rec = ruart_prof_begin_(s, M, N, K);
   if (act == RUART_ACT_GELU)
-    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, corr, s);
+    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
   else if (residual)
-    launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, corr, s);
+    launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
   else
-    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, corr, s);
+    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
   ruart_prof_end_(rec, s);
   RUART_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ruart_gemm_16c_nt_sel(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                                     const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int act, int corr,
+                                     void* stream) {
+  return ruart_gemm_16c_nt_ws(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, C8, M, N, K, act, corr, nullptr, 0, 0, stream);
 }
 
 extern "C" int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,

@@ -53,6 +53,24 @@ __device__ __forceinline__ void gelu_fwd_bwd_pk(f32x2_t x, f32x2_t& g, f32x2_t& 
   d = cdf + x * phi * 0.3989422804f;
 }
 
+// GROUP_M of the tile walk (workgroup ids walk groups of GROUP_M row panels, column-major inside a group) as a rule in the problem's TILE
+// counts and K - not in the benchmark's row count.  What the sweeps show (tools/gemm_corr_order_sweep.py; round 3 at 42 880 rows x bert-base,
+// profiles/r03_gemm_order_sweep_time.log; round 4 at 121 344 rows x bert-large, profiles/r04_gemm_order_sweep.log): a wide output (>= 8
+// column tiles) wants tall groups - 16 while an operand panel is short (K < 1024: 393 KB per 256 rows in the fp16c form), 8 for the longer
+// panels of bert-large (QKV 1 251 us at 8, 1 291 at 16; FF1 1 831 / 1 906); a narrow output with a long reduction (K >= 2048) a shorter one
+// (6); everything else 8; short matrices (< 96 row tiles: the (64, 512) halves of the north-star shape) 4 in the plain 16-bit kernel.
+// `precise` = the fp16c kernel (twice the K-tiles per tile).  Differences between neighbouring settings are 1-5 %, the walk is not what
+// bounds these kernels.
+static inline int ruart_tile_group_m(int row_tiles, int col_tiles, int K, bool precise) {
+  int g = 8;
+  if (precise) {
+    if (col_tiles >= 8) g = K >= 1024 ? 8 : 16;
+    else if (K >= 2048) g = 6;
+  }
+  if (row_tiles < 96 && !precise) g = 4;
+  return g;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

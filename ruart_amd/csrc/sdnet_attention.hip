@@ -47,44 +47,62 @@ struct Act {
 };
 __device__ __forceinline__ Act no_act() { return Act{0, nullptr, 0}; }
 
-// stage rows [r0, r0+nr) x cols [c0, c0+CH) of a row-major (rows x cols, ld) matrix into dst[nr_pad][ldd], zero-filled
+// stage rows [r0, r0+nr) x cols [c0, c0+CH) of a row-major (rows x cols, ld) matrix into dst[nr_pad][ldd], zero-filled.
+// Sixteen independent loads in flight per thread before the first LDS store.  Every load is UNCONDITIONAL - out-of-range elements
+// read a clamped (valid) address and are zeroed by a select when they are stored.  Rounds 1-3 wrote `in_range ? src[..] : 0`: hipcc
+// branches around such a load and waits vmcnt(0) behind it (cdna_hip_programming.md, projection GEMM item 4c), so the "sixteen in
+// flight" were sixteen dependent L2 round trips and the three attention kernels ran at 0.85 TB/s.
 __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols,
                                       Act act = Act{0, nullptr, 0}) {
-  // sixteen independent loads in flight per thread before the first LDS store (the loop is latency-bound otherwise: every
-  // iteration would wait ~0.5 us for its own L2 round trip)
   const int total = nr_pad * CH;
   for (int e0 = threadIdx.x; e0 < total; e0 += 16 * blockDim.x) {
-    float v[16];
+    float v[16], dv[16];
+    unsigned ok = 0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int e = e0 + u * blockDim.x;
       const int r = e / CH, c = e % CH;
       const int gr = r0 + r, gc = c0 + c;
-      v[u] = (e < total && gr < rows && gc < cols) ? act(src[(size_t)gr * ld + gc], gc) : 0.f;
+      if (e < total && gr < rows && gc < cols) ok |= 1u << u;
+      v[u] = src[(size_t)min(gr, rows - 1) * ld + min(gc, cols - 1)];
+    }
+    if (act.diag_len > 1) {                      // (wave-uniform: one branch around the group, not one per load)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dv[u] = act.diag[min(c0 + (e0 + u * (int)blockDim.x) % CH, cols - 1)];
+    } else {
+      const float d1 = act.diag_len == 1 ? act.diag[0] : 1.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dv[u] = d1;
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int e = e0 + u * blockDim.x;
-      if (e < total) dst[(e / CH) * ldd + (e % CH)] = v[u];
+      float x = v[u];
+      if (act.relu) x = fmaxf(x, 0.f);
+      x *= dv[u];
+      if (e < total) dst[(e / CH) * ldd + (e % CH)] = ((ok >> u) & 1u) ? x : 0.f;
     }
   }
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
 __device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols,
                                           const float* mul = nullptr) {
-  float v[4];                                  // 16 * CH = 1024 elements, 256 threads: all four loads in flight together
+  float v[4], m[4];                            // 16 * CH = 1024 elements, 256 threads: all four loads in flight together
+  unsigned ok = 0;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = threadIdx.x + u * 256;
     const int c = e & 15, r = e >> 4;          // c: 16 source columns (fast), r: 64 source rows
     const int gr = r0 + r, gc = c0 + c;
-    v[u] = (gr < rows && gc < cols) ? src[(size_t)gr * ld + gc] : 0.f;
-    if (mul && gr < rows && gc < cols) v[u] *= mul[(size_t)gr * ld + gc];
+    if (gr < rows && gc < cols) ok |= 1u << u;
+    const size_t at = (size_t)min(gr, rows - 1) * ld + min(gc, cols - 1);
+    v[u] = src[at];
+    m[u] = mul ? mul[at] : 1.f;                // (wave-uniform condition; the address is valid either way)
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = threadIdx.x + u * 256;
-    dst[(e & 15) * ldd + (e >> 4)] = v[u];
+    dst[(e & 15) * ldd + (e >> 4)] = ((ok >> u) & 1u) ? v[u] * m[u] : 0.f;
   }
 }
 
@@ -335,14 +353,49 @@ __device__ __forceinline__ float grid_partial_total(const float* part, float* re
   return block_sum<4>(s, red);
 }
 
+// The streaming loops below keep FOUR independent 16-byte loads per thread in flight (clamped indices, a select afterwards: no load sits
+// behind a branch); n % 4 != 0 or an unaligned base takes the scalar tail form for everything.
+#define WLN_FOR4(n4, ...)                                                                          \
+  for (long long i_ = blockIdx.x * 256LL + threadIdx.x; i_ < (n4); i_ += 4LL * 256 * WLN_BLOCKS) { \
+    long long ix_[4];                                                                              \
+    bool ok_[4];                                                                                   \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                             \
+      const long long j_ = i_ + (long long)u_ * 256 * WLN_BLOCKS;                                  \
+      ok_[u_] = j_ < (n4);                                                                         \
+      ix_[u_] = ok_[u_] ? j_ : (n4) - 1;                                                           \
+    }                                                                                              \
+    __VA_ARGS__                                                                                    \
+  }
+__device__ __forceinline__ bool wln_vec_ok(const void* a, const void* b, const void* c, long long n) {
+  return ((n & 3) == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0) && n >= 4;
+}
+
 __global__ __launch_bounds__(256) void wln_sum_kernel(const float* __restrict__ x, const float* __restrict__ x2, long long n,
                                                       float* __restrict__ part) {
   __shared__ float red[4];
   float s = 0.f, t = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
-    const float a = x[i];
-    s += a;
-    if (x2) t += a * x2[i];
+  if (wln_vec_ok(x, x2, nullptr, n)) {
+    const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
+    const f32x4_t* y4 = reinterpret_cast<const f32x4_t*>(x2);
+    const long long n4 = n >> 2;
+    if (x2) {
+      WLN_FOR4(n4, f32x4_t a[4], b[4];
+               _Pragma("unroll") for (int u = 0; u < 4; ++u) { a[u] = x4[ix_[u]]; b[u] = y4[ix_[u]]; }
+               _Pragma("unroll") for (int u = 0; u < 4; ++u) if (ok_[u]) {
+                 s += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+                 t += (a[u][0] * b[u][0] + a[u][1] * b[u][1]) + (a[u][2] * b[u][2] + a[u][3] * b[u][3]);
+               })
+    } else {
+      WLN_FOR4(n4, f32x4_t a[4];
+               _Pragma("unroll") for (int u = 0; u < 4; ++u) a[u] = x4[ix_[u]];
+               _Pragma("unroll") for (int u = 0; u < 4; ++u) if (ok_[u]) s += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);)
+    }
+  } else {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+      const float a = x[i];
+      s += a;
+      if (x2) t += a * x2[i];
+    }
   }
   s = block_sum<4>(s, red);
   if (x2) t = block_sum<4>(t, red);
@@ -356,9 +409,20 @@ __global__ __launch_bounds__(256) void wln_var_kernel(const float* __restrict__ 
   __shared__ float red[4];
   const float mean = grid_partial_total(part, red) / (float)n;
   float q = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
-    const float d = x[i] - mean;
-    q += d * d;
+  if (wln_vec_ok(x, nullptr, nullptr, n)) {
+    const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
+    const long long n4 = n >> 2;
+    WLN_FOR4(n4, f32x4_t a[4];
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) a[u] = x4[ix_[u]];
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) if (ok_[u]) {
+               const f32x4_t d = a[u] - mean;
+               q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+             })
+  } else {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+      const float d = x[i] - mean;
+      q += d * d;
+    }
   }
   q = block_sum<4>(q, red);
   if (threadIdx.x == 0) part2[blockIdx.x] = q;
@@ -375,10 +439,23 @@ __global__ __launch_bounds__(256) void wln_apply_kernel(const float* __restrict_
     stats[1] = rstd;
   }
   bool bad = false;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
-    const float o = (x[i] - mean) * rstd;
-    y[i] = o;
-    bad |= !(o == o);
+  if (wln_vec_ok(x, y, nullptr, n)) {
+    const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
+    f32x4_t* y4 = reinterpret_cast<f32x4_t*>(y);
+    const long long n4 = n >> 2;
+    WLN_FOR4(n4, f32x4_t a[4];
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) a[u] = x4[ix_[u]];
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) if (ok_[u]) {
+               const f32x4_t o = (a[u] - mean) * rstd;
+               y4[ix_[u]] = o;
+               bad |= !(o[0] == o[0]) || !(o[1] == o[1]) || !(o[2] == o[2]) || !(o[3] == o[3]);
+             })
+  } else {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) {
+      const float o = (x[i] - mean) * rstd;
+      y[i] = o;
+      bad |= !(o == o);
+    }
   }
   if (bad && nan_flag) atomicOr(nan_flag, 1);
 }
@@ -389,7 +466,17 @@ __global__ __launch_bounds__(256) void wln_bwd_kernel(const float* __restrict__ 
   const float mg = grid_partial_total(part, red) / (float)n;                 // mean(gy)
   const float mgy = grid_partial_total(part + WLN_BLOCKS, red) / (float)n;   // mean(gy * y)
   const float rstd = stats[1];
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) gx[i] = rstd * (gy[i] - mg - y[i] * mgy);
+  if (wln_vec_ok(y, gy, gx, n)) {
+    const f32x4_t* y4 = reinterpret_cast<const f32x4_t*>(y);
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gy);
+    f32x4_t* o4 = reinterpret_cast<f32x4_t*>(gx);
+    const long long n4 = n >> 2;
+    WLN_FOR4(n4, f32x4_t a[4], b[4];
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) { a[u] = y4[ix_[u]]; b[u] = g4[ix_[u]]; }
+             _Pragma("unroll") for (int u = 0; u < 4; ++u) if (ok_[u]) o4[ix_[u]] = rstd * (b[u] - mg - a[u] * mgy);)
+  } else {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * WLN_BLOCKS) gx[i] = rstd * (gy[i] - mg - y[i] * mgy);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

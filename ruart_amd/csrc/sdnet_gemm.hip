@@ -53,33 +53,61 @@ __device__ __forceinline__ int kc_off(int r, int chunk /*0..3*/) {
 
 // MODE 0: the operand's K index is contiguous in memory (element (row, k) at P[row*srow + k]);
 // MODE 1: its row index is contiguous (element (row, k) at P[k*sk + row]).
-template <int TM, int MODE, bool VEC>
+// VW: floats per load instruction along the contiguous index - 4 (16-byte aligned base, stride % 4 == 0, extent % 4 == 0), 2 (8-byte
+// analogue: the trunk's 250-wide activations) or 1.  EVERY load is unconditional: out-of-range rows / k are CLAMPED to the last valid
+// vector and zeroed by a select afterwards.  (Rounds 1-3 branched around each load - vector load inside the matrix, per-element scalar
+// loads at its edges and for every operand whose rows are not 16-byte aligned; hipcc waits vmcnt(0) behind every load it has to branch
+// around (cdna_hip_programming.md, projection GEMM item 4c), so an operand with 250-float rows was fetched as 16 DEPENDENT L2 round
+// trips per thread and K step.)
+template <int TM, int MODE, int VW>
 struct Stager {
   float v[16];
+  unsigned ok;      // bit e: element e is inside the matrix.  Applied in store(): a select right behind the load would make the wave
+                    // wait for it there, in front of the MFMAs the load is meant to overlap
+
+  __device__ __forceinline__ static void ldv(const float* p, float* out) {
+    if (VW == 4) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p);
+      out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = t[3];
+    } else if (VW == 2) {
+      typedef float f32x2v __attribute__((ext_vector_type(2)));
+      const f32x2v t = *reinterpret_cast<const f32x2v*>(p);
+      out[0] = t[0]; out[1] = t[1];
+    } else {
+      out[0] = *p;
+    }
+  }
 
   // rows = M or N (limit of the row index), r0 = first row of the tile, k0 = first k of this step.
   // S (optional): variational-dropout mask fused into the load.  MODE 0: element (row, k) *= S[(row / rpm) * K + k];
   // MODE 1: element (row, k) *= S[(k / rpm) * rows + row]  (rpm = time steps that share one mask row).
+  // MASKED is a compile-time flag: a run-time `if (S)` around the mask loads would put every load behind a branch again.
+  template <bool MASKED>
   __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid,
                                        const float* __restrict__ S = nullptr, int rpm = 1) {
+    ok = 0;
     if (MODE == 0) {
       const int kq = (tid & 7) * 4;                   // 4 consecutive k
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = r0 + p * (TM / 4) + (tid >> 3), k = k0 + kq;
-        const float* src = P + (long)r * srow + k;
-        if (r < rows && VEC && k + 3 < K) {
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
-          v[p * 4 + 0] = t[0]; v[p * 4 + 1] = t[1]; v[p * 4 + 2] = t[2]; v[p * 4 + 3] = t[3];
-        } else {
+        const int rc = min(r, rows - 1);
+        const float* rowp = P + (long)rc * srow;
+        const float* srowp = (MASKED && S) ? S + (size_t)(rc / rpm) * K : nullptr;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[p * 4 + i] = (r < rows && k + i < K) ? src[i] : 0.f;
-        }
-        if (S && r < rows) {
-          const float* sp = S + (size_t)(r / rpm) * K + k;
+        for (int j = 0; j < 4; j += VW) {
+          const int kk = k + j, kc = min(kk, K - VW);
+          float t[VW];
+          ldv(rowp + kc, t);
+          if ((r < rows) && (kk < K)) ok |= ((1u << VW) - 1u) << (p * 4 + j);     // extent % VW == 0: inside or outside as a whole
+          if (MASKED && S) {
+            float m[VW];
+            ldv(srowp + kc, m);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (k + i < K) v[p * 4 + i] *= sp[i];
+            for (int i = 0; i < VW; ++i) t[i] *= m[i];
+          }
+#pragma unroll
+          for (int i = 0; i < VW; ++i) v[p * 4 + j + i] = t[i];
         }
       }
     } else {
@@ -87,19 +115,23 @@ struct Stager {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int k = k0 + 2 * (tid / (TM / 4)) + (p & 1) + 16 * (p >> 1), r = r0 + m4;
-        const float* src = P + (long)k * sk + r;
-        if (k < K && VEC && r + 3 < rows) {
-          const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
-          v[p * 4 + 0] = t[0]; v[p * 4 + 1] = t[1]; v[p * 4 + 2] = t[2]; v[p * 4 + 3] = t[3];
-        } else {
+        const int kc = min(k, K - 1);
+        const float* kp = P + (long)kc * sk;
+        const float* skp = (MASKED && S) ? S + (size_t)(kc / rpm) * rows : nullptr;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[p * 4 + i] = (k < K && r + i < rows) ? src[i] : 0.f;
-        }
-        if (S && k < K) {
-          const float* sp = S + (size_t)(k / rpm) * rows + r;
+        for (int j = 0; j < 4; j += VW) {
+          const int rr = r + j, rrc = min(rr, rows - VW);
+          float t[VW];
+          ldv(kp + rrc, t);
+          if ((k < K) && (rr < rows)) ok |= ((1u << VW) - 1u) << (p * 4 + j);
+          if (MASKED && S) {
+            float m[VW];
+            ldv(skp + rrc, m);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (r + i < rows) v[p * 4 + i] *= sp[i];
+            for (int i = 0; i < VW; ++i) t[i] *= m[i];
+          }
+#pragma unroll
+          for (int i = 0; i < VW; ++i) v[p * 4 + j + i] = t[i];
         }
       }
     }
@@ -112,7 +144,7 @@ struct Stager {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bf16_t a, b;
-        split_bf16(v[p * 4 + i], a, b);
+        split_bf16(((ok >> (p * 4 + i)) & 1u) ? v[p * 4 + i] : 0.f, a, b);
         h[i] = a;
         l[i] = b;
       }
@@ -149,7 +181,7 @@ __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, 
 
 // One workgroup's share of a product: output tile `id / splitk`, K slice `id % splitk` (the body of gemm_x3_kernel and of the grouped
 // weight-gradient kernel below)
-template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP>
+template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP, bool MASKED = false>
 __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk, long sbn,
                                         const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N, int K, int splitk,
                                         float* __restrict__ ws, const float* __restrict__ a_scale, const float* __restrict__ b_scale,
@@ -174,25 +206,12 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
 #pragma unroll
     for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  Stager<TM, AMODE, VECA> sa;
-  Stager<TM, BMODE, VECB> sb;
   // operand A: rows = m (stride sam) in MODE 0 / k-rows of stride sak in MODE 1; operand B: "rows" = n
   const long a_srow = sam, a_sk = sak, b_srow = sbn, b_sk = sbk;
-  if (kbeg < kend) {
-    sa.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
-    sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
-  }
-  for (int t = kbeg; t < kend; ++t) {
-    char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
-    sa.store(st, st + ARR, tid, NP == 3);
-    sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3);
-    __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
-    if (t + 1 < kend) {
-      sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm);
-      sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm);
-    }
+  // one K step on LDS stage `st`: fragments of four m-tiles at a time (keeps the fragment registers at 40)
+  auto compute = [&](const char* st) {
 #pragma unroll
-    for (int jh = 0; jh < JT / 4; ++jh) {             // four m-tiles at a time keeps the fragment registers at 40
+    for (int jh = 0; jh < JT / 4; ++jh) {
       bf16x8_t ah[4], al[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -215,6 +234,77 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
         }
       }
     }
+  };
+#ifndef RUART_X3_PF
+#define RUART_X3_PF 2
+#endif
+#if RUART_X3_PF == 2
+  // Register-staged prefetch TWO K steps deep on the 128 tile (round 4): the trunk's products are short (K = 250 .. 1 800: 8-57 steps of
+  // 32) and a step's MFMA work (~0.4 us at two workgroups per CU) is shorter than an L2 round trip, so with one step of lookahead every
+  // store waited for its own loads (PMC: waves parked in s_waitcnt / s_barrier 45 % of their cycles).  Two register sets alternate with
+  // the two LDS stages; a set's loads are issued right after the barrier that follows its store and are consumed two steps later.
+  // (The 256 tile - 8 waves x 128 accumulators - has no registers for a second set.)
+  if constexpr (TM == 128) {
+    Stager<TM, AMODE, VWA> sa0, sa1;
+    Stager<TM, BMODE, VWB> sb0, sb1;
+    sa0.template load<MASKED>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
+    sb0.template load<MASKED>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
+    sa1.template load<MASKED>(A, a_srow, a_sk, m0, M, (kbeg + 1) * XBK, K, tid, a_scale, rpm);
+    sb1.template load<MASKED>(B, b_srow, b_sk, n0, N, (kbeg + 1) * XBK, K, tid, b_scale, rpm);
+    // No branch inside the pair loop: the loads past the slice's end are issued all the same (their addresses are clamped into the
+    // matrix, their elements are never stored), so hipcc can count vmcnt exactly - a load behind a run-time condition makes it
+    // assume the fewest outstanding loads at the join and wait for the YOUNGER set as well.
+    char* const st0 = smem;
+    char* const st1 = smem + 4 * ARR;
+    int t = kbeg;
+    // sched_barrier(0) pins the order  store | barrier | issue the loads of two steps ahead | MFMAs : left alone, hipcc sinks a
+    // set's loads below the MFMAs they are meant to run beside and hoists the NEXT store (with its vmcnt wait) above them.
+    for (; t + 1 < kend; t += 2) {
+      sa0.store(st0, st0 + ARR, tid, NP == 3);
+      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3);
+      __syncthreads();                                // one barrier per step: the other stage was last read two steps ago
+      __builtin_amdgcn_sched_barrier(0);
+      sa0.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 2) * XBK, K, tid, a_scale, rpm);
+      sb0.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 2) * XBK, K, tid, b_scale, rpm);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(st0);
+      __builtin_amdgcn_sched_barrier(0);
+      sa1.store(st1, st1 + ARR, tid, NP == 3);
+      sb1.store(st1 + 2 * ARR, st1 + 3 * ARR, tid, NP == 3);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      sa1.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 3) * XBK, K, tid, a_scale, rpm);
+      sb1.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 3) * XBK, K, tid, b_scale, rpm);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(st1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < kend) {                                   // odd step count: the last step's operands are in set 0
+      sa0.store(st0, st0 + ARR, tid, NP == 3);
+      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3);
+      __syncthreads();
+      compute(st0);
+    }
+  } else
+#endif
+  {
+    Stager<TM, AMODE, VWA> sa;
+    Stager<TM, BMODE, VWB> sb;
+    if (kbeg < kend) {
+      sa.template load<MASKED>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
+      sb.template load<MASKED>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
+    }
+    for (int t = kbeg; t < kend; ++t) {
+      char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
+      sa.store(st, st + ARR, tid, NP == 3);
+      sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3);
+      __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
+      if (t + 1 < kend) {
+        sa.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm);
+        sb.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm);
+      }
+      compute(st);
+    }
   }
 
   if (splitk > 1) {
@@ -227,10 +317,32 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
     return;
   }
   // lane owns rows m = .. + j*16 + fr and four consecutive columns n = .. + i*16 + fq*4 + r
-  const bool vec_out = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(C) | (R ? reinterpret_cast<uintptr_t>(R) : 0) | (bias ? reinterpret_cast<uintptr_t>(bias) : 0) |
+                         (c_scale ? reinterpret_cast<uintptr_t>(c_scale) : 0);
+  // whole-vector epilogue (bias, mask, residual, store as 16-byte accesses, none behind a per-element condition) when every pitch
+  // and base allows it; the element-wise form handles the matrix's last columns and odd pitches
+  const bool vec_all = (bits & 15) == 0 && (ldc & 3) == 0 && (!R || (ldr & 3) == 0) && (!c_scale || (N & 3) == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    if (vec_all && n + 3 < N) {
+      f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const int m = m0 + wm * (TM / 2) + j * 16 + fr;
+        if (m >= M) continue;
+        f32x4_t v = acc[i][j] + bv;
+        if (act == RUART_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
+        }
+        if (c_scale) v *= *reinterpret_cast<const f32x4_t*>(c_scale + (size_t)(m / rpm) * N + n);
+        if (R) v += *reinterpret_cast<const f32x4_t*>(R + (size_t)m * ldr + n);
+        *reinterpret_cast<f32x4_t*>(C + (size_t)m * ldc + n) = v;
+      }
+      continue;
+    }
     f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
@@ -258,25 +370,21 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
           if (n + r < N) v[r] += rp[r];
       }
       float* dst = C + (size_t)m * ldc + n;
-      if (vec_out && n + 3 < N) {
-        *reinterpret_cast<f32x4_t*>(dst) = v;
-      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < N) dst[r] = v[r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) dst[r] = v[r];
     }
   }
 }
 
-template <int TM, int AMODE, int BMODE, bool VECA, bool VECB, int NP = 3>     // NP = 1: the hi.hi product only (plain bf16)
+template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP = 3, bool MASKED = false>     // NP = 1: the hi.hi product only (plain bf16)
 __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
                                                             long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
                                                             int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
                                                             const float* __restrict__ a_scale, const float* __restrict__ b_scale,
                                                             const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
                                                             int ldr, int act) {
-  x3_tile<TM, AMODE, BMODE, VECA, VECB, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, a_scale, b_scale, c_scale, rpm, R,
+  x3_tile<TM, AMODE, BMODE, VWA, VWB, NP, MASKED>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, a_scale, b_scale, c_scale, rpm, R,
                                             ldr, act, xcd_remap(blockIdx.x, gridDim.x));
 }
 
@@ -306,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_grouped_tn_kernel(const X3GArg
   while (q + 1 < g.n && id >= g.p[q + 1].blk0) ++q;          // wave-uniform scan over <= 44 problems
   const X3GProb& P = g.p[q];
   const float* R = (P.accum && P.splitk == 1) ? P.C : nullptr;
-  x3_tile<128, 1, 1, VECA, VECB, 3>(P.A, 1, P.lda, P.B, P.ldb, 1, nullptr, P.C, P.ldc, P.M, P.N, P.K, P.splitk, P.ws, nullptr, nullptr,
+  x3_tile<128, 1, 1, VECA ? 4 : 1, VECB ? 4 : 1, 3>(P.A, 1, P.lda, P.B, P.ldb, 1, nullptr, P.C, P.ldc, P.M, P.N, P.K, P.splitk, P.ws, nullptr, nullptr,
                                     nullptr, 1, R, P.ldc, RUART_ACT_NONE, id - P.blk0);
 }
 
@@ -324,8 +432,40 @@ __device__ __forceinline__ void x3_reduce_body(const float* __restrict__ ws, con
   const int m = (tile / ntn) * TM + wm * (TM / 2) + j * 16 + fr, n = (tile % ntn) * TM + wn * 64 + i * 16 + fq * 4;
   if (m >= M || n >= N) return;
   const float* p = ws + (size_t)tile * splitk * (TM * TM) + (ij * T::THREADS + tid) * 4;
+  // slices in slice order (the sum's order is part of the contract: deterministic, equal to the grouped form), eight loads in flight
   f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-  for (int sl = 0; sl < splitk; ++sl) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)sl * (TM * TM));
+  int sl = 0;
+  for (; sl + 8 <= splitk; sl += 8) {
+    f32x4_t a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4_t*>(p + (size_t)(sl + u) * (TM * TM));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += a[u];
+  }
+  {
+    f32x4_t a[8];                                      // tail: clamped loads, masked adds - no load behind a branch
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4_t*>(p + (size_t)min(sl + u, splitk - 1) * (TM * TM));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (sl + u < splitk) s += a[u];
+  }
+  // epilogue: whole-vector form when the four columns are inside the matrix and every row pitch / base allows 16-byte access
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(C) | (R ? reinterpret_cast<uintptr_t>(R) : 0) | (bias ? reinterpret_cast<uintptr_t>(bias) : 0) |
+                         (c_scale ? reinterpret_cast<uintptr_t>(c_scale) : 0);
+  const bool vec = n + 3 < N && (bits & 15) == 0 && (ldc & 3) == 0 && (!R || (ldr & 3) == 0) && (!c_scale || (N & 3) == 0);
+  if (vec) {
+    f32x4_t v = s;
+    if (bias) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+    if (act == RUART_ACT_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] * 0.5f * (1.0f + erff(v[r] * 0.70710678118654752440f));
+    }
+    if (c_scale) v *= *reinterpret_cast<const f32x4_t*>(c_scale + (size_t)(m / rpm) * N + n);
+    if (R) v += *reinterpret_cast<const f32x4_t*>(R + (size_t)m * ldr + n);
+    *reinterpret_cast<f32x4_t*>(C + (size_t)m * ldc + n) = v;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (n + r < N) {
@@ -390,11 +530,11 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
   return p;
 }
 
-template <int TM, int AM, int BM_, bool VA, bool VB, int NP = 3>
+template <int TM, int AM, int BM_, int VA, int VB, int NP = 3, bool MASKED = false>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
                int N, int K, const Plan& p, float* ws, const float* a_scale, const float* b_scale, const float* c_scale, int rpm,
                const float* R, int ldr, int act, hipStream_t s) {
-  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB, NP>;
+  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB, NP, MASKED>;
   constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
@@ -432,28 +572,61 @@ int gemm_xn(const float* A, long long sam, long long sak, const float* B, long l
   if (amode < 0 || bmode < 0) return (int)hipErrorInvalidValue;        // one unit stride per operand
   Plan p = make_plan(M, N, K, amode, bmode);
   if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) p.splitk = 1;   // no room: unsplit
-  // 16-byte vector loads need an aligned base and a non-unit stride that is a multiple of 4 floats
-  const bool va = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (((amode == 0 ? sam : sak) & 3) == 0);
-  const bool vb = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (((bmode == 0 ? sbn : sbk) & 3) == 0);
+  // floats per load along each operand's contiguous index (Stager): base alignment, row pitch and extent must all allow it; a fused
+  // mask is read with the operand's width (its pitch is the operand's extent)
+  auto width = [](const float* base, long pitch, int extent, const float* mask) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(base) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0);
+    if ((bits & 15) == 0 && (pitch & 3) == 0 && (extent & 3) == 0) return 4;
+    if ((bits & 7) == 0 && (pitch & 1) == 0 && (extent & 1) == 0) return 2;
+    return 1;
+  };
+  const int vwa = width(A, amode == 0 ? sam : sak, amode == 0 ? K : M, a_scale);
+  const int vwb = width(B, bmode == 0 ? sbn : sbk, bmode == 0 ? K : N, b_scale);
+  if (p.tm == 256 && (vwa == 1 || vwb == 1)) {          // the big tile is built for the 16- and 8-byte forms only
+    p.tm = 128;
+    p.tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    p.splitk = 1;
+  }
   hipStream_t s = (hipStream_t)stream;
-#define X3V(TM, AM, BM_)                                                                                                          \
-  do {                                                                                                                            \
-    if (va && vb) launch_x3<TM, AM, BM_, true, true, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else if (va) launch_x3<TM, AM, BM_, true, false, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else if (vb) launch_x3<TM, AM, BM_, false, true, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                  \
-    else launch_x3<TM, AM, BM_, false, false, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s);                         \
+#define X3L(TM, AM, BM_, VA, VB) \
+  launch_x3<TM, AM, BM_, VA, VB, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s)
+#define X3W(TM, AM, BM_)                                         \
+  do {                                                           \
+    if (vwa == 4 && vwb == 4) X3L(TM, AM, BM_, 4, 4);            \
+    else if (vwa == 4 && vwb == 2) X3L(TM, AM, BM_, 4, 2);       \
+    else if (vwa == 2 && vwb == 4) X3L(TM, AM, BM_, 2, 4);       \
+    else if (vwa == 2 && vwb == 2) X3L(TM, AM, BM_, 2, 2);       \
+    else if (TM == 256) return (int)hipErrorInvalidValue;        \
+    else X3S(AM, BM_);                                           \
   } while (0)
-#define X3(AM, BM_)                 \
-  do {                              \
-    if (p.tm == 256) X3V(256, AM, BM_); \
-    else X3V(128, AM, BM_);         \
+#define X3S(AM, BM_)                                             \
+  do {                                                           \
+    if (vwa == 4) X3L(128, AM, BM_, 4, 1);                       \
+    else if (vwa == 2) X3L(128, AM, BM_, 2, 1);                  \
+    else if (vwb == 4) X3L(128, AM, BM_, 1, 4);                  \
+    else if (vwb == 2) X3L(128, AM, BM_, 1, 2);                  \
+    else X3L(128, AM, BM_, 1, 1);                                \
   } while (0)
-  if (amode == 0 && bmode == 0) X3(0, 0);
-  else if (amode == 0 && bmode == 1) X3(0, 1);
-  else if (amode == 1 && bmode == 0) X3(1, 0);
-  else X3(1, 1);
-#undef X3
-#undef X3V
+  if (a_scale || b_scale) {
+    // operand masks fused into the loads (a test / experiment path: the product materialises x * mask once, ops._Linear): the one
+    // instantiation per layout that carries the mask loads, scalar width
+    if (p.tm == 256) { p.tm = 128; p.tiles = ((M + 127) / 128) * ((N + 127) / 128); p.splitk = 1; }
+#define X3M(AM, BM_) launch_x3<128, AM, BM_, 1, 1, NP, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s)
+    if (amode == 0 && bmode == 0) X3M(0, 0);
+    else if (amode == 0 && bmode == 1) X3M(0, 1);
+    else if (amode == 1 && bmode == 0) X3M(1, 0);
+    else X3M(1, 1);
+#undef X3M
+  } else if (p.tm == 256) {                            // (make_plan picks the big tile for a K-contiguous B only)
+    if (bmode != 0) return (int)hipErrorInvalidValue;
+    if (amode == 0) X3W(256, 0, 0); else X3W(256, 1, 0);
+  } else if (amode == 0 && bmode == 0) X3W(128, 0, 0);
+  else if (amode == 0 && bmode == 1) X3W(128, 0, 1);
+  else if (amode == 1 && bmode == 0) X3W(128, 1, 0);
+  else X3W(128, 1, 1);
+#undef X3S
+#undef X3W
+#undef X3L
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -536,8 +709,8 @@ extern "C" int ruart_gemm_x3_tn_grouped(const ruart_x3_tn_problem* probs, int n,
     for (int i = 0; i < n; ++i) {
       const ruart_x3_tn_problem& q = probs[i];
       if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return (int)hipErrorInvalidValue;
-      const bool qa = ((reinterpret_cast<uintptr_t>(q.A) & 15) == 0) && ((q.lda & 3) == 0);
-      const bool qb = ((reinterpret_cast<uintptr_t>(q.B) & 15) == 0) && ((q.ldb & 3) == 0);
+      const bool qa = ((reinterpret_cast<uintptr_t>(q.A) & 15) == 0) && ((q.lda & 3) == 0) && ((q.M & 3) == 0);
+      const bool qb = ((reinterpret_cast<uintptr_t>(q.B) & 15) == 0) && ((q.ldb & 3) == 0) && ((q.N & 3) == 0);
       if (qa != va || qb != vb) continue;
       const Plan pl = make_plan(q.M, q.N, q.K, 1, 1);          // (a transposed-read B operand always plans the 128 tile)
       X3GProb& P = g.p[g.n];

@@ -32,7 +32,8 @@ class BertModelC(Structure):
                 ("w_ff1", POINTER(c_void_p)), ("b_ff1", POINTER(c_void_p)),
                 ("w_ff2", POINTER(c_void_p)), ("b_ff2", POINTER(c_void_p)),
                 ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p)), ("f32_gemm", c_int), ("corr8", c_int),
-                ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p))]
+                ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p)),
+                ("tail_cus", c_int)]
 
 
 class X3TnProblemC(Structure):
@@ -57,8 +58,12 @@ _P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
 _SIGNATURES = {
     "ruart_version": (c_char_p, []),
     "ruart_gemm_16_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16_tail_ws_bytes": (c_size_t, [_I, _I, _I, _I]),
+    "ruart_gemm_16_nt_ws": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t, _I, _P]),
     "ruart_gemm_16c_nt": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ruart_gemm_16c_nt_sel": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_gemm_16c_tail_ws_bytes": (c_size_t, [_I, _I, _I, _I]),
+    "ruart_gemm_16c_nt_ws": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, c_size_t, _I, _P]),
     "ruart_f16c_shifts": (_I, [POINTER(c_int)]),
     "ruart_bert_set_correction": (_I, [_I, _I, _I, _I, ctypes.c_ulonglong]),
     "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),

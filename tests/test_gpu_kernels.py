@@ -75,6 +75,104 @@ def _w8(W):
     return W.to(torch.float16).contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
 
+@pytest.mark.parametrize("M,N,K,cus", [(81 * 256, 768, 768, 240),        # 3 tail tiles, 6 slices of 2 K-tiles
+                                       (128 * 256, 768, 3072, 256),      # the north-star halves: 384 tiles = 1.5 rounds, long K: 2 slices
+                                       (128 * 256, 768, 768, 256)])      # ... short K: left alone
+@pytest.mark.parametrize("mode", ["plain", "res32", "gelu"])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_gemm_16_tail_split(M, N, K, cus, mode, dt):
+    """ruart_gemm_16_nt_ws (plain 16-bit product): tail tiles cut along K + fix-up launch == the single launch to fp32 summation order,
+    deterministic, every element written."""
+    lib = hip.load()
+    d = dev()
+    code = hip.PRECISION[dt]
+    td = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(td).to(d)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(td).to(d)
+    bias = (torch.randn(N, generator=g) * 0.1).to(d)
+    Rd = torch.randn(M, N, generator=g).to(d) if mode == "res32" else None
+    act = hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE
+    out_dt = hip.DT_F32 if mode == "res32" else code
+    nbytes = int(lib.ruart_gemm_16_tail_ws_bytes(M, N, K, cus))
+    tiles, r = (M // 256) * (N // 256), ((M // 256) * (N // 256)) % cus
+    assert (nbytes > 0) == (tiles > cus and r > 0 and (4 * r <= cus or (5 * r <= 3 * cus and K >= 2048)))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=d)
+
+    def run(use_ws):
+        C = torch.full((M, N), float("nan"), dtype=torch.float32 if mode == "res32" else td, device=d)
+        rc = lib.ruart_gemm_16_nt_ws(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(bias), hip.ptr(Rd), N, hip.DT_F32, hip.ptr(C), N, out_dt, M, N, K, act,
+                                     code, hip.ptr(ws) if use_ws else None, nbytes if use_ws else 0, cus, hip.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return C
+
+    C0, C1, C2 = run(False), run(True), run(True)
+    assert torch.equal(C1, C2)
+    assert not torch.isnan(C1.float()).any()
+    tol = 2e-6 if mode == "res32" else (1e-2 if dt == "bf16" else 2e-3)              # 16-bit outputs: one rounding step
+    err = float((C1.float() - C0.float()).abs().max()) / max(1.0, float(C0.float().abs().max()))
+    assert err < tol, err
+    if nbytes == 0:
+        assert torch.equal(C0, C1)
+
+
+@pytest.mark.parametrize("M,N,K,cus", [(81 * 256, 768, 768, 240),      # 243 tiles: 3 tail tiles cut into 6 slices of 4 K-tiles
+                                       (85 * 256, 1024, 3072, 240),    # 340 tiles: 100 tail tiles (long K), 2 slices = the f16 and the fp8 phase
+                                       (85 * 256, 1024, 768, 240),     # the same at K = 768: a 42 %-full last round of short tiles is left alone
+                                       (43 * 256, 768, 3072, 120),     # 129 tiles: 9 tail tiles, 8 slices of 12 K-tiles (K = 3072)
+                                       (16 * 256, 768, 768, 240)])     # one partial round: left alone (no second launch)
+@pytest.mark.parametrize("mode", ["plain", "res", "gelu"])
+def test_gemm_16c_tail_split(M, N, K, cus, mode):
+    """ruart_gemm_16c_nt_ws: the tiles of the last, partial round of `cus` CUs are cut along K, a second launch sums a tile's slices in
+    slice order and runs its epilogue.  Same product as the single launch to fp32 summation order, bit-identical between two runs, and
+    every output element written (the buffers start as NaN)."""
+    from ruart_amd.bert import split_f16c
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = (torch.randn(N, generator=g) * 0.1).to(d)
+    A16, A8 = [t.to(d) for t in split_f16c(A)]
+    W16, W8 = [t.to(d) for t in _w8(W)]
+    Rd = torch.randn(M, N, generator=g).to(d) if mode == "res" else None
+    act = hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE
+    nbytes = int(lib.ruart_gemm_16c_tail_ws_bytes(M, N, K, cus))
+    tiles = (M // 256) * (N // 256)
+    r = tiles % cus
+    assert (nbytes > 0) == (tiles > cus and r > 0 and (4 * r <= cus or (5 * r <= 3 * cus and K >= 2048)))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=d)
+
+    def run(use_ws):
+        if mode == "gelu":
+            C = torch.full((M, N), float("nan"), dtype=torch.float16, device=d)
+            C8 = torch.full((M, 2 * N), 0x7f, dtype=torch.uint8, device=d)          # 0x7f = e4m3 NaN
+        else:
+            C = torch.full((M, N), float("nan"), dtype=torch.float32, device=d)
+            C8 = None
+        rc = lib.ruart_gemm_16c_nt_ws(hip.ptr(A16), hip.ptr(A8), K, hip.ptr(W16), hip.ptr(W8), K, hip.ptr(bias), hip.ptr(Rd), N, hip.ptr(C), N,
+                                      hip.ptr(C8), M, N, K, act, 3, hip.ptr(ws) if use_ws else None, nbytes if use_ws else 0, cus,
+                                      hip.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return C, C8
+
+    C0, C80 = run(False)
+    C1, C81 = run(True)
+    C2, C82 = run(True)
+    assert torch.equal(C1, C2) and (C81 is None or torch.equal(C81, C82))            # deterministic
+    assert not torch.isnan(C1.float()).any()
+    ref = C0.float()
+    tol = 2e-3 if mode == "gelu" else 2e-6                                           # f16 output rounding / fp32 summation order
+    err = float((C1.float() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err < tol, err
+    if nbytes == 0:
+        assert torch.equal(C0, C1)
+    if C81 is not None:
+        assert int((C81 != C80).sum()) < 0.01 * C81.numel()                          # the fp8 companions move only where a value sat on a rounding edge
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (256, 768, 3072), (256, 2304, 768)])
 @pytest.mark.parametrize("mode", ["plain", "res", "gelu"])
 def test_gemm_16c_fp8_correction(M, N, K, mode):

@@ -250,6 +250,73 @@ def test_stacked_brnn_vs_reference(layers_golden, tag, nl, bid, ln, gemm):
         _close(p.grad, z[tag + "_g_" + n_], 20 * tol, 2e-4, "g " + n_)
 
 
+@pytest.mark.parametrize("gemm", ["fp32", "x3"])
+def test_deep_attention_vs_reference(golden_dir, gemm):
+    """a9, Layers.py:471-524: the product's DeepAttention module (three fused attentions + BiLSTM, return_bef_rnn) on the reference's own
+    per-op vectors - outputs and every input / parameter gradient (tests/golden/layers_extra.npz)."""
+    import ruart_amd.layers as L
+    from ruart_amd import ops
+    z = np.load(os.path.join(golden_dir, "layers_extra.npz"))
+    L.set_dropout_prob(0.0)
+    ops.trunk_gemm = gemm
+    B, L1, L2, Wd, Hh, HL, per = [int(v) for v in z["deep_dims"]]
+    m = L.DeepAttention({"hidden_size": Hh, "highlvl_hidden_size": HL}, abstr_list_cnt=2, deep_att_hidden_size_per_abstr=per,
+                        correlation_func=3, word_hidden_size=Wd).to(DEV)
+    for n_, p in m.named_parameters():
+        p.data = T(z["deep_w_" + n_]).to(DEV)
+    grab = lambda name, n: [T(z["deep_%s_%d" % (name, i)]).to(DEV).requires_grad_() for i in range(n)]
+    x1w, x1a, x2w, x2a = grab("x1_word", 1), grab("x1_abstr", 2), grab("x2_word", 1), grab("x2_abstr", 3)
+    h, pre = m(x1w, x1a, x2w, x2a, T(z["deep_m1"]).to(DEV), T(z["deep_m2"]).to(DEV), return_bef_rnn=True)
+    tol = 2e-6 if gemm == "fp32" else 5e-5
+    _close(h, z["deep_h"], tol, 1e-5, "h")
+    _close(pre, z["deep_pre"], tol, 1e-5, "pre")
+    ((h * T(z["deep_gh"]).to(DEV)).sum() + (pre * T(z["deep_gpre"]).to(DEV)).sum()).backward()
+    for name, lst in (("x1_word", x1w), ("x1_abstr", x1a), ("x2_word", x2w), ("x2_abstr", x2a)):
+        for i, t in enumerate(lst):
+            _close(t.grad, z["deep_g_%s_%d" % (name, i)], 20 * tol, 1e-4, "g %s %d" % (name, i))
+    for n_, p in m.named_parameters():
+        _close(p.grad, z["deep_g_" + n_], 20 * tol, 2e-4, "g " + n_)
+
+
+@pytest.mark.parametrize("gemm", ["fp32", "x3"])
+def test_prealign_vs_reference(golden_dir, gemm):
+    """a5, SDNet.py:495-551: ``SDNet._prealign`` (scatter the real words of a sample into one row by host-built indices, fused attention
+    over the question's word vectors, gather back) against the reference's get_prealign_emb with its four Python loops, on the packed
+    word layout the product uses: values at every real word, gradients of the item / question vectors and of the projection."""
+    import ruart_amd.layers as L
+    from ruart_amd import ops
+    from ruart_amd.batch import BatchIndex
+    from ruart_amd.sdnet import SDNet
+    z = np.load(os.path.join(golden_dir, "layers_extra.npz"))
+    nq, nocr, nod, bv, V = [int(v) for v in z["pre_args"]]
+    opt = default_opt(vocab_size=V, cuda=True, device=DEV)
+    q, ocr, od, _, _ = synth.synthetic_batch(opt, int(z["pre_B"]), seed=int(z["pre_seed"]), n_q=nq, n_ocr=nocr, n_od=nod, bert_vocab=bv, ragged=True)
+    assert ocr["num_cnt"] == z["pre_ocr_num_cnt"].tolist()
+    L.set_dropout_prob(0.0)
+    ops.trunk_gemm = gemm
+    pa = L.Attention(300, z["pre_w"].shape[0], correlation_func=3, do_similarity=True).to(DEV)
+    pa.scoring.linear.weight.data = T(z["pre_w"]).to(DEV)
+    host = type("Host", (), {"pre_align": pa})()                       # _prealign reads nothing else of the SDNet
+    bi = BatchIndex(q, ocr, od, opt, torch.device(DEV))
+    key_q = "fasttext" if "fasttext" in opt["q_embedding"] else "glove"
+    qe = T(z["pre_q_emb"]).to(DEV).requires_grad_()
+    q_mask = q[key_q + "_mask"].to(DEV).to(torch.uint8)
+    tol = 2e-6 if gemm == "fp32" else 5e-5
+    for tag, idx in (("ocr", bi.ocr), ("od", bi.od)):
+        emb = T(z["pre_%s_emb" % tag]).to(DEV).requires_grad_()           # (items, Lw, 300) as the reference holds it
+        flat = idx.dev["flat_word"]
+        words = emb.reshape(-1, 300)[flat]                               # the product's packed (real words, 300) layout
+        out = SDNet._prealign(host, words, idx, qe, q_mask)
+        ref = T(z["pre_%s_out" % tag]).reshape(-1, 300)[flat.cpu()]
+        _close(out, ref.numpy(), tol, 1e-5, tag + " out")
+        g = T(z["pre_g_" + tag]).reshape(-1, 300)[flat.cpu()].to(DEV)
+        (out * g).sum().backward()
+        gref = T(z["pre_g" + tag]).reshape(-1, 300)[flat.cpu()]
+        _close(emb.grad.reshape(-1, 300)[flat], gref.numpy(), 20 * tol, 1e-4, tag + " g emb")
+    _close(qe.grad, z["pre_gq"], 20 * tol, 1e-4, "g q")
+    _close(pa.scoring.linear.weight.grad, z["pre_gw"], 20 * tol, 2e-4, "g w")
+
+
 @pytest.mark.parametrize("variant", ["no_answer", "plain"])
 def test_predict_decode_on_device(golden_dir, variant):
     """``trainer.decode_predictions`` fed DEVICE scores (as ``predict`` feeds it) against the reference's predict loop

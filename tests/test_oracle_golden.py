@@ -93,6 +93,42 @@ def test_final_scores(layers):
             close(p.grad, z["score_g_" + name], 1e-5, 1e-4, "g " + name)
 
 
+def test_deep_attention_and_prealign(golden_dir):
+    """The oracle's deep_attention (Layers.py:471-524) and _prealign (SDNet.py:495-551) against the reference's own per-op vectors
+    (tests/golden/layers_extra.npz): outputs and every input gradient."""
+    z = np.load(os.path.join(golden_dir, "layers_extra.npz"))
+    P = {"m." + k[len("deep_w_"):]: T(z[k]).requires_grad_() for k in z.files if k.startswith("deep_w_")}
+    grab = lambda name, n: [T(z["deep_%s_%d" % (name, i)]).requires_grad_() for i in range(n)]
+    x1w, x1a, x2w, x2a = grab("x1_word", 1), grab("x1_abstr", 2), grab("x2_word", 1), grab("x2_abstr", 3)
+    h, pre = O.deep_attention(P, "m", x1w, x1a, x2w, x2a, T(z["deep_m2"]))
+    assert np.abs(h.detach().numpy() - z["deep_h"]).max() < 2e-6 and np.abs(pre.detach().numpy() - z["deep_pre"]).max() < 2e-6
+    ((h * T(z["deep_gh"])).sum() + (pre * T(z["deep_gpre"])).sum()).backward()
+    for name, lst in (("x1_word", x1w), ("x1_abstr", x1a), ("x2_word", x2w), ("x2_abstr", x2a)):
+        for i, t in enumerate(lst):
+            assert np.abs(t.grad.numpy() - z["deep_g_%s_%d" % (name, i)]).max() < 1e-5, (name, i)
+    for k, t in P.items():
+        if t.grad is not None:
+            assert np.abs(t.grad.numpy() - z["deep_g_" + k[2:]]).max() < 1e-5, k
+    # pre-align: same synthetic batch layout as the generator's
+    from ruart_amd import synth
+    from ruart_amd.arguments import default_opt
+    nq, nocr, nod, bv, V = [int(v) for v in z["pre_args"]]
+    opt = default_opt(vocab_size=V, cuda=False)
+    q, ocr, od, _, _ = synth.synthetic_batch(opt, int(z["pre_B"]), seed=int(z["pre_seed"]), n_q=nq, n_ocr=nocr, n_od=nod, bert_vocab=bv, ragged=True)
+    assert ocr["num_cnt"] == z["pre_ocr_num_cnt"].tolist()
+    Pp = {"pre_align.scoring.linear.weight": T(z["pre_w"]).requires_grad_(), "pre_align.scoring.diagonal": T(z["pre_diag"])}
+    qe = T(z["pre_q_emb"]).requires_grad_()
+    key_q = "fasttext" if "fasttext" in opt["q_embedding"] else "glove"
+    for tag, items in (("ocr", ocr), ("od", od)):
+        e = T(z["pre_%s_emb" % tag]).requires_grad_()
+        out, _ = O._prealign(Pp, e, items["len_cnt"], qe, q[key_q + "_mask"])
+        assert np.abs(out.detach().numpy() - z["pre_%s_out" % tag]).max() < 2e-6, tag
+        (out * T(z["pre_g_" + tag])).sum().backward()
+        assert np.abs(e.grad.numpy() - z["pre_g" + tag]).max() < 1e-5, tag
+    assert np.abs(qe.grad.numpy() - z["pre_gq"]).max() < 1e-5
+    assert np.abs(Pp["pre_align.scoring.linear.weight"].grad.numpy() - z["pre_gw"]).max() < 1e-5
+
+
 def test_whole_tensor_ln(layers):
     z = layers
     x = T(z["wln_x"]).requires_grad_()

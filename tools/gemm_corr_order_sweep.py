@@ -19,12 +19,16 @@ ap.add_argument("--rows", type=int, default=42880)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--orders", default="0,2,3,4,6,8,12,16")
 ap.add_argument("--seq", default="")
+ap.add_argument("--hidden", type=int, default=768, help="1024 with --inter 4096: the bert-large (stress) projections")
+ap.add_argument("--inter", type=int, default=3072)
+ap.add_argument("--auto", action="store_true", help="also time the library's own per-shape choice (no ruart_gemm_set_tile_order)")
 a = ap.parse_args()
 lib = hip.load()
 d = torch.device("cuda:0")
 M = (a.rows + 255) // 256 * 256
-shapes = [("qkv", 2304, 768, hip.ACT_NONE, False), ("ao", 768, 768, hip.ACT_NONE, True), ("ff1", 3072, 768, hip.ACT_GELU, False),
-          ("ff2", 768, 3072, hip.ACT_NONE, True)]
+H, I = a.hidden, a.inter
+shapes = [("qkv", 3 * H, H, hip.ACT_NONE, False), ("ao", H, H, hip.ACT_NONE, True), ("ff1", I, H, hip.ACT_GELU, False),
+          ("ff2", H, I, hip.ACT_NONE, True)]
 g = torch.Generator(device="cpu").manual_seed(0)
 ops = {}
 for name, N, K, act, res in shapes:
@@ -64,6 +68,20 @@ for order in [int(x) for x in a.orders.split(",")]:
         torch.cuda.synchronize()
         line.append("%s %6.1f us" % (name, e0.elapsed_time(e1) * 1e3 / a.iters))
     print("order %2d: %s" % (order, "  ".join(line)), flush=True)
-lib.ruart_gemm_set_tile_order(8)
+if a.auto:
+    assert lib.ruart_gemm_set_tile_order(-1) == 0   # back to the rule in (row tiles, column tiles, K)
+    line = []
+    for name, N, K, _, _ in shapes:
+        run(name)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run(name)
+        e1.record()
+        torch.cuda.synchronize()
+        line.append("%s %6.1f us" % (name, e0.elapsed_time(e1) * 1e3 / a.iters))
+    print("rule    : %s" % "  ".join(line), flush=True)
+else:
+    lib.ruart_gemm_set_tile_order(8)
 if a.seq:
     json.dump({"rows": M, "seq": seq}, open(a.seq, "w"))
