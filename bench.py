@@ -426,7 +426,7 @@ def main():
             ach = fl_i / (ms_i * 1e-3) / 1e12
             ach_t = fl_t / (ms_t * 1e-3) / 1e12
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")       # PMC passes cannot run inside this process:
+            tf = os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")       # PMC passes cannot run inside this process:
             if os.path.exists(tf) and a.batch == 64 and not a.stress:           # the committed rocprofv3 summary of this shape
                 traffic = json.load(open(tf)).get(GEMM_KERNEL[a.precision], {}).get("avg_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": GEMM_KERNEL[a.precision], "achieved": round(ach_t, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",

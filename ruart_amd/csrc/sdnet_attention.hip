@@ -52,14 +52,14 @@ __device__ __forceinline__ Act no_act() { return Act{0, nullptr, 0}; }
 // read a clamped (valid) address and are zeroed by a select when they are stored.  Rounds 1-3 wrote `in_range ? src[..] : 0`: hipcc
 // branches around such a load and waits vmcnt(0) behind it (cdna_hip_programming.md, projection GEMM item 4c), so the "sixteen in
 // flight" were sixteen dependent L2 round trips and the three attention kernels ran at 0.85 TB/s.
-__device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols,
-                                      Act act = Act{0, nullptr, 0}) {
+template <int U>
+__device__ __forceinline__ void stage_u(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols, Act act) {
   const int total = nr_pad * CH;
-  for (int e0 = threadIdx.x; e0 < total; e0 += 16 * blockDim.x) {
-    float v[16], dv[16];
+  for (int e0 = threadIdx.x; e0 < total; e0 += U * blockDim.x) {
+    float v[U], dv[U];
     unsigned ok = 0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * blockDim.x;
       const int r = e / CH, c = e % CH;
       const int gr = r0 + r, gc = c0 + c;
@@ -68,14 +68,14 @@ __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const flo
     }
     if (act.diag_len > 1) {                      // (wave-uniform: one branch around the group, not one per load)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) dv[u] = act.diag[min(c0 + (e0 + u * (int)blockDim.x) % CH, cols - 1)];
+      for (int u = 0; u < U; ++u) dv[u] = act.diag[min(c0 + (e0 + u * (int)blockDim.x) % CH, cols - 1)];
     } else {
       const float d1 = act.diag_len == 1 ? act.diag[0] : 1.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) dv[u] = d1;
+      for (int u = 0; u < U; ++u) dv[u] = d1;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * blockDim.x;
       float x = v[u];
       if (act.relu) x = fmaxf(x, 0.f);
@@ -83,6 +83,14 @@ __device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const flo
       if (e < total) dst[(e / CH) * ldd + (e % CH)] = ((ok >> u) & 1u) ? x : 0.f;
     }
   }
+}
+// the loads in flight per thread follow the tile: a 16-row tile is 4 elements per thread (the trainable encoder's short windows call
+// these kernels with 16-row key panels too - sixteen clamped loads each would be 4x the traffic), a 64-row panel 16
+__device__ __forceinline__ void stage(float* dst, int ldd, int nr_pad, const float* src, int ld, int r0, int rows, int c0, int cols,
+                                      Act act = Act{0, nullptr, 0}) {
+  if (nr_pad <= 16) stage_u<4>(dst, ldd, nr_pad, src, ld, r0, rows, c0, cols, act);
+  else if (nr_pad <= 32) stage_u<8>(dst, ldd, nr_pad, src, ld, r0, rows, c0, cols, act);
+  else stage_u<16>(dst, ldd, nr_pad, src, ld, r0, rows, c0, cols, act);
 }
 // same but transposed on the fly: dst[c][r] = src[r0 + r][c0 + c]   (dst is [CH][ldd], r < 16)
 __device__ __forceinline__ void stage_t16(float* dst, int ldd, const float* src, int ld, int r0, int rows, int c0, int cols,

@@ -10,6 +10,9 @@ from ruart_amd.arguments import default_opt
 
 dev = torch.device("cuda:0")
 opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_size=64)
+if os.environ.get("RUART_UNLOCK_X3"):              # the fp32-class trainable-encoder graph: every encoder product on ruart_gemm_x3 as well
+    opt.pop("LOCK_BERT")
+    opt["bert_train_gemm"] = "x3"
 tr, _ = bench.build_trainer(opt, synth.bert_config(), dev)
 batches = [tr.ToCUDA(synth.synthetic_batch(opt, 64, seed=7 + i, n_q=30, n_ocr=100, n_od=36)) for i in range(2)]
 for i in range(3):
