@@ -105,8 +105,10 @@ int ruart_gemm_16_tn_splitk(const void* P, int ldp, const void* Q, int ldq, floa
 int ruart_gemm_set_tile_order(int group_m);
 /* Tile variant of ruart_gemm_16_nt: 5 (default) = 256x256 tile, four phases per K-tile with the prefetch in flight across
  * barriers (needs M, N % 256 == 0 and K % 128 == 0); 3 = 256x256 tile, plain two-stage loop (M, N % 256 == 0); 0 = 128x128
- * tile.  A shape a variant cannot take falls back to the next one.  All variants sum in the same order and are bitwise
- * identical (tools/gemm_check.py).  Other values are rejected. */
+ * tile; 7 = round 4's experiment, one wave per SIMD: 4 waves x 128x128 per 256x256 tile, accumulators in AGPRs, one barrier per K-tile
+ * (M, N % 256 == 0, K % 64 == 0, K >= 128; 7-12 % slower than 5 on the encoder's shapes).  A shape a variant cannot take
+ * falls back to the next one.  All variants sum in the same order and are bitwise identical (tools/gemm_check.py,
+ * test_gemm_16_one_wave_per_simd_variant).  Other values are rejected. */
 int ruart_gemm_set_variant(int v);
 /* fp32 form: any M, N, K; act in {NONE, GELU, RELU}; bias / residual may be NULL. */
 int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* residual, int ldr,

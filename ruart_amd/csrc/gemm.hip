@@ -801,7 +801,7 @@ extern "C" int ruart_gemm_set_tile_order(int group_m) {
 }
 extern "C" int ruart_gemm_set_variant(int v) {
   RUART_ENTRY();
-  if (v != 0 && v != 3 && v != 5) return (int)hipErrorInvalidValue;
+  if (v != 0 && v != 3 && v != 5 && v != 7) return (int)hipErrorInvalidValue;
   g_gemm_variant = v;
   return 0;
 }
@@ -879,6 +879,188 @@ extern "C" int ruart_prof_read(double* total_ms, long long* launches, double* fl
 int g_gemm_variant = 5;          // 0: 128x128 2-stage (any M, N multiple of 128); 3: 256x256 2-stage; 5: 256x256 four phases per K-tile, counted
                                  // vmcnt, staggered wave groups (M, N % 256 == 0, K % 128 == 0; else 3, else 0)
 
+// ------------------------------------------------------------------------------------------------
+// Variant 7 (round 4 experiment, the verdict's form (b)): ONE wave per SIMD.  256x256x64 tile, 4 waves (2 x 2), each wave a 128x128 block =
+// 8 x 8 MFMA tiles (256 accumulator registers; the kernel runs in the 512-register budget of a one-wave-per-SIMD launch).  Per MFMA the wave
+// reads 1/4 fragment instead of the 3/8 of the 8-wave kernel (a third fewer LDS bytes), there is ONE workgroup barrier per K-tile instead of
+// eight and no hand-over of the matrix pipe between two waves - but nobody else issues the wave's LDS-DMA and fragment reads: they sit
+// between its own MFMAs (one ds_read_b128 per 4 MFMAs, one DMA per 8 in the second half of a K-tile).
+//   K-tile t lives in LDS buffer t & 1 ([256 rows][128 B] per operand, the XOR swizzle of lds_off on the source chunk and on the read).
+//   step 0 (k 0..31):  64 MFMAs on fragment set X | reads set Y = (t, k 32..63) from buffer b
+//   mid-tile:          vmcnt(0) (this wave's pieces of tile t+1, issued one step ago, have landed), lgkmcnt(0), s_barrier
+//                      -> buffer b is read by no wave any more, buffer b^1 is complete for every wave
+//   step 1 (k 32..63): 64 MFMAs on set Y | reads set X = (t+1, k 0..31) from buffer b^1 | issues tile t+2's 16 DMA pieces into buffer b
+// M, N % 256 == 0, K % 64 == 0, K >= 128.
+// ------------------------------------------------------------------------------------------------
+// MFMA with the accumulator tile pinned to the AGPR half of the register file ("+a"): with 256 accumulator registers plus two fragment
+// sets the kernel needs > 256 registers, and left to itself hipcc (ROCm 7.2) keeps the MFMAs on VGPR accumulators and shuttles every tile
+// through v_accvgpr_read / _write around each MFMA (4 + 4 vector moves per MFMA in the K loop).  The hazard recogniser does not see
+// inside an asm statement: the accumulators are first read ~100 instructions and two barriers after the last MFMA (epilogue).
+__device__ __forceinline__ void mfma_agpr(const f16x8_t& a, const f16x8_t& b, f32x4_t& c) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_agpr(const bf16x8_t& a, const bf16x8_t& b, f32x4_t& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+#ifndef RUART_W4_DMA_EARLY
+#define RUART_W4_DMA_EARLY 0
+#endif
+template <typename T16, bool OUT_F32, int RES, int ACT>
+__global__ __launch_bounds__(256, 1) void gemm_16_nt_256w4(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, const void* __restrict__ R, int ldr,
+                                                           void* __restrict__ C, int ldc, int M, int N, int K, int order) {
+  constexpr int kOper = 256 * BK * 2;            // 32 KB per operand K-tile
+  constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * kBuf = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  p8_tile_of(__builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), M / BM4, N / BN4, order, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm);
+  tn = __builtin_amdgcn_readfirstlane(tn);
+  const int m0 = tm * BM4, n0 = tn * BN4;
+
+  // staging: wave w fills rows 64 w .. 64 w + 63 of both operand tiles: 8 pieces of 8 rows x 128 B each
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const unsigned a_lane = (unsigned)(srow * lda + schunk * 8) * 2, w_lane = (unsigned)(srow * ldw + schunk * 8) * 2;
+  const T16* a_src = A + (size_t)(m0 + wave * 64) * lda;
+  const T16* w_src = W + (size_t)(n0 + wave * 64) * ldw;
+  const size_t a8 = (size_t)8 * lda, w8 = (size_t)8 * ldw;
+  char* const st_base = smem + wave * 8192;
+  auto piece = [&](int d, int q, int kt) {       // piece q of 16: 0..7 activations, 8..15 weights
+    if (q < 8) dma16(a_src + (size_t)q * a8 + kt * BK, a_lane, st_base + d * kBuf + q * 1024);
+    else dma16(w_src + (size_t)(q - 8) * w8 + kt * BK, w_lane, st_base + d * kBuf + kOper + (q - 8) * 1024);
+  };
+
+  f32x4_t acc[8][8];                             // [i: 16 columns of the wave's 128][j: 16 rows]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  typedef typename Vec8<T16>::type frag_t;
+  frag_t fx[16], fy[16];                         // a fragment set: [0..7] weights (columns), [8..15] activations (rows)
+  auto rd = [&](frag_t (&f)[16], int q, int d, int ks) {      // read q of 16 of the set for k-step ks of buffer d
+    const char* base = smem + d * kBuf + (q < 8 ? kOper : 0);
+    const int row = (q < 8 ? wn * 128 + q * 16 : wm * 128 + (q - 8) * 16) + fr;
+    f[q] = *reinterpret_cast<const frag_t*>(base + lds_off(row, ks * 4 + fq));
+  };
+  // one k-step: 64 MFMAs on `cur`; behind every group of four, one read of `nxt` (buffer rd_d, k-step rd_ks; the eight activation
+  // fragments first - the next step's first eight MFMAs need them all -, then the weight fragments in the order the MFMAs take them) and,
+  // in the second half of a K-tile, one DMA piece of tile dma_kt into buffer dma_d.  sched_barrier pins the groups; RD / DMA are
+  // compile-time so that no read or DMA sits behind a branch.
+  auto step = [&](frag_t (&cur)[16], frag_t (&nxt)[16], auto rd_tag, int rd_d, int rd_ks, auto dma_tag, int dma_d, int dma_kt) {
+    constexpr bool RD = decltype(rd_tag)::value, DMA = decltype(dma_tag)::value;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = g * 4 + u, i = idx >> 3, j = idx & 7;
+        mfma_agpr(cur[i], cur[8 + j], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (RD) rd(nxt, g < 8 ? 8 + g : g - 8, rd_d, rd_ks);
+#if RUART_W4_DMA_EARLY            // (diagnostic builds: both pieces of a pair in the first half of the step - half a step more flight time)
+      if (DMA && g < 8) {
+        piece(dma_d, 2 * g, dma_kt);
+        piece(dma_d, 2 * g + 1, dma_kt);
+      }
+#else
+      if (DMA) piece(dma_d, g, dma_kt);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+  auto mid = [&] {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tile's pieces (issued during the previous step 1 / the prologue)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RUART_BAR();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end_step = [&] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nt = K / BK;                                      // >= 2
+#pragma unroll
+  for (int q = 0; q < 16; ++q) piece(0, q, 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) piece(1, q, 1);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // K-tile 0 landed (this wave's pieces)
+  RUART_BAR();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) rd(fx, q, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  int t = 0;
+  for (; t + 2 < nt; ++t) {                                   // tiles with two successors
+    const int d = t & 1;
+    step(fx, fy, Tt{}, d, 1, Ff{}, 0, 0);                     // step 0: compute (t, 0), read (t, 1)
+    mid();
+    step(fy, fx, Tt{}, d ^ 1, 0, Tt{}, d, t + 2);             // step 1: compute (t, 1), read (t+1, 0), stage t+2 into this tile's buffer
+    end_step();
+  }
+  {                                                           // second to last tile: nothing left to stage
+    const int d = t & 1;
+    step(fx, fy, Tt{}, d, 1, Ff{}, 0, 0);
+    mid();
+    step(fy, fx, Tt{}, d ^ 1, 0, Ff{}, 0, 0);
+    end_step();
+    ++t;
+  }
+  {                                                           // last tile
+    const int d = t & 1;
+    step(fx, fy, Tt{}, d, 1, Ff{}, 0, 0);
+    end_step();
+    step(fy, fx, Ff{}, 0, 0, Ff{}, 0, 0);
+  }
+  RUART_BAR();                                                // every wave is done reading operand tiles
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // (MFMA results in AGPRs: the asm MFMAs are invisible to the hazard recogniser)
+
+  // epilogue through LDS: 32 rows x 128 columns per wave and pass (528-byte rows: conflict-free for the 16-byte writes and reads)
+  constexpr int ERS = 528;
+  char* my = smem + wave * (32 * ERS);
+  const int ncol = n0 + wn * 128 + (lane & 31) * 4;
+  f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        *reinterpret_cast<f32x4_t*>(my + (jj * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + jj];
+    f32x4_t v[16], res[16];
+    const int mrow = m0 + wm * 128 + hh * 32 + (lane >> 5);
+    if (RES != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        if (RES == 1) res[rr] = load4(reinterpret_cast<const T16*>(R) + (size_t)(mrow + rr * 2) * ldr + ncol);
+        if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 2) * ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 2 + (lane >> 5)) * ERS + (lane & 31) * 16) + bv;
+    if (ACT != 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) v[rr] = gelu4(v[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      if (RES != 0) v[rr] += res[rr];
+      if (OUT_F32)
+        store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 2) * ldc + ncol, v[rr]);
+      else
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 2) * ldc + ncol, v[rr]);
+    }
+  }
+}
+
 // ---- tail split (see gemm_corr.hip: the same scheme for the plain 16-bit product) ---------------------------------------------------
 // Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices in slice order, then the tile's epilogue.
 template <typename T16, bool OUT_F32, int RES, int ACT>
@@ -947,18 +1129,24 @@ extern "C" size_t ruart_gemm_16_tail_ws_bytes(int M, int N, int K, int cus) {
   const P8TailPlan p = p8_tail_plan((M / BM4) * (N / BN4), K / BK, cus);
   return (size_t)p.r * p.S * BM4 * BN4 * sizeof(float);
 }
-// workspace / planning CU count of the call in flight (set by ruart_gemm_16_nt_ws around launch_gemm16; the library's entry points are
-// called from one host thread per process)
-static void* g_tail_ws = nullptr;
-static size_t g_tail_ws_bytes = 0;
-static int g_tail_cus = 0;
+// workspace / planning CU count of the call in flight on THIS host thread (set by ruart_gemm_16_nt_ws around launch_gemm16; thread-local:
+// the autograd engine's thread and the main thread both enter the library)
+static thread_local void* g_tail_ws = nullptr;
+static thread_local size_t g_tail_ws_bytes = 0;
+static thread_local int g_tail_cus = 0;
 
 template <typename T16, bool OF, int RS, int AC>
 static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float* bias, const void* residual, int ldr, void* C, int ldc,
                        int M, int N, int K, hipStream_t s) {
   constexpr int lds = 2 * 2 * BM4 * BK * 2;              // 128 KB: both 256x256 kernels
   const bool sq = M % BM4 == 0 && N % BN4 == 0;
-  if (g_gemm_variant == 5 && sq && K % (2 * BK) == 0) {
+  if (g_gemm_variant == 7 && sq && K % BK == 0 && K >= 2 * BK && AC <= 1) {
+    auto kern = gemm_16_nt_256w4<T16, OF, RS, AC>;
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+    (void)done;
+    const int order = g_tile_order_auto ? ruart_tile_group_m(M / BM4, N / BN4, K, false) : g_tile_order;
+    hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(256), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K, order);
+  } else if (g_gemm_variant >= 5 && sq && K % (2 * BK) == 0) {
     auto kern = gemm_16_nt_256p8<T16, OF, RS, AC>;
     static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
     (void)done;

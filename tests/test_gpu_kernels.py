@@ -75,6 +75,47 @@ def _w8(W):
     return W.to(torch.float16).contiguous(), pair.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(512, 768, 768, "res32"), (768, 512, 128, "plain"), (1024, 2304, 768, "plain"), (512, 3072, 768, "gelu"),
+                                        (512, 768, 3072, "res32"), (256, 256, 192, "res16")])
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_gemm_16_one_wave_per_simd_variant(M, N, K, mode, dt):
+    """Variant 7 of ruart_gemm_16_nt (round 4 experiment: 4 waves x 128x128 per 256x256 tile, accumulators in AGPRs, one barrier per
+    K-tile) multiplies in the same k order as the shipped four-phase kernel (variant 5): the outputs are BIT-identical, every element
+    written.  K = 192: an odd number of K-tiles (the four-phase kernel needs an even one and hands that shape to its two-stage sibling:
+    compared to rounding there)."""
+    lib = hip.load()
+    d = dev()
+    code = hip.PRECISION[dt]
+    td = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(td).to(d)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(td).to(d)
+    bias = torch.randn(N, generator=g).to(d)
+    R, rdt, of = None, code, False
+    if mode == "res32":
+        R, rdt, of = torch.randn(M, N, generator=g).to(d), hip.DT_F32, True
+    elif mode == "res16":
+        R = torch.randn(M, N, generator=g).to(td).to(d)
+    act = hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE
+    outs = []
+    try:
+        for v in (5, 7):
+            assert lib.ruart_gemm_set_variant(v) == 0
+            C = torch.full((M, N), float("nan"), dtype=torch.float32 if of else td, device=d)
+            rc = lib.ruart_gemm_16_nt(hip.ptr(A), K, hip.ptr(W), K, hip.ptr(bias), hip.ptr(R), N, rdt, hip.ptr(C), N, hip.DT_F32 if of else code, M, N, K,
+                                      act, code, hip.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append(C)
+    finally:
+        lib.ruart_gemm_set_variant(5)
+    assert not torch.isnan(outs[1].float()).any()
+    if K % 128 == 0:
+        assert torch.equal(outs[0], outs[1])
+    else:
+        assert float((outs[0].float() - outs[1].float()).abs().max()) <= 1e-2 * max(1.0, float(outs[0].float().abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,cus", [(81 * 256, 768, 768, 240),        # 3 tail tiles, 6 slices of 2 K-tiles
                                        (128 * 256, 768, 3072, 256),      # the north-star halves: 384 tiles = 1.5 rounds, long K: 2 slices
                                        (128 * 256, 768, 768, 256)])      # ... short K: left alone
