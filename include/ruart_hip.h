@@ -427,15 +427,18 @@ int ruart_set_nan_flag(int* flag);
 int ruart_gemm_x3_plan(int M, int N, int K, int a_k_contiguous /* sak == 1 */, int b_k_contiguous /* sbk == 1 */, int* splitk,
                        size_t* ws_bytes);
 /* Optional fused variational dropout (Models/Layers.py:23-30: one mask row per batch row, shared by `rows_per_scale_row`
- * consecutive time steps, already scaled by 1/(1-p)); NULL = none:
- *   a_scale (M / rows_per_scale_row, K): A(m,k) *= a_scale[m / rpm][k]      (needs sak == 1)   - forward  (x*mask) W^T
- *   c_scale (M / rows_per_scale_row, N): C(m,n) *= c_scale[m / rpm][n]                          - dX = (dY W) * mask
- *   b_scale (K / rows_per_scale_row, N): B(k,n) *= b_scale[k / rpm][n]      (needs sbn == 1)   - dW = dY^T (x*mask) */
+ * consecutive time steps; a mask element is 0 or keep_scale = 1/(1-p)); NULL = none:
+ *   a_keep  (M / rows_per_scale_row, K) bytes: A(m,k) *= a_keep[m / rpm][k] ? keep_scale : 0   (needs sak == 1) - forward (x*mask) W^T
+ *   b_keep  (K / rows_per_scale_row, N) bytes: B(k,n) *= b_keep[k / rpm][n] ? keep_scale : 0   (needs sbn == 1) - dW = dY^T (x*mask)
+ *   c_scale (M / rows_per_scale_row, N) fp32 : C(m,n) *= c_scale[m / rpm][n]                                    - dX = (dY W) * mask
+ * The operand masks travel as one byte per element and are read inside the operand loads (at most one of a_keep / b_keep per call;
+ * M, K < 2^20); c_scale is the mask itself and is applied in the epilogue. */
 /* Epilogue: C = act(A.B + bias) [* c_scale] + residual;  act = RUART_ACT_NONE | RUART_ACT_GELU (exact erf form), residual (M, N)
  * fp32 with row stride ldr or NULL - the encoder's dense+bias(+GELU)(+residual) steps in its split-operand precision mode. */
 int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
                   const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
-                  const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
+                  const unsigned char* a_keep, const unsigned char* b_keep, float keep_scale, const float* c_scale, int rows_per_scale_row,
+                  void* stream);
 /* All weight gradients of a training step in ONE launch (+ one for the split-K sums): problem i is dW_i (M x N, row stride ldc) (+)=
  * dY_i^T . X_i with dY_i (K rows, M columns, row stride lda) and X_i (K rows, N columns, row stride ldb) as the backward pass holds
  * them - autograd's grad_weight = grad_output.t().mm(input) of the nn.Linear sites at Models/Layers.py:155, 166, 226-227.  Every
@@ -454,7 +457,8 @@ int ruart_gemm_x3_tn_grouped(const ruart_x3_tn_problem* probs, int n, float* ws,
  * Same arguments, layouts, epilogue and workspace rule.  For products whose result is a gradient (dX, dW) beside a 16-bit encoder. */
 int ruart_gemm_x1(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, const float* bias,
                   const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K, float* ws, size_t ws_bytes,
-                  const float* a_scale, const float* b_scale, const float* c_scale, int rows_per_scale_row, void* stream);
+                  const unsigned char* a_keep, const unsigned char* b_keep, float keep_scale, const float* c_scale, int rows_per_scale_row,
+                  void* stream);
 
 /* Weight-gradient product in plain bf16 (one MFMA product instead of three): C (M, N) fp32 = A^T . B, where A is stored (K, M)
  * with row stride `sak_rows` and B is stored (K, N) with row stride `sbk_rows` (both row-contiguous, 16-byte aligned, strides

@@ -179,7 +179,7 @@ extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_ba
       return ruart_gemm_16_nt_ws(A, K, W, K, bias, res, N, dt, C, N, out_dt, rows, N, K, act, dt, tws, tws_bytes, m->tail_cus, stream);
     if (m->f32_gemm == 1)                                        // fp32 storage, split-bf16 products (no K split at these sizes)
       return ruart_gemm_x3((const float*)A, K, 1, (const float*)W, 1, K, bias, (const float*)res, N, act, (float*)C, N, rows, N, K,
-                           nullptr, 0, nullptr, nullptr, nullptr, 1, stream);
+                           nullptr, 0, nullptr, nullptr, 1.f, nullptr, 1, stream);
     return ruart_gemm_f32_nt((const float*)A, K, (const float*)W, K, bias, (const float*)res, N, (float*)C, N, rows, N, K, act, stream);
   };
 

@@ -59,9 +59,18 @@ __device__ __forceinline__ int kc_off(int r, int chunk /*0..3*/) {
 // loads at its edges and for every operand whose rows are not 16-byte aligned; hipcc waits vmcnt(0) behind every load it has to branch
 // around (cdna_hip_programming.md, projection GEMM item 4c), so an operand with 250-float rows was fetched as 16 DEPENDENT L2 round
 // trips per thread and K step.)
-template <int TM, int MODE, int VW>
+// MASKED (compile time): a variational-dropout mask is fused into the operand.  A variational mask holds only 0 and 1/(1-p), so it
+// travels as ONE BYTE per element (0 = dropped) plus the scalar 1/(1-p): MODE 0: element (row, k) is kept iff S[(row / rpm) * K + k],
+// MODE 1: iff S[(k / rpm) * rows + row]  (rpm = time steps that share one mask row); kept elements are multiplied by `scale`, exactly
+// what x * mask computes.  The bytes of a load's VW elements are fetched as one 32- / 16- / 8-bit load from the same (clamped)
+// coordinates into their own registers (4 per operand at VW = 4) and applied in store() - a select right behind the loads would
+// make the wave wait for them in front of the MFMAs they are meant to overlap.  (Rounds 2-3 read an fp32 mask as per-element scalar
+// loads behind a run-time `if (S)`: 1.5-2x slower than a separate multiply pass, so the product materialised x * mask; an fp32 mask
+// in vector registers - 16 more per register set - spilled in the 256 tile and in the two-set 128 tile.)
+template <int TM, int MODE, int VW, bool MASKED = false>
 struct Stager {
   float v[16];
+  unsigned mb[MASKED ? 16 / VW : 1];   // VW keep-bytes per word
   unsigned ok;      // bit e: element e is inside the matrix.  Applied in store(): a select right behind the load would make the wave
                     // wait for it there, in front of the MFMAs the load is meant to overlap
 
@@ -77,74 +86,82 @@ struct Stager {
       out[0] = *p;
     }
   }
+  __device__ __forceinline__ static unsigned ldm(const unsigned char* p) {
+    if (VW == 4) return *reinterpret_cast<const unsigned*>(p);
+    if (VW == 2) return *reinterpret_cast<const unsigned short*>(p);
+    return *p;
+  }
+
+  // x / rpm for 0 <= x < 2^20, rpm >= 1: one multiply by the reciprocal (exact: the quotient's distance to the next integer is
+  // >= 0.5 / rpm, the product's rounding error < x 2^-22)
+  __device__ __forceinline__ static int div_rpm(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+  // once per tile (MASKED, MODE 0): offsets of the mask rows of this thread's four operand rows - they do not change along K
+  // (kept by the caller: the two register sets of the prefetch share them; a mask has < 2^31 elements)
+  __device__ __forceinline__ static void mask_rows(int (&mo)[4], int r0, int rows, int K, int tid, int rpm) {
+    const float inv = 1.0f / (float)rpm;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) mo[p] = div_rpm(min(r0 + p * (TM / 4) + (tid >> 3), rows - 1), inv) * K;
+  }
 
   // rows = M or N (limit of the row index), r0 = first row of the tile, k0 = first k of this step.
-  // S (optional): variational-dropout mask fused into the load.  MODE 0: element (row, k) *= S[(row / rpm) * K + k];
-  // MODE 1: element (row, k) *= S[(k / rpm) * rows + row]  (rpm = time steps that share one mask row).
-  // MASKED is a compile-time flag: a run-time `if (S)` around the mask loads would put every load behind a branch again.
-  template <bool MASKED>
+  // Addresses are the wave-uniform base pointer + ONE unsigned 32-bit element offset per load (the saddr form of global_load): an
+  // operand spans < 2^30 elements (checked on the host).  Four 64-bit row pointers per operand and register set - what the pointer
+  // form `P + row * pitch` costs - were the registers the 256 tile spilled inside its K loop once the mask words joined them.
   __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid,
-                                       const float* __restrict__ S = nullptr, int rpm = 1) {
+                                       const unsigned char* __restrict__ S, int rpm, const int (&mo)[4]) {
     ok = 0;
     if (MODE == 0) {
       const int kq = (tid & 7) * 4;                   // 4 consecutive k
+      const unsigned pitch = (unsigned)srow;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int r = r0 + p * (TM / 4) + (tid >> 3), k = k0 + kq;
-        const int rc = min(r, rows - 1);
-        const float* rowp = P + (long)rc * srow;
-        const float* srowp = (MASKED && S) ? S + (size_t)(rc / rpm) * K : nullptr;
+        const unsigned ro = (unsigned)min(r, rows - 1) * pitch;
 #pragma unroll
         for (int j = 0; j < 4; j += VW) {
           const int kk = k + j, kc = min(kk, K - VW);
-          float t[VW];
-          ldv(rowp + kc, t);
+          ldv(P + (ro + (unsigned)kc), &v[p * 4 + j]);
           if ((r < rows) && (kk < K)) ok |= ((1u << VW) - 1u) << (p * 4 + j);     // extent % VW == 0: inside or outside as a whole
-          if (MASKED && S) {
-            float m[VW];
-            ldv(srowp + kc, m);
-#pragma unroll
-            for (int i = 0; i < VW; ++i) t[i] *= m[i];
-          }
-#pragma unroll
-          for (int i = 0; i < VW; ++i) v[p * 4 + j + i] = t[i];
+          if (MASKED) mb[(p * 4 + j) / VW] = ldm(S + (unsigned)(mo[p] + kc));
         }
       }
     } else {
       const int m4 = (tid % (TM / 4)) * 4;            // 4 consecutive rows
+      const float inv = 1.0f / (float)rpm;
+      const unsigned pitch = (unsigned)sk;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int k = k0 + 2 * (tid / (TM / 4)) + (p & 1) + 16 * (p >> 1), r = r0 + m4;
         const int kc = min(k, K - 1);
-        const float* kp = P + (long)kc * sk;
-        const float* skp = (MASKED && S) ? S + (size_t)(kc / rpm) * rows : nullptr;
+        const unsigned ko = (unsigned)kc * pitch;
+        const unsigned so = MASKED ? (unsigned)(div_rpm(kc, inv) * rows) : 0u;
 #pragma unroll
         for (int j = 0; j < 4; j += VW) {
           const int rr = r + j, rrc = min(rr, rows - VW);
-          float t[VW];
-          ldv(kp + rrc, t);
+          ldv(P + (ko + (unsigned)rrc), &v[p * 4 + j]);
           if ((k < K) && (rr < rows)) ok |= ((1u << VW) - 1u) << (p * 4 + j);
-          if (MASKED && S) {
-            float m[VW];
-            ldv(skp + rrc, m);
-#pragma unroll
-            for (int i = 0; i < VW; ++i) t[i] *= m[i];
-          }
-#pragma unroll
-          for (int i = 0; i < VW; ++i) v[p * 4 + j + i] = t[i];
+          if (MASKED) mb[(p * 4 + j) / VW] = ldm(S + (so + (unsigned)rrc));
         }
       }
     }
   }
 
-  __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid, bool with_lo = true) const {
+  __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid, bool with_lo = true, float scale = 1.f) const {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       bf16x4_t h, l;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bf16_t a, b;
-        split_bf16(((ok >> (p * 4 + i)) & 1u) ? v[p * 4 + i] : 0.f, a, b);
+        const int e = p * 4 + i;
+        bool keep = (ok >> e) & 1u;
+        float x = v[e];
+        if (MASKED) {
+          keep = keep && ((mb[e / VW] >> (8 * (e % VW))) & 0xffu);
+          x *= scale;
+        }
+        split_bf16(keep ? x : 0.f, a, b);
         h[i] = a;
         l[i] = b;
       }
@@ -181,12 +198,12 @@ __device__ __forceinline__ bf16x8_t frag(const char* img, int row_base, int fr, 
 
 // One workgroup's share of a product: output tile `id / splitk`, K slice `id % splitk` (the body of gemm_x3_kernel and of the grouped
 // weight-gradient kernel below)
-template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP, bool MASKED = false>
+template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP, int MSK = 0>    // MSK: 0 no fused mask, 1 a_scale, 2 b_scale
 __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B, long sbk, long sbn,
                                         const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N, int K, int splitk,
-                                        float* __restrict__ ws, const float* __restrict__ a_scale, const float* __restrict__ b_scale,
-                                        const float* __restrict__ c_scale, int rpm, const float* __restrict__ R, int ldr, int act,
-                                        int id) {
+                                        float* __restrict__ ws, const unsigned char* __restrict__ a_scale, const unsigned char* __restrict__ b_scale,
+                                        float keep_scale, const float* __restrict__ c_scale, int rpm, const float* __restrict__ R, int ldr,
+                                        int act, int id) {
   typedef XT<TM> T;
   constexpr int ARR = T::ARR, JT = T::JT;
   extern __shared__ __attribute__((aligned(1024))) char smem[];          // 2 stages x (A_hi, A_lo, B_hi, B_lo)
@@ -235,6 +252,9 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
       }
     }
   };
+  int moa[4] = {0, 0, 0, 0}, mob[4] = {0, 0, 0, 0};
+  if (MSK == 1 && AMODE == 0) Stager<TM, AMODE, VWA, true>::mask_rows(moa, m0, M, K, tid, rpm);
+  if (MSK == 2 && BMODE == 0) Stager<TM, BMODE, VWB, true>::mask_rows(mob, n0, N, K, tid, rpm);
 #ifndef RUART_X3_PF
 #define RUART_X3_PF 2
 #endif
@@ -245,12 +265,12 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
   // the two LDS stages; a set's loads are issued right after the barrier that follows its store and are consumed two steps later.
   // (The 256 tile - 8 waves x 128 accumulators - has no registers for a second set.)
   if constexpr (TM == 128) {
-    Stager<TM, AMODE, VWA> sa0, sa1;
-    Stager<TM, BMODE, VWB> sb0, sb1;
-    sa0.template load<MASKED>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
-    sb0.template load<MASKED>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
-    sa1.template load<MASKED>(A, a_srow, a_sk, m0, M, (kbeg + 1) * XBK, K, tid, a_scale, rpm);
-    sb1.template load<MASKED>(B, b_srow, b_sk, n0, N, (kbeg + 1) * XBK, K, tid, b_scale, rpm);
+    Stager<TM, AMODE, VWA, MSK == 1> sa0, sa1;
+    Stager<TM, BMODE, VWB, MSK == 2> sb0, sb1;
+    sa0.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
+    sb0.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
+    sa1.load(A, a_srow, a_sk, m0, M, (kbeg + 1) * XBK, K, tid, a_scale, rpm, moa);
+    sb1.load(B, b_srow, b_sk, n0, N, (kbeg + 1) * XBK, K, tid, b_scale, rpm, mob);
     // No branch inside the pair loop: the loads past the slice's end are issued all the same (their addresses are clamped into the
     // matrix, their elements are never stored), so hipcc can count vmcnt exactly - a load behind a run-time condition makes it
     // assume the fewest outstanding loads at the join and wait for the YOUNGER set as well.
@@ -260,48 +280,48 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
     // sched_barrier(0) pins the order  store | barrier | issue the loads of two steps ahead | MFMAs : left alone, hipcc sinks a
     // set's loads below the MFMAs they are meant to run beside and hoists the NEXT store (with its vmcnt wait) above them.
     for (; t + 1 < kend; t += 2) {
-      sa0.store(st0, st0 + ARR, tid, NP == 3);
-      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3);
+      sa0.store(st0, st0 + ARR, tid, NP == 3, keep_scale);
+      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();                                // one barrier per step: the other stage was last read two steps ago
       __builtin_amdgcn_sched_barrier(0);
-      sa0.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 2) * XBK, K, tid, a_scale, rpm);
-      sb0.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 2) * XBK, K, tid, b_scale, rpm);
+      sa0.load(A, a_srow, a_sk, m0, M, (t + 2) * XBK, K, tid, a_scale, rpm, moa);
+      sb0.load(B, b_srow, b_sk, n0, N, (t + 2) * XBK, K, tid, b_scale, rpm, mob);
       __builtin_amdgcn_sched_barrier(0);
       compute(st0);
       __builtin_amdgcn_sched_barrier(0);
-      sa1.store(st1, st1 + ARR, tid, NP == 3);
-      sb1.store(st1 + 2 * ARR, st1 + 3 * ARR, tid, NP == 3);
+      sa1.store(st1, st1 + ARR, tid, NP == 3, keep_scale);
+      sb1.store(st1 + 2 * ARR, st1 + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      sa1.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 3) * XBK, K, tid, a_scale, rpm);
-      sb1.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 3) * XBK, K, tid, b_scale, rpm);
+      sa1.load(A, a_srow, a_sk, m0, M, (t + 3) * XBK, K, tid, a_scale, rpm, moa);
+      sb1.load(B, b_srow, b_sk, n0, N, (t + 3) * XBK, K, tid, b_scale, rpm, mob);
       __builtin_amdgcn_sched_barrier(0);
       compute(st1);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (t < kend) {                                   // odd step count: the last step's operands are in set 0
-      sa0.store(st0, st0 + ARR, tid, NP == 3);
-      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3);
+      sa0.store(st0, st0 + ARR, tid, NP == 3, keep_scale);
+      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();
       compute(st0);
     }
   } else
 #endif
   {
-    Stager<TM, AMODE, VWA> sa;
-    Stager<TM, BMODE, VWB> sb;
+    Stager<TM, AMODE, VWA, MSK == 1> sa;
+    Stager<TM, BMODE, VWB, MSK == 2> sb;
     if (kbeg < kend) {
-      sa.template load<MASKED>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm);
-      sb.template load<MASKED>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm);
+      sa.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
+      sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
     }
     for (int t = kbeg; t < kend; ++t) {
       char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
-      sa.store(st, st + ARR, tid, NP == 3);
-      sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3);
+      sa.store(st, st + ARR, tid, NP == 3, keep_scale);
+      sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
       if (t + 1 < kend) {
-        sa.template load<MASKED>(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm);
-        sb.template load<MASKED>(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm);
+        sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm, moa);
+        sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm, mob);
       }
       compute(st);
     }
@@ -377,15 +397,16 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
   }
 }
 
-template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP = 3, bool MASKED = false>     // NP = 1: the hi.hi product only (plain bf16)
+template <int TM, int AMODE, int BMODE, int VWA, int VWB, int NP = 3, int MSK = 0>     // NP = 1: the hi.hi product only (plain bf16)
 __global__ __launch_bounds__(TM * 2, 2) void gemm_x3_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ B,
                                                             long sbk, long sbn, const float* __restrict__ bias, float* __restrict__ C,
                                                             int ldc, int M, int N, int K, int splitk, float* __restrict__ ws,
-                                                            const float* __restrict__ a_scale, const float* __restrict__ b_scale,
+                                                            const unsigned char* __restrict__ a_scale,
+                                                            const unsigned char* __restrict__ b_scale, float keep_scale,
                                                             const float* __restrict__ c_scale, int rpm, const float* __restrict__ R,
                                                             int ldr, int act) {
-  x3_tile<TM, AMODE, BMODE, VWA, VWB, NP, MASKED>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, a_scale, b_scale, c_scale, rpm, R,
-                                            ldr, act, xcd_remap(blockIdx.x, gridDim.x));
+  x3_tile<TM, AMODE, BMODE, VWA, VWB, NP, MSK>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, splitk, ws, a_scale, b_scale, keep_scale, c_scale,
+                                               rpm, R, ldr, act, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // ---- grouped weight gradients --------------------------------------------------------------------------------------------------
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_grouped_tn_kernel(const X3GArg
   const X3GProb& P = g.p[q];
   const float* R = (P.accum && P.splitk == 1) ? P.C : nullptr;
   x3_tile<128, 1, 1, VECA ? 4 : 1, VECB ? 4 : 1, 3>(P.A, 1, P.lda, P.B, P.ldb, 1, nullptr, P.C, P.ldc, P.M, P.N, P.K, P.splitk, P.ws, nullptr, nullptr,
-                                    nullptr, 1, R, P.ldc, RUART_ACT_NONE, id - P.blk0);
+                                    1.f, nullptr, 1, R, P.ldc, RUART_ACT_NONE, id - P.blk0);
 }
 
 // second launch of a split-K product: one thread per 4 output floats adds the slices in slice order and writes C (+ bias)
@@ -530,16 +551,17 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
   return p;
 }
 
-template <int TM, int AM, int BM_, int VA, int VB, int NP = 3, bool MASKED = false>
+template <int TM, int AM, int BM_, int VA, int VB, int NP = 3, int MSK = 0>
 void launch_x3(const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, float* C, int ldc, int M,
-               int N, int K, const Plan& p, float* ws, const float* a_scale, const float* b_scale, const float* c_scale, int rpm,
+               int N, int K, const Plan& p, float* ws, const unsigned char* a_scale, const unsigned char* b_scale, float keep_scale,
+               const float* c_scale, int rpm,
                const float* R, int ldr, int act, hipStream_t s) {
-  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB, NP, MASKED>;
+  auto kern = gemm_x3_kernel<TM, AM, BM_, VA, VB, NP, MSK>;
   constexpr int lds = 2 * 4 * XT<TM>::ARR;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3(p.tiles * p.splitk), dim3(XT<TM>::THREADS), lds, s, A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K,
-                     p.splitk, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act);
+                     p.splitk, ws, a_scale, b_scale, keep_scale, c_scale, rpm, R, ldr, act);
   if (p.splitk > 1)
     hipLaunchKernelGGL(x3_reduce_kernel<TM>, dim3(p.tiles * 4 * XT<TM>::JT), dim3(XT<TM>::THREADS), 0, s, ws, bias, C, ldc, M, N, p.splitk,
                        c_scale, rpm, R, ldr, act);
@@ -560,8 +582,8 @@ namespace {
 template <int NP>
 int gemm_xn(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
             const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
-            float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
-            int rows_per_scale_row, void* stream) {
+            float* ws, size_t ws_bytes, const unsigned char* a_scale, const unsigned char* b_scale, float keep_scale,
+            const float* c_scale, int rows_per_scale_row, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return (int)hipErrorInvalidValue;
   if ((residual && ldr < N) || (act != RUART_ACT_NONE && act != RUART_ACT_GELU)) return (int)hipErrorInvalidValue;
   const float* R = residual;
@@ -570,14 +592,19 @@ int gemm_xn(const float* A, long long sam, long long sak, const float* B, long l
   const int amode = (sak == 1) ? 0 : (sam == 1 ? 1 : -1);
   const int bmode = (sbk == 1) ? 0 : (sbn == 1 ? 1 : -1);
   if (amode < 0 || bmode < 0) return (int)hipErrorInvalidValue;        // one unit stride per operand
+  {   // the kernels address an operand as base + a 32-bit element offset
+    const long long ea = amode == 0 ? (long long)(M - 1) * sam + K : (long long)(K - 1) * sak + M;
+    const long long eb = bmode == 0 ? (long long)(N - 1) * sbn + K : (long long)(K - 1) * sbk + N;
+    if (ea >= (1LL << 30) || eb >= (1LL << 30) || sam < 0 || sak < 0 || sbk < 0 || sbn < 0) return (int)hipErrorInvalidValue;
+  }
   Plan p = make_plan(M, N, K, amode, bmode);
   if (p.splitk > 1 && (!ws || ws_bytes < (size_t)p.tiles * p.splitk * p.tm * p.tm * sizeof(float))) p.splitk = 1;   // no room: unsplit
   // floats per load along each operand's contiguous index (Stager): base alignment, row pitch and extent must all allow it; a fused
   // mask is read with the operand's width (its pitch is the operand's extent)
-  auto width = [](const float* base, long pitch, int extent, const float* mask) {
-    const uintptr_t bits = reinterpret_cast<uintptr_t>(base) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0);
-    if ((bits & 15) == 0 && (pitch & 3) == 0 && (extent & 3) == 0) return 4;
-    if ((bits & 7) == 0 && (pitch & 1) == 0 && (extent & 1) == 0) return 2;
+  auto width = [](const float* base, long pitch, int extent, const unsigned char* mask) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(base), mbits = mask ? reinterpret_cast<uintptr_t>(mask) : 0;   // (mask: 1 B / element)
+    if ((bits & 15) == 0 && (mbits & 3) == 0 && (pitch & 3) == 0 && (extent & 3) == 0) return 4;
+    if ((bits & 7) == 0 && (mbits & 1) == 0 && (pitch & 1) == 0 && (extent & 1) == 0) return 2;
     return 1;
   };
   const int vwa = width(A, amode == 0 ? sam : sak, amode == 0 ? K : M, a_scale);
@@ -589,7 +616,7 @@ int gemm_xn(const float* A, long long sam, long long sak, const float* B, long l
   }
   hipStream_t s = (hipStream_t)stream;
 #define X3L(TM, AM, BM_, VA, VB) \
-  launch_x3<TM, AM, BM_, VA, VB, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s)
+  launch_x3<TM, AM, BM_, VA, VB, NP>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, keep_scale, c_scale, rpm, R, ldr, act, s)
 #define X3W(TM, AM, BM_)                                         \
   do {                                                           \
     if (vwa == 4 && vwb == 4) X3L(TM, AM, BM_, 4, 4);            \
@@ -608,14 +635,27 @@ int gemm_xn(const float* A, long long sam, long long sak, const float* B, long l
     else X3L(128, AM, BM_, 1, 1);                                \
   } while (0)
   if (a_scale || b_scale) {
-    // operand masks fused into the loads (a test / experiment path: the product materialises x * mask once, ops._Linear): the one
-    // instantiation per layout that carries the mask loads, scalar width
-    if (p.tm == 256) { p.tm = 128; p.tiles = ((M + 127) / 128) * ((N + 127) / 128); p.splitk = 1; }
-#define X3M(AM, BM_) launch_x3<128, AM, BM_, 1, 1, NP, true>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, c_scale, rpm, R, ldr, act, s)
-    if (amode == 0 && bmode == 0) X3M(0, 0);
-    else if (amode == 0 && bmode == 1) X3M(0, 1);
-    else if (amode == 1 && bmode == 0) X3M(1, 0);
-    else X3M(1, 1);
+    // One operand mask fused into the loads (ops._Linear: the forward's (x * mask) W^T with a_scale, dW = dY^T (x * mask) with b_scale).
+    // Both operands are read with the narrower of their two vector widths (one instantiation per width, not per pair).
+    if (a_scale && b_scale) return (int)hipErrorInvalidValue;
+    const int vw = vwa < vwb ? vwa : vwb;
+#define X3M(TM, AM, BM_, VW_, MSK_) \
+  launch_x3<TM, AM, BM_, VW_, VW_, NP, MSK_>(A, sam, sak, B, sbk, sbn, bias, C, ldc, M, N, K, p, ws, a_scale, b_scale, keep_scale, c_scale, rpm, R, ldr, act, s)
+    if (a_scale && amode == 0 && bmode == 0) {
+      if (p.tm == 256 && vw >= 2) {
+        if (vw == 4) X3M(256, 0, 0, 4, 1); else X3M(256, 0, 0, 2, 1);
+      } else {
+        if (p.tm == 256) { p.tm = 128; p.tiles = ((M + 127) / 128) * ((N + 127) / 128); p.splitk = 1; }
+        if (vw == 4) X3M(128, 0, 0, 4, 1); else if (vw == 2) X3M(128, 0, 0, 2, 1); else X3M(128, 0, 0, 1, 1);
+      }
+    } else {
+      if (p.tm == 256) { p.tm = 128; p.tiles = ((M + 127) / 128) * ((N + 127) / 128); p.splitk = 1; }
+      if (b_scale && amode == 1 && bmode == 1) {
+        if (vw == 4) X3M(128, 1, 1, 4, 2); else if (vw == 2) X3M(128, 1, 1, 2, 2); else X3M(128, 1, 1, 1, 2);
+      } else if (a_scale && amode == 0 && bmode == 1) X3M(128, 0, 1, 1, 1);
+      else if (b_scale && amode == 0 && bmode == 1) X3M(128, 0, 1, 1, 2);
+      else return (int)hipErrorInvalidValue;           // (a_scale needs sak == 1, b_scale sbn == 1: checked above)
+    }
 #undef X3M
   } else if (p.tm == 256) {                            // (make_plan picks the big tile for a K-contiguous B only)
     if (bmode != 0) return (int)hipErrorInvalidValue;
@@ -634,19 +674,19 @@ int gemm_xn(const float* A, long long sam, long long sak, const float* B, long l
 
 extern "C" int ruart_gemm_x3(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                              const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
-                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
-                             int rows_per_scale_row, void* stream) {
+                             float* ws, size_t ws_bytes, const unsigned char* a_keep, const unsigned char* b_keep, float keep_scale,
+                             const float* c_scale, int rows_per_scale_row, void* stream) {
   RUART_ENTRY();
-  return gemm_xn<3>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
+  return gemm_xn<3>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_keep, b_keep, keep_scale, c_scale,
                     rows_per_scale_row, stream);
 }
 
 extern "C" int ruart_gemm_x1(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn,
                              const float* bias, const float* residual, int ldr, int act, float* C, int ldc, int M, int N, int K,
-                             float* ws, size_t ws_bytes, const float* a_scale, const float* b_scale, const float* c_scale,
-                             int rows_per_scale_row, void* stream) {
+                             float* ws, size_t ws_bytes, const unsigned char* a_keep, const unsigned char* b_keep, float keep_scale,
+                             const float* c_scale, int rows_per_scale_row, void* stream) {
   RUART_ENTRY();
-  return gemm_xn<1>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_scale, b_scale, c_scale,
+  return gemm_xn<1>(A, sam, sak, B, sbk, sbn, bias, residual, ldr, act, C, ldc, M, N, K, ws, ws_bytes, a_keep, b_keep, keep_scale, c_scale,
                     rows_per_scale_row, stream);
 }
 
@@ -655,7 +695,7 @@ extern "C" int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const floa
   RUART_ENTRY();
   // A stored (K, M): element (m, k) at A[k * sak_rows + m]; B stored (K, N)
   return gemm_xn<1>(A, 1, sak_rows, B, sbk_rows, 1, nullptr, nullptr, 0, RUART_ACT_NONE, C, ldc, M, N, K, ws, ws_bytes, nullptr, nullptr,
-                    nullptr, 1, stream);
+                    1.f, nullptr, 1, stream);
 }
 
 // ---- grouped weight gradients: host side ---------------------------------------------------------------------------------------
@@ -708,7 +748,9 @@ extern "C" int ruart_gemm_x3_tn_grouped(const ruart_x3_tn_problem* probs, int n,
     };
     for (int i = 0; i < n; ++i) {
       const ruart_x3_tn_problem& q = probs[i];
-      if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return (int)hipErrorInvalidValue;
+      if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || q.lda < q.M || q.ldb < q.N || q.ldc < q.N ||
+          (long long)q.K * q.lda >= (1LL << 30) || (long long)q.K * q.ldb >= (1LL << 30))
+        return (int)hipErrorInvalidValue;
       const bool qa = ((reinterpret_cast<uintptr_t>(q.A) & 15) == 0) && ((q.lda & 3) == 0) && ((q.M & 3) == 0);
       const bool qb = ((reinterpret_cast<uintptr_t>(q.B) & 15) == 0) && ((q.ldb & 3) == 0) && ((q.N & 3) == 0);
       if (qa != va || qb != vb) continue;

@@ -126,9 +126,9 @@ _SIGNATURES = {
     "ruart_gemm_x3_tn_grouped": (_I, [POINTER(X3TnProblemC), _I, _P, c_size_t, _P]),
     "ruart_gemm_x3_plan": (_I, [_I, _I, _I, _I, _I, POINTER(ctypes.c_int), POINTER(ctypes.c_size_t)]),
     "ruart_gemm_x3": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _P, _I, _I,
-                           _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _I, _P]),
+                           _I, _I, _P, ctypes.c_size_t, _P, _P, ctypes.c_float, _P, _I, _P]),
     "ruart_gemm_x1": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _P, _I, _I,
-                           _I, _I, _P, ctypes.c_size_t, _P, _P, _P, _I, _P]),
+                           _I, _I, _P, ctypes.c_size_t, _P, _P, ctypes.c_float, _P, _I, _P]),
     "ruart_stream_create_cu_masked": (_I, [_I, POINTER(ctypes.c_void_p)]),
     "ruart_stream_destroy": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),

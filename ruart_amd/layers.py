@@ -48,15 +48,19 @@ class MaskBank:
         for p, n in self.demand.items():
             if n > 0:
                 t = torch.empty(int(n * 1.05) + 1024, device=device, dtype=torch.float32).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
-                self.buf[p] = [t, 0]
+                # the same masks as one byte per element (0 = dropped): what the projections read inside their operand loads (ops._Linear)
+                self.buf[p] = [t, 0, (t != 0).view(torch.uint8)]
 
     def take(self, rows, cols, p, like):
         n = rows * cols
-        self.used[p] = self.used.get(p, 0) + n
+        step = (n + 3) & ~3                     # every mask starts 16-byte aligned: the GEMMs read it with vector loads (ops._Linear)
+        self.used[p] = self.used.get(p, 0) + step
         ent = self.buf.get(p)
         if ent is not None and ent[0].device == like.device and ent[1] + n <= ent[0].numel():
             m = ent[0][ent[1]:ent[1] + n].view(rows, cols)
-            ent[1] += n
+            m.keep = ent[2][ent[1]:ent[1] + n].view(rows, cols)
+            m.keep_scale = 1.0 / (1.0 - p)
+            ent[1] += step
             return m
         return torch.bernoulli(like.new_full((rows, cols), 1.0 - p)) / (1.0 - p)
 

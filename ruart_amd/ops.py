@@ -10,12 +10,16 @@ torch.mm, and SDNet runs that mode on ONE stream.
 There is no CPU path: a CPU tensor raises ``hip.HipError``.
 """
 import ctypes
+import os
 
 import torch
 
 from . import hip
 
 _WS = {}
+# Timing diagnostics only (tools/r04_abl.sh): RUART_ABL_SKIP=lstm,x3,attn,wln leaves out the launches of a kernel class - outputs are
+# zero-filled, results are WRONG - to read a class's marginal cost in the pipelined step.  Empty in every product run.
+_ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)
 
 
 def _scratch(device, n, tag=""):
@@ -66,7 +70,10 @@ class _FusedAttention(torch.autograd.Function):
         dl = 0 if diag is None else diag.numel()
         out = torch.empty(B, L1, D3, dtype=torch.float32, device=pa.device)
         probs = torch.empty(B, L1, L2, dtype=torch.float32, device=pa.device)
-        rc = lib.ruart_attn_fwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(mask), hip.ptr(diag), dl, int(relu),
+        if "attn" in _ABL_SKIP:
+            out.zero_()
+            probs.zero_()
+        rc = 0 if "attn" in _ABL_SKIP else lib.ruart_attn_fwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(mask), hip.ptr(diag), dl, int(relu),
                                        hip.ptr(pscale), hip.ptr(out), hip.ptr(probs), B, L1, L2, h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_fwd")
         ctx.save_for_backward(pa, pk, v, probs, diag, pscale)
@@ -85,7 +92,11 @@ class _FusedAttention(torch.autograd.Function):
         ds = torch.empty_like(probs)
         gdiag = (torch.empty(B * ((L1 + 15) // 16), h, dtype=torch.float32, device=pa.device)
                  if (dl > 1 and ctx.needs_input_grad[4]) else None)
-        rc = lib.ruart_attn_bwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
+        if "attn" in _ABL_SKIP:
+            for t in (ga, gk, gv, gdiag):
+                if t is not None:
+                    t.zero_()
+        rc = 0 if "attn" in _ABL_SKIP else lib.ruart_attn_bwd_pscale(hip.ptr(pa), hip.ptr(pk), hip.ptr(v), hip.ptr(probs), hip.ptr(gout), hip.ptr(diag), dl, ctx.relu,
                                        hip.ptr(pscale), hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2,
                                        h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_bwd")
@@ -185,6 +196,8 @@ trunk_gemm = "x3"
 # bf16 product with fp32 accumulation - what mixed-precision training uses for gradients).  SDNet.forward sets it from
 # opt['ruart_trunk_grad_gemm'] (default "x3").  Forward products always use trunk_gemm.
 trunk_grad_gemm = "x3"
+# variational-dropout masks of the projections' inputs read inside the GEMM's operand loads (see _Linear)
+fuse_operand_masks = os.environ.get("RUART_FUSE_MASK", "1") != "0"
 
 
 def _one_unit_stride(t):
@@ -197,13 +210,15 @@ def _one_unit_stride(t):
     return t.contiguous()
 
 
-def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale=None, rpm=1, residual=None):
+def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scale=1.0, c_scale=None, rpm=1, residual=None):
     """a (M,K) . b (K,N) (+ bias (N,)) (+ residual (M,N)) -> (M,N) fp32 on the split-bf16 MFMA kernel - every size, down to a
     single row: no product of a step goes to the vendor library (see the module docstring).
     ``mode``: 'x3' | 'x1' | 'fp32' (torch.mm: the validation mode); default = the module-level ``trunk_gemm`` (autograd Functions
     pass the mode of their forward).  ``out``: optional contiguous (M, N) destination.
-    ``a_scale`` (M/rpm, K) / ``b_scale`` (K/rpm, N) / ``c_scale`` (M/rpm, N): variational-dropout masks fused into the operand
-    loads / the output (each mask row is shared by ``rpm`` consecutive rows)."""
+    Variational-dropout masks fused into the product (each mask row is shared by ``rpm`` consecutive rows): ``a_keep`` (M/rpm, K) /
+    ``b_keep`` (K/rpm, N) uint8 - the operand element is multiplied by ``keep_scale`` where the byte is non-zero and dropped where
+    it is zero, inside the operand loads (one of the two per call, operand in its natural orientation); ``c_scale`` (M/rpm, N) fp32
+    multiplies the output in the epilogue."""
     M, K = a.shape
     N = b.shape[1]
     mode = mode or trunk_gemm
@@ -212,18 +227,22 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
             if not (t.is_cuda and t.dtype == torch.float32):
                 raise hip.HipError("ops.mm: fp32 device tensors only (there is no CPU path); got %s on %s" % (t.dtype, t.device))
     use_x3 = mode in ("x3", "x1")
+
+    def apply_keep(t, keep):
+        return t * (keep.repeat_interleave(rpm, 0) != 0).to(t.dtype) * keep_scale
+
     if use_x3:
         a, b = _one_unit_stride(a), _one_unit_stride(b)
-        # the fused operand masks follow the operand's natural orientation only: otherwise multiply first
-        if a_scale is not None and a.stride(1) != 1:
-            a, a_scale = _one_unit_stride(a * a_scale.repeat_interleave(rpm, 0)), None
-        if b_scale is not None and b.stride(1) != 1:
-            b, b_scale = _one_unit_stride(b * b_scale.repeat_interleave(rpm, 0)), None
+        # the fused operand masks follow the operand's natural orientation only (and one operand at a time): otherwise multiply first
+        if a_keep is not None and (a.stride(1) != 1 or b_keep is not None or max(M, K) >= (1 << 20)):
+            a, a_keep = _one_unit_stride(apply_keep(a, a_keep)), None
+        if b_keep is not None and (b.stride(1) != 1 or max(N, K) >= (1 << 20)):
+            b, b_keep = _one_unit_stride(apply_keep(b, b_keep)), None
     if not use_x3:
-        if a_scale is not None:
-            a = a * a_scale.repeat_interleave(rpm, 0)
-        if b_scale is not None:
-            b = b * b_scale.repeat_interleave(rpm, 0)
+        if a_keep is not None:
+            a = apply_keep(a, a_keep)
+        if b_keep is not None:
+            b = apply_keep(b, b_keep)
         r = torch.mm(a, b) if bias is None else torch.addmm(bias, a, b)
         if c_scale is not None:
             r = r * c_scale.repeat_interleave(rpm, 0)
@@ -239,9 +258,9 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
     sbk, sbn = (1, b.stride(1)) if b.stride(0) == 1 and b.stride(1) != 1 else (b.stride(0), 1)
     if b.stride(0) == 1 and b.stride(1) == 1:            # K == 1 or N == 1: either description is valid
         sbk, sbn = b.stride(0), 1
-    for sc, shape in ((a_scale, (M // rpm, K)), (b_scale, (K // rpm, N)), (c_scale, (M // rpm, N))):
-        if sc is not None and not (sc.is_contiguous() and tuple(sc.shape) == shape and sc.dtype == torch.float32):
-            raise ValueError("mm: a fused mask must be a contiguous fp32 %s tensor" % (shape,))
+    for sc, shape, dt in ((a_keep, (M // rpm, K), torch.uint8), (b_keep, (K // rpm, N), torch.uint8), (c_scale, (M // rpm, N), torch.float32)):
+        if sc is not None and not (sc.is_contiguous() and tuple(sc.shape) == shape and sc.dtype == dt):
+            raise ValueError("mm: a fused mask must be a contiguous %s %s tensor" % (dt, shape))
     nbytes = ctypes.c_size_t(0)
     hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
     ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
@@ -251,8 +270,10 @@ def mm(a, b, bias=None, mode=None, out=None, a_scale=None, b_scale=None, c_scale
         if not (residual.shape == (M, N) and residual.dtype == torch.float32 and residual.stride(1) == 1):
             residual = residual.contiguous()
         ldr = residual.stride(0)
+    if "x3" in _ABL_SKIP:
+        return out.zero_()
     hip.check(fn(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(residual), ldr, hip.ACT_NONE, hip.ptr(out), N,
-                 M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_scale), hip.ptr(b_scale), hip.ptr(c_scale), int(rpm),
+                 M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_keep), hip.ptr(b_keep), float(keep_scale), hip.ptr(c_scale), int(rpm),
                  hip.stream_ptr()), "ruart_gemm_x3")
     return out
 
@@ -346,41 +367,45 @@ def _defer_weight_grad(gy, xm, w):
 
 class _Linear(torch.autograd.Function):
     """y = (x * mask) W^T (+ b) with x (rows, K), W (N, K), mask (rows / rpm, K) or None, on ruart_gemm_x3.
-    The masked input is materialised once (it is also the operand of dW = dY^T (x * mask)); the backward multiply is fused:
-    dX = (dY W) * mask comes out of the GEMM epilogue.  (Fusing the mask into the OPERAND loads as well - a_scale / b_scale of
-    the kernel - was measured 1.5-2x slower than the separate multiply: the mask is a second load stream per element.)"""
+    With the mask's one-byte-per-element form at hand (``keep``, ``keep_scale``: layers.MaskBank) no pass of its own applies it: the
+    forward reads the bytes beside x in the operand loads (a_keep), dW = dY^T (x * mask) reads them beside x again (b_keep), and
+    dX = (dY W) * mask comes out of the GEMM epilogue (c_scale) - x * mask is never materialised.  Without it (a mask drawn outside the
+    bank; ``fuse_operand_masks = False`` / RUART_FUSE_MASK=0: the form of rounds 2-3) the forward multiplies once and keeps the product."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mask, rpm, wparts=None):
+    def forward(ctx, x, w, b, mask, rpm, wparts=None, keep=None, keep_scale=1.0):
         """``wparts``: [(Parameter, row0, row1), ...] when ``w`` is a concatenation of parameters along its rows (the two directions of a
         BiLSTM input projection): deferred weight gradients are then taken per part, straight into the parameters."""
-        xm = x if mask is None else (x.view(-1, rpm, x.shape[1]) * mask.unsqueeze(1)).view(x.shape)
-        ctx.save_for_backward(xm, w, mask)
+        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm       # form of the two backward products
+        fused = (mask is not None and keep is not None and fuse_operand_masks and trunk_gemm == "x3" and not defer_weight_grads
+                 and x.stride(1) == 1 and x.shape[0] < (1 << 20) and x.shape[1] < (1 << 20))
+        ctx.fused, ctx.keep_scale = fused, float(keep_scale)
+        xm = x if (mask is None or fused) else (x.view(-1, rpm, x.shape[1]) * mask.unsqueeze(1)).view(x.shape)
+        ctx.save_for_backward(xm, w, mask, keep if fused else None)
         # the Parameter behind w, when w IS one (a grouped end-of-backward product writes its .grad directly, see above)
         ctx.wparam = w if (isinstance(w, torch.nn.Parameter) and w.requires_grad) else None
         ctx.wparts = wparts
         ctx.has_bias = b is not None
-        ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm       # form of the two backward products
         ctx.rpm = rpm
-        return mm(xm, w.t(), b)
+        return mm(xm, w.t(), b, a_keep=keep if fused else None, keep_scale=keep_scale, rpm=rpm)
 
     @staticmethod
     def backward(ctx, gy):
-        xm, w, mask = ctx.saved_tensors
+        xm, w, mask, keep = ctx.saved_tensors
         gx = mm(gy, w, mode=ctx.mode, c_scale=mask, rpm=ctx.rpm) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
             wp, parts = ctx.wparam, ctx.wparts
             done = False
-            if defer_weight_grads and ctx.mode == "x3" and gy.stride(1) == 1:
+            if defer_weight_grads and ctx.mode == "x3" and gy.stride(1) == 1 and not ctx.fused:
                 if wp is not None:
                     done = _defer_weight_grad(gy, xm, wp)
                 elif parts and all(p.requires_grad and p.is_leaf for p, _, _ in parts):
                     done = all([_defer_weight_grad(gy[:, r0:r1], xm, p) for p, r0, r1 in parts])
             if not done:
-                gw = mm(gy.t(), xm, mode=ctx.mode)
+                gw = mm(gy.t(), xm, mode=ctx.mode, b_keep=keep, keep_scale=ctx.keep_scale, rpm=ctx.rpm)
         gb = colsum(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class _AddMM(torch.autograd.Function):
@@ -435,7 +460,8 @@ def addmm(base, x, w):
 
 def linear(x, w, b=None, mask=None, wparts=None):
     """F.linear for fp32 device tensors of any leading shape, through ``mm``.  ``mask`` (B, K) with x (B, T, K): variational
-    dropout (x * mask[:, None, :]) applied inside the op - one multiply in the forward, none in the backward."""
+    dropout (x * mask[:, None, :]) applied inside the op.  A mask that carries its byte form (``mask.keep`` uint8 (B, K), ``mask.keep_scale``
+    = 1/(1-p): what layers.MaskBank hands out) is read inside the three products; any other mask costs one multiply in the forward."""
     if trunk_gemm != "x3":             # exact-fp32 validation mode
         if mask is not None:
             x = x * mask.unsqueeze(1)
@@ -444,13 +470,15 @@ def linear(x, w, b=None, mask=None, wparts=None):
         raise hip.HipError("ops.linear: device tensors only (there is no CPU path)")
     lead = x.shape[:-1]
     rpm = 1
+    keep, keep_scale = None, 1.0
     if mask is not None:
         if x.dim() != 3 or mask.shape != (x.shape[0], x.shape[2]):
             raise ValueError("linear(mask=): x (B, T, K) with mask (B, K)")
         rpm = x.shape[1]
+        keep, keep_scale = getattr(mask, "keep", None), getattr(mask, "keep_scale", 1.0)      # layers.MaskBank attaches them
         mask = mask.contiguous()
     x2 = x.reshape(-1, x.shape[-1])
-    y = _Linear.apply(x2, w, b, mask, rpm, wparts)
+    y = _Linear.apply(x2, w, b, mask, rpm, wparts, keep, keep_scale)
     return y.view(*lead, w.shape[0])
 
 
@@ -546,8 +574,14 @@ class _LstmRecurrence(torch.autograd.Function):
         gates = torch.empty_like(xproj) if need else None
         cells = torch.empty_like(y) if need else None
         hprev = torch.empty_like(y) if w_hh.requires_grad else None
-        hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), hip.ptr(hprev), B, T, h,
-                                     ndir, hip.stream_ptr()), "ruart_lstm_fwd")
+        if "lstm" in _ABL_SKIP:
+            y.zero_()
+            for t in (gates, cells, hprev):
+                if t is not None:
+                    t.zero_()
+        else:
+            hip.check(lib.ruart_lstm_fwd(hip.ptr(xproj), hip.ptr(w_hh), hip.ptr(y), hip.ptr(gates), hip.ptr(cells), hip.ptr(hprev), B, T, h,
+                                         ndir, hip.stream_ptr()), "ruart_lstm_fwd")
         ctx.ndir, ctx.h = ndir, h
         ctx.mode = trunk_grad_gemm if trunk_gemm == "x3" else trunk_gemm
         ctx.save_for_backward(w_hh, gates, cells, hprev)
@@ -562,8 +596,11 @@ class _LstmRecurrence(torch.autograd.Function):
         B, T, _ = ctx.shape
         gy = gy.contiguous()
         gx = torch.empty_like(gates)
-        hip.check(lib.ruart_lstm_bwd(hip.ptr(gy), hip.ptr(w_hh), hip.ptr(gates), hip.ptr(cells), hip.ptr(gx), B, T, h, ndir,
-                                     hip.stream_ptr()), "ruart_lstm_bwd")
+        if "lstm" in _ABL_SKIP:
+            gx.zero_()
+        else:
+            hip.check(lib.ruart_lstm_bwd(hip.ptr(gy), hip.ptr(w_hh), hip.ptr(gates), hip.ptr(cells), hip.ptr(gx), B, T, h, ndir,
+                                         hip.stream_ptr()), "ruart_lstm_bwd")
         # grad_W_hh[d] = sum_{b,t} da[b,t,d] (x) h_prev[b,t,d]: one GEMM per direction on column slices (strided views, no copies)
         gw = None
         if ctx.needs_input_grad[1]:

@@ -751,16 +751,21 @@ def test_linear_x3_autograd_matches_fp32():
         assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
 
 
-def test_linear_x3_fused_dropout_mask():
+@pytest.mark.parametrize("B,T,K,N", [(64, 37, 250, 500), (64, 100, 1250, 1000), (64, 100, 800, 250), (64, 36, 1800, 250), (8, 5, 253, 130),
+                                     (3, 7, 36, 20), (64, 40, 1088, 1000)])
+def test_linear_x3_fused_dropout_mask(B, T, K, N):
     """ops.linear(x, w, b, mask=) folds the variational-dropout multiply (one mask row per batch row, shared over time) into
-    the forward GEMM and both gradient GEMMs: same values and gradients as multiplying first."""
+    the forward GEMM's operand loads (a_scale), the weight gradient's (b_scale) and the input gradient's epilogue (c_scale): same
+    values and gradients as multiplying first - at the trunk's shapes (16- and 8-byte mask loads, both tile sizes, split K) and at
+    an odd width (scalar loads)."""
     from ruart_amd import ops
+    assert ops.fuse_operand_masks
     g = torch.Generator().manual_seed(4)
-    B, T, K, N = 64, 37, 250, 500
     x = torch.randn(B, T, K, generator=g).cuda().requires_grad_(True)
     w = (torch.randn(N, K, generator=g) * 0.05).cuda().requires_grad_(True)
     b = torch.randn(N, generator=g).cuda().requires_grad_(True)
-    mask = (torch.bernoulli(torch.full((B, K), 0.7), generator=g) / 0.7).cuda()
+    mask = (torch.bernoulli(torch.full((B, K), 0.7), generator=g) * (1.0 / 0.7)).cuda()
+    mask.keep, mask.keep_scale = (mask != 0).view(torch.uint8), 1.0 / 0.7         # the byte form layers.MaskBank attaches
     gy = torch.randn(B, T, N, generator=g).cuda()
     y = ops.linear(x, w, b, mask=mask)
     y.backward(gy)
@@ -772,6 +777,13 @@ def test_linear_x3_fused_dropout_mask():
         scale = float(r_.abs().max())
         assert float((a_ - r_).abs().max()) <= 3e-5 * scale + 1e-6, name
     assert bool((got[1][mask.unsqueeze(1).expand_as(x) == 0] == 0).all())      # dropped features get exactly zero gradient
+    # a mask without the byte form takes the multiply-first path: same numbers
+    x.grad = w.grad = b.grad = None
+    plain = mask.clone()
+    y3 = ops.linear(x, w, b, mask=plain)
+    y3.backward(gy)
+    assert float((y3.detach() - got[0]).abs().max()) <= 1e-5 * float(got[0].abs().max())
+    assert float((w.grad - got[2]).abs().max()) <= 1e-5 * float(got[2].abs().max())
 
 
 @pytest.mark.parametrize("V,D,n,pad", [(2000, 300, 17000, 1), (51, 12, 17000, None), (75, 8, 2560, None), (300, 300, 40, 1), (10, 1000, 500, None),

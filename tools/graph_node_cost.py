@@ -59,7 +59,7 @@ nul = P(None)
 
 def mm(A, B, C, m, n, k, s):
     # C (m, n) = A (m, k) . B (k, n), both row-major: sam = k, sak = 1, sbk = n, sbn = 1; no workspace -> unsplit, one kernel
-    ck(lib.ruart_gemm_x3(hip.ptr(A), k, 1, hip.ptr(B), n, 1, nul, nul, 0, 0, hip.ptr(C), n, m, n, k, nul, 0, nul, nul, nul, 1, s),
+    ck(lib.ruart_gemm_x3(hip.ptr(A), k, 1, hip.ptr(B), n, 1, nul, nul, 0, 0, hip.ptr(C), n, m, n, k, nul, 0, nul, nul, 1.0, nul, 1, s),
        "ruart_gemm_x3")
 
 

@@ -32,7 +32,7 @@ def t(f, n=2000):
 
 def bare():
     lib.ruart_gemm_x3(hip.ptr(x), K, 1, hip.ptr(wt), 1, K, hip.ptr(b), None, 0, hip.ACT_NONE, hip.ptr(out), N, M, N, K, hip.ptr(ws), nbytes.value,
-                      None, None, None, 1, hip.stream_ptr())
+                      None, None, 1.0, None, 1, hip.stream_ptr())
 
 
 st = hip.stream_ptr()
@@ -40,7 +40,7 @@ px, pw, pb, po, pws = hip.ptr(x), hip.ptr(wt), hip.ptr(b), hip.ptr(out), hip.ptr
 
 
 def barest():
-    lib.ruart_gemm_x3(px, K, 1, pw, 1, K, pb, None, 0, hip.ACT_NONE, po, N, M, N, K, pws, nbytes.value, None, None, None, 1, st)
+    lib.ruart_gemm_x3(px, K, 1, pw, 1, K, pb, None, 0, hip.ACT_NONE, po, N, M, N, K, pws, nbytes.value, None, None, 1.0, None, 1, st)
 
 
 print("torch.empty(M, N)                      %6.1f us" % t(lambda: torch.empty(M, N, device=dev)))
