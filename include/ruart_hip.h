@@ -238,6 +238,21 @@ int ruart_attn_train_fwd(const void* qkv16, int ld, void* ctx16, int ldc, int H,
                          const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, void* stream);
 int ruart_attn_train_bwd(const void* qkv16, int ld, const void* dctx_bf16, int ldc, void* dqkv_bf16, int ldd, int H, int n_heads, int n_blocks,
                          const int* blk_q0, const int* blk_q1, const int* tok_lo, float p_drop, unsigned seed, float* bias_part, void* stream);
+/* The same attention for sequences LONGER than one window (65 .. 512 word pieces; Models/Bert/Bert.py:96-99 windows longer inputs): the
+ * host cuts such a sequence into chunks of <= 64 consecutive tokens [chunk_q0, chunk_q1), all starting at the sequence's first token in
+ * steps of 64 and stored consecutively; chunk_k0 / chunk_k1 = the chunk's whole sequence, chunk_first = the index of the sequence's
+ * first chunk.  One workgroup per (chunk, head).  Forward: the chunk's queries against all key tiles of the sequence (online softmax)
+ * + lse2 (n_tokens x n_heads floats: log2 of each row's sum of exp(score), read by the backward).  Backward: [dQ | dK | dV] rows of the
+ * chunks' tokens in two launches (the chunk's queries over the key tiles; the chunk's keys over the query tiles), no atomics;
+ * needs lse2 and two workspaces: delta_ws (n_tokens x n_heads floats) and scale_ws
+ * (n_chunks x n_heads floats); bias_part (optional, n_chunks x 2H) as in ruart_attn_train_bwd.  Same dropout stream as the window
+ * kernels (indexed by query token and key offset inside the sequence). */
+int ruart_attn_train_fwd_long(const void* qkv16, int ld, void* ctx16, int ldc, int H, int n_heads, int n_chunks, const int* chunk_q0,
+                              const int* chunk_q1, const int* chunk_k0, const int* chunk_k1, float p_drop, unsigned seed, float* lse2,
+                              void* stream);
+int ruart_attn_train_bwd_long(const void* qkv16, int ld, const void* dctx_bf16, int ldc, void* dqkv_bf16, int ldd, int H, int n_heads,
+                              int n_chunks, const int* chunk_q0, const int* chunk_q1, const int* chunk_k0, const int* chunk_k1, const int* chunk_first, float p_drop, unsigned seed, const float* lse2, float* delta_ws,
+                              float* scale_ws, float* bias_part, void* stream);
 
 /* ---- whole BERT encoder (Models/Bert/modeling.py:585-614, all layer outputs kept as Bert.py:137 needs) ---- */
 typedef struct {

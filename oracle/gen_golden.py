@@ -9,7 +9,7 @@ large configurations; they are regenerated from the same seed by
 weight tensor is stored so drift is detected).
 
     python oracle/gen_golden.py            # writes all fixtures
-    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_full | e2e_full_ragged | e2e_stress | e2e_outliers | e2e_phoc | e2e_unlocked | host | dataset | phoc | predict | update
+    python oracle/gen_golden.py layers     # one group: layers | bert | e2e | e2e_full | e2e_full_ragged | e2e_stress | e2e_outliers | e2e_phoc | e2e_unlocked | e2e_unlocked_long | host | dataset | phoc | predict | update
 
 Reference entry points exercised (file:line in /root/reference):
     Models/Bert/modeling.py:585-614   BertModel.forward
@@ -596,25 +596,29 @@ def gen_e2e_phoc():
     save("sdnet_e2e_phoc", **arrays)
 
 
-def gen_e2e_unlocked():
+def gen_e2e_unlocked(name="sdnet_e2e_unlocked", n_q=12):
     """SDNet.forward + loss + backward WITHOUT `LOCK_BERT` (Models/SDNet.py:88-94): the encoder is part of the graph and every one of
     its parameters gets a gradient.  BERT's own dropout (re-enabled by network.train()) is configured to 0 so
-    the pass is deterministic.  Stored: scores, loss, the gradient norm of every parameter, a few gradient slices."""
+    the pass is deterministic.  Stored: scores, loss, the gradient norm of every parameter, a few gradient slices.
+    ``e2e_unlocked_long``: the same with 90-word questions - BERT sequences of more than 64 word pieces (Models/Bert/Bert.py:96-99
+    takes up to 512), beyond one window of the 16-bit trainable encoder's attention kernels."""
     opt = default_opt(vocab_size=600)
     opt.pop("LOCK_BERT")
+    if n_q > opt["max_q_len"]:                       # room for the long questions (the collate widths; the model itself has no limit)
+        opt["max_q_len"], opt["max_q_bert_len"] = n_q + 10, 2 * n_q
     bert_cfg = synth.bert_config(vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     seed = 1033
     net, opt, bw, sw, L = build_reference_sdnet(opt, bert_cfg, seed)
     assert all(p.requires_grad for p in net.Bert.parameters())
     B = 2
-    q, ocr, od, gt, extra = synth.synthetic_batch(opt, B, seed=23, n_q=12, n_ocr=16, n_od=6, bert_vocab=2000, ragged=True)
+    q, ocr, od, gt, extra = synth.synthetic_batch(opt, B, seed=23, n_q=n_q, n_ocr=16, n_od=6, bert_vocab=2000, ragged=True)
     L.set_dropout_prob(0.0)
     net.train()
     net.drop_emb = False
     scores, _ = net(q, ocr, od)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, gt) * gt.size(1)
     loss.backward()
-    arrays = dict(seed=np.array(seed), batch_seed=np.array(23), B=np.array(B), vocab_size=np.array(600),
+    arrays = dict(seed=np.array(seed), batch_seed=np.array(23), B=np.array(B), vocab_size=np.array(600), n_q=np.array(n_q),
                   scores=scores.detach().numpy(), loss=np.array(loss.item()), ocr_num_cnt=np.array(ocr["num_cnt"]))
     names, norms = [], []
     for n_, p in net.named_parameters():
@@ -631,7 +635,7 @@ def gen_e2e_unlocked():
     for k, sl in pick.items():
         arrays["grad:" + k] = prm[k].grad[sl].numpy().copy()
     print("bert grads:", sum(1 for n_ in names if n_.startswith("Bert.")), "none:", [n_ for n_, v in zip(names, norms) if v < 0])
-    save("sdnet_e2e_unlocked", **arrays)
+    save(name, **arrays)
 
 
 # ----------------------------------------------------------------------------------
@@ -953,6 +957,8 @@ if __name__ == "__main__":
         gen_e2e_phoc()
     if "e2e_unlocked" in which:
         gen_e2e_unlocked()
+    if "e2e_unlocked_long" in which:
+        gen_e2e_unlocked("sdnet_e2e_unlocked_long", n_q=90)
     if "host" in which:
         gen_host()
     if "dataset" in which:

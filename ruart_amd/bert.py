@@ -249,6 +249,36 @@ class PackedTokens:
             self._emb_sorts_host = (np.concatenate([a for srt in sorts for a in srt]).astype(np.int32), [[len(a) for a in srt] for srt in sorts])
         return self._emb_sorts_host
 
+    def train_plan(self, device):
+        """Attention plan of the trainable 16-bit encoder (bert_train16.py), from this stream's query blocks: ``win`` = (q0, q1) of the
+        windows of whole short sequences (ruart_attn_train_fwd / _bwd) and ``chunks`` = (q0, q1, k0, k1, first) of the <= 64-token
+        chunks of every sequence longer than one window (ruart_attn_train_fwd_long / _bwd_long: chunks of a sequence are consecutive,
+        start at its first token in steps of 64; ``first`` = index of the sequence's first chunk).  int32 device tensors, cached."""
+        plan = getattr(self, "_train_plan", None)
+        if plan is None or plan["device"] != device:
+            T, Tp, nb, nlb = self.T, self.Tp, self.n_blocks, self.n_long_blocks
+            o = 2 * Tp + 2 * T
+            blk = self.host[o:o + 4 * nb].reshape(4, nb)
+            lblk = self.host[o + 4 * nb:o + 4 * nb + 4 * nlb].reshape(4, nlb)
+            own = (blk[0] == blk[2]) & (blk[1] == blk[3]) & ((blk[1] - blk[0]) <= 64)
+            win = blk[:2, own]
+            ch = [tuple(int(v) for v in blk[:, i]) for i in np.nonzero(~own)[0]]
+            for i in range(nlb):                                   # 128-query blocks of the frozen path's long-sequence kernel
+                q0, q1, k0, k1 = (int(v) for v in lblk[:, i])
+                ch += [(a, min(a + 64, q1), k0, k1) for a in range(q0, q1, 64)]
+            ch.sort()
+            ok = all(q1 - q0 <= 64 and (q0 - k0) % 64 == 0 and k0 <= q0 < q1 <= k1 for q0, q1, k0, k1 in ch)
+            idx = {c[0]: i for i, c in enumerate(ch)}
+            ok = ok and all(k0 in idx and (q0 - k0) // 64 == i - idx[k0] for i, (q0, q1, k0, k1) in enumerate(ch))
+            arr = np.array([c + (idx.get(c[2], 0),) for c in ch], dtype=np.int32).reshape(-1, 5).T.copy()
+            both = torch.from_numpy(np.concatenate([win.reshape(-1), arr.reshape(-1)]).astype(np.int32)).to(device)
+            nw, nc = win.shape[1], arr.shape[1]
+            plan = {"device": device, "ok": bool(ok), "n_win": nw, "n_chunks": nc,
+                    "win": [both[i * nw:(i + 1) * nw] for i in range(2)],
+                    "chunks": [both[2 * nw + i * nc:2 * nw + (i + 1) * nc] for i in range(5)]}
+            self._train_plan = plan
+        return plan
+
     def embedding_sorts(self, device):
         """[sort of the word-piece ids, sort of the positions] as tuples of int32 device tensors (one H2D copy, cached)."""
         if getattr(self, "_emb_sorts", None) is None:

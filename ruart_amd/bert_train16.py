@@ -23,8 +23,9 @@ torch row-wise ops:
             Every reduction has a fixed order: two passes from the same seed give the same bits.
 
 Accuracy class: mixed-precision training - f16 activations, bf16 gradients, fp32 accumulation, master weights and residual-stream
-gradient (tests hold every parameter-gradient norm of the reference's backward to 3 %).  Sequences longer than 64 word pieces are
-outside the attention kernels' window: such a batch falls back to the fp32-class path of bert_train.py.
+gradient (tests hold every parameter-gradient norm of the reference's backward to 3 %).  Sequences longer than 64 word pieces (up to the
+512 of Models/Bert/Bert.py:96-99) are cut into 64-token chunks that attend to their whole sequence (``ruart_attn_train_fwd_long`` /
+``_bwd_long``); only a stream with a key bias (the unpacked -10000 mode) still takes the fp32-class path of bert_train.py.
 """
 import numpy as np
 import torch
@@ -138,8 +139,17 @@ class _Run:
         wq16, wo16, w1_16, w2_16 = self._prep_weights(l, scale)
         qkv = self._gemm(x16, wq16, b_qkv, self._new(Tp, 3 * H, torch.float16), hip.DT_F16)
         ctx = self._new(Tp, H, torch.float16, zero=True)
-        _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, pk.n_blocks, hip.ptr(pk.blk[0]), hip.ptr(pk.blk[1]),
-                                      hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_fwd")
+        plan = pk.train_plan(self.dev)
+        if plan["n_win"]:                                            # windows of whole short sequences
+            _chk(lib.ruart_attn_train_fwd(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, plan["n_win"], hip.ptr(plan["win"][0]),
+                                          hip.ptr(plan["win"][1]), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), st()), "ruart_attn_train_fwd")
+        lse = None
+        if plan["n_chunks"]:                                         # sequences longer than one window: <= 64-token chunks against the whole sequence
+            c = plan["chunks"]
+            lse = torch.empty(self.T, self.nh, dtype=torch.float32, device=self.dev)
+            _chk(lib.ruart_attn_train_fwd_long(hip.ptr(qkv), 3 * H, hip.ptr(ctx), H, H, self.nh, plan["n_chunks"], hip.ptr(c[0]), hip.ptr(c[1]),
+                                               hip.ptr(c[2]), hip.ptr(c[3]), float(self.p_a), self._seed(l, 0), hip.ptr(lse), st()),
+                 "ruart_attn_train_fwd_long")
         ao = self._gemm(ctx, wo16, P[pre + "attention.output.dense.bias"], self._new(Tp, H, torch.float32), hip.DT_F16)
         mid, pre1, st1 = self._ln_fwd(ao, x16, P[pre + "attention.output.LayerNorm.gamma"], P[pre + "attention.output.LayerNorm.beta"],
                                       self.p_h, self._seed(l, 1))
@@ -150,7 +160,7 @@ class _Run:
         del g16
         _, pre2, st2 = self._ln_fwd(ff, mid, P[pre + "output.LayerNorm.gamma"], P[pre + "output.LayerNorm.beta"], self.p_h,
                                     self._seed(l, 2), out=out16)
-        return (qkv, ctx, pre1, st1, mid, h16, pre2, st2)
+        return (qkv, ctx, pre1, st1, mid, h16, pre2, st2, lse)
 
     def _embed_fwd(self):
         """embeddings -> LayerNorm -> dropout on the f16 kernels: (x16, LayerNorm input f16, statistics)"""
@@ -267,10 +277,16 @@ class _Run:
         self.part = torch.empty(max(256, Tp // 128) * 256 * 256 + 4 * wmax * H, dtype=torch.float32, device=dev)
         self.cs_ws = torch.empty(int(lib.ruart_gemm_16_nt_gelu_bwd_ws_floats(Tp, I)), dtype=torch.float32, device=dev)
         self.ln_ws = torch.empty(int(lib.ruart_ln_train_bwd_ws_floats(H)), dtype=torch.float32, device=dev)
-        self.bias_part = torch.empty(pk.n_blocks, 2 * H, dtype=torch.float32, device=dev)
+        plan = pk.train_plan(dev)
+        n_win, n_chunks = plan["n_win"], plan["n_chunks"]
+        self.bias_part = torch.empty(max(n_win, 1), 2 * H, dtype=torch.float32, device=dev)
+        if n_chunks:
+            self.bias_part_long = torch.empty(n_chunks, 2 * H, dtype=torch.float32, device=dev)
+            self.delta_ws = torch.empty(T, self.nh, dtype=torch.float32, device=dev)
+            self.scale_ws = torch.empty(n_chunks, self.nh, dtype=torch.float32, device=dev)
         dqkv = torch.zeros(Tp, 3 * H, dtype=torch.bfloat16, device=dev)                 # pad rows stay zero
         dX = torch.zeros(Tp, H, dtype=torch.float32, device=dev)
-        blk_q0, blk_q1 = pk.blk[0], pk.blk[1]
+        blk_q0, blk_q1 = plan["win"]
         if self.recompute:                                                               # (accurate forward: only layer outputs were kept)
             self.x_in, self.pre_e, self.st_e = self._embed_fwd()
             scratch = self._new(Tp, H, torch.float16)
@@ -280,7 +296,7 @@ class _Run:
             x16 = self.layers[l - 1] if l > 0 else self.x_in
             if self.recompute:
                 self.saved[l] = self._layer_fwd(l, x16, scratch)      # this layer's activations again, on the f16 kernels
-            qkv, ctx, pre1, st1, mid, h16, pre2, st2 = self.saved[l]
+            qkv, ctx, pre1, st1, mid, h16, pre2, st2, lse = self.saved[l]
             # ---- output LayerNorm (+ the layer-mix gradient of this layer's output) and the FFN
             d_res2, d_g2, dg2, db2, dbias2 = self._ln_bwd(dX, G, self.lw[l:l + 1], pre2, st2, P[pre + "output.LayerNorm.gamma"], self.p_h,
                                                           self._seed(l, 2))
@@ -306,11 +322,20 @@ class _Run:
             grads[pre + "attention.output.dense.bias"] = dbias1
             grads[pre + "attention.output.dense.weight"] = self._dw(d_g1, self._bf16(ctx))
             d_ctx = self._gemm(d_g1, wot, None, self._new(Tp, H, torch.bfloat16), hip.DT_BF16)
-            _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, pk.n_blocks, hip.ptr(blk_q0),
-                                          hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), hip.ptr(self.bias_part), st()),
-                 "ruart_attn_train_bwd")
             db = torch.empty(2 * H, dtype=torch.float32, device=dev)          # [query | value] bias gradients: the windows' sums, in order
-            _chk(lib.ruart_colsum_f32_rows(hip.ptr(self.bias_part), pk.n_blocks, 2 * H, 2 * H, hip.ptr(db), 0, st()), "ruart_colsum_f32_rows")
+            if n_win:
+                _chk(lib.ruart_attn_train_bwd(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, n_win, hip.ptr(blk_q0),
+                                              hip.ptr(blk_q1), hip.ptr(pk.tok_lo), float(self.p_a), self._seed(l, 0), hip.ptr(self.bias_part), st()),
+                     "ruart_attn_train_bwd")
+                _chk(lib.ruart_colsum_f32_rows(hip.ptr(self.bias_part), n_win, 2 * H, 2 * H, hip.ptr(db), 0, st()), "ruart_colsum_f32_rows")
+            if n_chunks:                                                      # sequences longer than one window
+                c = plan["chunks"]
+                _chk(lib.ruart_attn_train_bwd_long(hip.ptr(qkv), 3 * H, hip.ptr(d_ctx), H, hip.ptr(dqkv), 3 * H, H, self.nh, n_chunks,
+                                                   hip.ptr(c[0]), hip.ptr(c[1]), hip.ptr(c[2]), hip.ptr(c[3]), hip.ptr(c[4]), float(self.p_a),
+                                                   self._seed(l, 0), hip.ptr(lse), hip.ptr(self.delta_ws), hip.ptr(self.scale_ws),
+                                                   hip.ptr(self.bias_part_long), st()), "ruart_attn_train_bwd_long")
+                _chk(lib.ruart_colsum_f32_rows(hip.ptr(self.bias_part_long), n_chunks, 2 * H, 2 * H, hip.ptr(db), 1 if n_win else 0, st()),
+                     "ruart_colsum_f32_rows")
             # the key bias shifts every score of a query row by the same q . b_k, which the softmax ignores: its gradient is
             # sum_i q_i sum_j dS_ij with sum_j dS_ij = 0 - exactly zero (the reference's 1e-9 is its own rounding noise)
             grads[a + "query.bias"], grads[a + "key.bias"], grads[a + "value.bias"] = db[:H] * scale, torch.zeros_like(db[:H]), db[H:]
@@ -379,7 +404,13 @@ class BertModelTrainable16(BertModelTrainable):
         return ent[1]
 
     def supports(self, packed):
-        return packed.n_long_blocks == 0 and packed.max_len <= 64 and packed.bias_host is None and packed.Tp % 256 == 0
+        """every packed stream without a key bias: windows of whole short sequences and - round 4 - <= 64-token chunks of longer ones"""
+        if packed.bias_host is not None or packed.Tp % 256 != 0:
+            return False
+        if packed.n_long_blocks == 0 and packed.max_len <= 64:
+            return True
+        host_plan = packed.train_plan(packed.ids.device if getattr(packed, "ids", None) is not None else torch.device("cpu"))
+        return bool(host_plan["ok"])
 
     def supports_forward_only(self, packed, training):
         """no gradient wanted and no dropout active: the accurate forward takes any packed stream the frozen fp16c path takes"""

@@ -90,6 +90,8 @@ _SIGNATURES = {
     "ruart_mix_rows_bwd": (_I, [_P, _LL, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_attn_train_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, ctypes.c_uint, _P]),
     "ruart_attn_train_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _F, ctypes.c_uint, _P, _P]),
+    "ruart_attn_train_fwd_long": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, ctypes.c_uint, _P, _P]),
+    "ruart_attn_train_bwd_long": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, ctypes.c_uint, _P, _P, _P, _P, _P]),
     "ruart_gemm_f32_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_bert_embed_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "ruart_rows_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _I, _P]),

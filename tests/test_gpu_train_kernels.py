@@ -349,6 +349,120 @@ def test_attention_train_dropout_is_consistent():
     assert abs(lhs - rhs2) > 5 * abs(lhs - rhs)                                    # another seed: another mask
 
 
+def _long_plan(lens):
+    """(windows, chunks) of a packed stream as bert.PackedTokens.train_plan cuts it: whole short sequences in <= 64-token windows,
+    every longer sequence in chunks of <= 64 tokens that attend to the whole sequence"""
+    from ruart_amd.bert import PackedTokens
+    lens = np.asarray(lens, dtype=np.int64)
+    cu = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cu[1:])
+    blk, _ = PackedTokens._plan_blocks(lens, cu, mfma_long=False)
+    own = (blk[0] == blk[2]) & (blk[1] == blk[3])
+    win = blk[:2, own]
+    ch = blk[:, ~own]
+    first = np.array([int(np.nonzero(ch[0] == k0)[0][0]) for k0 in ch[2]], dtype=np.int32)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(DEV)
+    return cu, [to(win[0]), to(win[1])], [to(ch[0]), to(ch[1]), to(ch[2]), to(ch[3]), to(first)], torch.from_numpy(np.repeat(cu[:-1], lens).astype(np.int32)).to(DEV)
+
+
+def _attn_long_run(lib, qd, dOd, heads, cu, win, ch, tok_lo, p, seed):
+    """forward + backward of a packed stream through the window kernels (short sequences) and the *_long kernels (the others)"""
+    T, H = qd.shape[0], heads * 64
+    ctx = torch.zeros(T, H, dtype=torch.float16, device=DEV)
+    lse = torch.full((T, heads), float("nan"), device=DEV)
+    nw, nc = win[0].numel(), ch[0].numel()
+    if nw:
+        assert lib.ruart_attn_train_fwd(hip.ptr(qd), 3 * H, hip.ptr(ctx), H, H, heads, nw, hip.ptr(win[0]), hip.ptr(win[1]), hip.ptr(tok_lo), p, seed, _st()) == 0
+    assert lib.ruart_attn_train_fwd_long(hip.ptr(qd), 3 * H, hip.ptr(ctx), H, H, heads, nc, hip.ptr(ch[0]), hip.ptr(ch[1]), hip.ptr(ch[2]), hip.ptr(ch[3]),
+                                         p, seed, hip.ptr(lse), _st()) == 0
+    dqkv = torch.zeros(T, 3 * H, dtype=torch.bfloat16, device=DEV)
+    bw = torch.zeros(max(nw, 1), 2 * H, device=DEV)
+    bl = torch.full((nc, 2 * H), float("nan"), device=DEV)
+    if nw:
+        assert lib.ruart_attn_train_bwd(hip.ptr(qd), 3 * H, hip.ptr(dOd), H, hip.ptr(dqkv), 3 * H, H, heads, nw, hip.ptr(win[0]), hip.ptr(win[1]),
+                                        hip.ptr(tok_lo), p, seed, hip.ptr(bw), _st()) == 0
+    delta = torch.empty(T, heads, device=DEV)
+    scale = torch.empty(nc, heads, device=DEV)
+    assert lib.ruart_attn_train_bwd_long(hip.ptr(qd), 3 * H, hip.ptr(dOd), H, hip.ptr(dqkv), 3 * H, H, heads, nc, hip.ptr(ch[0]),
+                                         hip.ptr(ch[1]), hip.ptr(ch[2]), hip.ptr(ch[3]), hip.ptr(ch[4]), p, seed, hip.ptr(lse), hip.ptr(delta),
+                                         hip.ptr(scale), hip.ptr(bl), _st()) == 0
+    torch.cuda.synchronize()
+    return ctx, dqkv, bw.double().sum(0) + bl.double().sum(0)
+
+
+def test_attention_train_long_sequences_vs_autograd():
+    """Sequences of 65 .. 512 word pieces (ruart_attn_train_fwd_long / _bwd_long: 64-token chunks against the whole sequence, online
+    softmax, dQ and dK / dV in two launches) beside short ones (the window kernels), against a float64 autograd attention per
+    sequence: context rows, [dQ | dK | dV] rows and the query / value bias sums.  Lengths cover a ragged last chunk (65, 130, 200), a
+    chunk-aligned one (128) and the maximum (512)."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(21)
+    heads = 2
+    H = heads * 64
+    lens = [5, 65, 64, 130, 3, 512, 30, 128, 200, 40]
+    cu, win, ch, tok_lo = _long_plan(lens)
+    assert win[0].numel() >= 2 and ch[0].numel() == 2 + 3 + 8 + 2 + 4
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H, generator=g)
+    qkv[:, :H] *= 0.125 * 3
+    q16 = qkv.half()
+    dO = torch.randn(T, H, generator=g) * 1e-3
+    dO[int(cu[5]):int(cu[5]) + 64] *= 37.0                       # chunks of one sequence with different dO scales
+    dOb = dO.bfloat16()
+    ctx, dqkv, bsum = _attn_long_run(lib, q16.to(DEV), dOb.to(DEV), heads, cu, win, ch, tok_lo, 0.0, 0)
+    xr = q16.double().requires_grad_()
+    ref = _attn_ref(xr, cu, heads)
+    assert float((ctx.double().cpu() - ref).abs().max()) < 4e-3                    # f16 operands / output, O(1) values
+    ref.backward(dOb.double())
+    got, want = dqkv.double().cpu(), xr.grad
+    bsum = bsum.cpu()
+    for name, sl, bs in (("dQ", slice(0, H), bsum[:H]), ("dV", slice(2 * H, 3 * H), bsum[H:])):
+        assert float((bs - want[:, sl].sum(0)).abs().max()) < 2e-3 * float(want[:, sl].abs().sum(0).max()), name
+    for name, sl in (("dQ", slice(0, H)), ("dK", slice(H, 2 * H)), ("dV", slice(2 * H, 3 * H))):
+        for a, b in zip(cu[:-1], cu[1:]):                                          # per sequence: the long ones must hold the same bound
+            w_, g_ = want[a:b, sl], got[a:b, sl]
+            e = float((g_ - w_).abs().max()) / float(w_.abs().max())
+            rel = float((g_ - w_).norm() / w_.norm())
+            assert e < 4e-2 and rel < 1.5e-2, (name, int(b - a), e, rel)           # bf16 results, f16 operands
+
+
+def test_attention_train_long_matches_the_window_kernels_and_their_dropout_stream():
+    """A 64-token sequence pushed through the *_long kernels as ONE chunk must agree with the window kernels - same probabilities, the
+    SAME dropout mask (the hash is indexed by query token and key offset in both) - and with dropout <dO, O> == <dV, V> holds across
+    the chunks of a long sequence (the backward regenerates the forward's mask in both of its launches)."""
+    lib = hip.load()
+    g = torch.Generator().manual_seed(22)
+    heads, p, seed = 2, 0.1, 4321
+    H = heads * 64
+    lens = [64, 50, 300]
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    T = int(cu[-1])
+    qkv = torch.randn(T, 3 * H, generator=g)
+    qkv[:, :H] *= 0.125 * 2
+    qkv[:, 2 * H:] = torch.randint(-4, 5, (T, H), generator=g).float() / 4          # exact in f16 and bf16
+    qd = qkv.half().to(DEV)
+    dO = (torch.randint(-4, 5, (T, H), generator=g).float() / 64).bfloat16()
+    dOd = dO.to(DEV)
+    to = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    tok_lo = torch.from_numpy(np.repeat(cu[:-1], lens).astype(np.int32)).to(DEV)
+    # (a) the first two sequences as windows, the third as chunks; (b) all three as chunks of themselves
+    win = [to([0, 64]), to([64, 114])]
+    q0 = list(range(114, T, 64))
+    ch_a = [to(q0), to([min(a + 64, T) for a in q0]), to([114] * len(q0)), to([T] * len(q0)), to([0] * len(q0))]
+    ctx_a, dq_a, _ = _attn_long_run(lib, qd, dOd, heads, cu, win, ch_a, tok_lo, p, seed)
+    allq = [0, 64] + q0
+    ch_b = [to(allq), to([64, 114] + [min(a + 64, T) for a in q0]), to([0, 64] + [114] * len(q0)), to([64, 114] + [T] * len(q0)),
+            to([0, 1] + [2] * len(q0))]
+    ctx_b, dq_b, _ = _attn_long_run(lib, qd, dOd, heads, cu, [to([]), to([])], ch_b, tok_lo, p, seed)
+    assert float((ctx_a.float() - ctx_b.float()).abs().max()) < 4e-3              # same mask: only the rounding point of P differs
+    assert float((dq_a.float() - dq_b.float()).abs().max()) < 3e-2 * float(dq_a.float().abs().max())
+    ctx0, _, _ = _attn_long_run(lib, qd, dOd, heads, cu, win, ch_a, tok_lo, 0.0, seed)
+    assert float((ctx_a.float() - ctx0.float()).abs().max()) > 1e-2               # the mask does something
+    lhs = float((dO.double() * ctx_a.double().cpu()).sum())
+    rhs = float((dq_a[:, 2 * H:].double().cpu() * qkv[:, 2 * H:].double()).sum())
+    assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), 1e-3), (lhs, rhs)
+
+
 def test_trainable_encoder_long_sequence_stays_off_the_vendor_gemm():
     """A sequence of 385..512 word pieces is beyond the fused attention kernel's key panel: the fp32-class trainable encoder serves
     it slice by slice on ruart_gemm_x3 (bert_train.py) - never torch.bmm - and agrees with a plain torch attention, values and
