@@ -489,6 +489,9 @@ int ruart_gemm_bf16_tn(const float* A, long long sak_rows, const float* B, long 
  * ordinary stream; n_cus < 0 enables the LAST |n_cus| bits instead (experiments).  ruart_stream_destroy drops it early; never call that from an atexit hook (teardown order
  * of the runtime / profiler is not under the caller's control) - process exit releases the stream. */
 int ruart_stream_create_cu_masked(int n_cus, void** stream_out);
+/* A non-blocking HIP stream of the given priority (HIP's scale: -1 high, 0 normal, 1 low; clamped to the device's range - torch's own
+ * stream pool offers high and normal only).  Returns the granted level counted from the highest (>= 0) or a negative error. */
+int ruart_stream_create_priority(int priority, void** stream_out);
 int ruart_stream_destroy(void* stream);
 
 #ifdef __cplusplus

@@ -588,7 +588,8 @@ class Bert(nn.Module):
         cus = self.prefetch_cus()
         st = self._pf_streams.get(cus)
         if st is None or st.device != dev:
-            st = self._pf_streams[cus] = hip.cu_masked_stream(cus, dev) if cus > 0 else torch.cuda.Stream(device=dev)
+            epr = int(os.environ.get("RUART_ENCODER_PRIORITY", 0))            # experiments: -1 = a HIGH-priority (unmasked) encoder stream
+            st = self._pf_streams[cus] = hip.cu_masked_stream(cus, dev) if cus > 0 else torch.cuda.Stream(device=dev, priority=epr)
         # the set being recycled was last read by the step BEFORE the current one: waiting for the point where the current
         # step picked up its own layers (layers_for) is enough, wherever in the step the prefetch is launched
         if after_stream is not None:

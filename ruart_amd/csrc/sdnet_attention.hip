@@ -731,6 +731,19 @@ extern "C" int ruart_stream_create_cu_masked(int n_cus, void** stream_out) {
   return 0;
 }
 
+extern "C" int ruart_stream_create_priority(int priority, void** stream_out) {
+  RUART_ENTRY();
+  if (!stream_out) return -1;
+  int least = 0, greatest = 0;                       // HIP: numerically lower = higher priority; the range is [greatest, least]
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return -2;
+  if (priority > least) priority = least;
+  if (priority < greatest) priority = greatest;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) return -3;
+  *stream_out = (void*)s;
+  return priority - greatest;                        // >= 0: the level granted, counted from the highest
+}
+
 extern "C" int ruart_stream_destroy(void* stream) {
   RUART_ENTRY();
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;

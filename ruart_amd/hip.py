@@ -132,6 +132,7 @@ _SIGNATURES = {
     "ruart_gemm_x1": (_I, [_P, ctypes.c_longlong, ctypes.c_longlong, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _I, _I, _P, _I, _I,
                            _I, _I, _P, ctypes.c_size_t, _P, _P, ctypes.c_float, _P, _I, _P]),
     "ruart_stream_create_cu_masked": (_I, [_I, POINTER(ctypes.c_void_p)]),
+    "ruart_stream_create_priority": (_I, [_I, POINTER(ctypes.c_void_p)]),
     "ruart_stream_destroy": (_I, [_P]),
     "ruart_gemm_set_tile_order": (_I, [_I]),
     "ruart_gemm_set_variant": (_I, [_I]),
@@ -227,6 +228,22 @@ def cu_masked_stream(n_cus, device):
     # default prefetch stream then).  The process exit releases the stream; call ruart_stream_destroy yourself to drop one earlier.
     st = torch.cuda.ExternalStream(out.value, device=device)
     st._ruart_handle = out.value            # for destroy_stream()
+    return st
+
+
+def priority_stream(priority, device):
+    """torch view of a non-blocking HIP stream of HIP priority ``priority`` (-1 high, 0 normal, 1 LOW - a level torch's stream pool
+    does not offer; ruart_stream_create_priority)."""
+    import torch
+    lib = load()
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = lib.ruart_stream_create_priority(int(priority), ctypes.byref(out))
+    if rc < 0:
+        raise HipError("ruart_stream_create_priority failed (%d)" % rc)
+    st = torch.cuda.ExternalStream(out.value, device=device)
+    st._ruart_handle = out.value
+    st._ruart_level = rc
     return st
 
 

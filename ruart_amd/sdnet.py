@@ -498,17 +498,19 @@ class SDNet(nn.Module):
 
     # -- stream plumbing -----------------------------------------------------------------------------------
     def trunk_stream_priority(self):
-        """Priority of the step's streams (the trainer's step stream and the two branch streams): NORMAL beside a CU-masked encoder
-        stream - the fp16c schedule, where the encoder pass is the longer of the two and a high-priority trunk delays single tiles of
-        its GEMM grids (25.5 -> 24.5 ms per step) - and HIGH otherwise: beside an unmasked encoder stream of equal priority the
-        trunk's small kernels wait behind 256-workgroup GEMM rounds (plain f16: 21.2 ms against 18.6).  RUART_TRUNK_PRIORITY
-        overrides (experiments)."""
+        """Priority of the step's streams (the trainer's step stream and the two branch streams), on HIP's scale (-1 high, 0 normal,
+        1 low).  LOW beside a CU-masked encoder stream - the fp16c schedule, where the encoder pass IS the step (its last GEMM ends
+        it) and the trunk has ~3 ms of slack: a high-priority trunk delays single tiles of the GEMM grids (25.5 -> 24.5 ms per step
+        at normal priority, round 3), and at LOW priority - a level torch's stream pool does not offer (hip.priority_stream) - the
+        step is another 0.6-0.7 ms shorter on the pool's slower boxes (26.0 -> 25.3 ms) and unchanged on its fastest (24.2);
+        `profiles/r04_trunk_priority.log`.  HIGH otherwise: beside an unmasked encoder stream of equal priority the trunk's small
+        kernels wait behind 256-workgroup GEMM rounds (plain f16: 21.2 ms against 18.6).  RUART_TRUNK_PRIORITY overrides."""
         env = os.environ.get("RUART_TRUNK_PRIORITY")
         if env is not None:
             return int(env)
         bert = getattr(self, "Bert", None)
         masked = bert is not None and hasattr(bert, "prefetch_cus") and bert.prefetch_cus() > 0
-        return 0 if masked else -1
+        return 1 if masked else -1
 
     def _side_streams(self, dev):
         pr = self.trunk_stream_priority()                           # same priority as the step stream (trainer.on_step_stream)
@@ -518,6 +520,8 @@ class SDNet(nn.Module):
             ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))          # experiments: see trainer.on_step_stream
             if ncu != 0:
                 st = (hip.cu_masked_stream(ncu, dev), hip.cu_masked_stream(ncu, dev))
+            elif pr > 0:                                            # LOW priority: not in torch's pool (hip.priority_stream)
+                st = (hip.priority_stream(pr, dev), hip.priority_stream(pr, dev))
             else:
                 st = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
             cache[pr] = st

@@ -296,6 +296,9 @@ class SDNetTrainer(BaseTrainer):
             if ncu != 0:
                 from . import hip
                 st = hip.cu_masked_stream(ncu, dev)
+            elif pr > 0:                                        # LOW priority: not in torch's pool
+                from . import hip
+                st = hip.priority_stream(pr, dev)
             else:
                 st = torch.cuda.Stream(device=dev, priority=pr)
             cache[pr] = st

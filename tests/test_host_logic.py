@@ -490,7 +490,7 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
             self.Bert = bert
 
     assert FakeBert(240, True).prefetch_cus() == 240 and FakeBert(240, False).prefetch_cus() == 0
-    assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 0          # fp16c schedule, training: beside the masked pass
+    assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 1          # fp16c schedule, training: LOW beside the masked pass
     assert FakeNet(FakeBert(240, False)).trunk_stream_priority() == -1        # evaluation: unmasked pass, trunk first
     assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
     monkeypatch.setenv("RUART_TRUNK_PRIORITY", "-1")
