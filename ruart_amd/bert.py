@@ -402,6 +402,9 @@ def bert_encode(weights, packed, buffers=None):
     return layers
 
 
+_ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)      # timing diagnostics (ops._ABL_SKIP)
+
+
 class _PoolMix(torch.autograd.Function):
     """out[dst_row[w]] = sum_l layer_w[l] * mean(layer_l[span]) ; gradient only w.r.t. layer_w (BERT is locked,
     Models/SDNet.py:91-94)."""
@@ -415,7 +418,7 @@ class _PoolMix(torch.autograd.Function):
         W = span_start.numel()
         out = torch.zeros(n_rows, H, dtype=torch.float32, device=layers.device)
         lw = layer_w.detach().to(torch.float32).contiguous()
-        if W > 0 and "pool" not in os.environ.get("RUART_ABL_SKIP", ""):          # (timing diagnostics: ops._ABL_SKIP)
+        if W > 0 and "pool" not in _ABL_SKIP:          # (timing diagnostics only, see ops._ABL_SKIP: empty in every product run)
             rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
                                          hip.ptr(dst_row), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
             hip.check(rc, "ruart_bert_pool_mix")
@@ -430,7 +433,7 @@ class _PoolMix(torch.autograd.Function):
         NL, Tp, H = layers.shape
         W = span_start.numel()
         g = torch.zeros(NL, dtype=torch.float32, device=layers.device)
-        if W > 0 and "pool" not in os.environ.get("RUART_ABL_SKIP", ""):
+        if W > 0 and "pool" not in _ABL_SKIP:
             grad_out = grad_out.contiguous()
             partial = torch.empty(W * NL, dtype=torch.float32, device=layers.device)
             rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),

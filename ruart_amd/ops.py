@@ -17,7 +17,7 @@ import torch
 from . import hip
 
 _WS = {}
-# Timing diagnostics only (tools/r04_abl.sh): RUART_ABL_SKIP=lstm,x3,attn,wln leaves out the launches of a kernel class - outputs are
+# Timing diagnostics only (tools/r04_abl.sh, r04_abl2.sh): RUART_ABL_SKIP=lstm,x3,attn (here), pool (bert.py), trunk (sdnet.py) leaves out the launches of a kernel class - outputs are
 # zero-filled, results are WRONG - to read a class's marginal cost in the pipelined step.  Empty in every product run.
 _ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)
 

@@ -409,7 +409,7 @@ class SDNet(nn.Module):
         else:
             layers = self.Bert.layers_for(bi.packed)
         self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
-        if "trunk" in os.environ.get("RUART_ABL_SKIP", ""):      # timing diagnostics (ops._ABL_SKIP): the step without any trunk work
+        if "trunk" in ops._ABL_SKIP:          # timing diagnostics only (ops._ABL_SKIP, empty in every product run): no trunk work at all
             Bq = q_list[opt["q_emb_initial"]].shape[0]
             return torch.zeros(Bq, bi.ocr_mask.shape[1] + 1, device=dev) + lw.sum() * 0.0, None
         H = self.Bert.weights.hidden
