@@ -108,9 +108,15 @@ struct Stager {
   // Addresses are the wave-uniform base pointer + ONE unsigned 32-bit element offset per load (the saddr form of global_load): an
   // operand spans < 2^30 elements (checked on the host).  Four 64-bit row pointers per operand and register set - what the pointer
   // form `P + row * pitch` costs - were the registers the 256 tile spilled inside its K loop once the mask words joined them.
+  // ROWS past the matrix are clamped and NOT zeroed: they only reach output rows / columns that nothing stores (the epilogue and the
+  // split-K sum test m < M, n < N), and they are copies of real rows, so they are finite.  Only k >= K has to contribute zeros, and
+  // that happens in the last K step alone: KFULL (the step lies inside K: no clamp of k, no validity bits, no select in store()) is
+  // what every other step runs - the per-element bounds select was 110 of the 233 VALU instructions of a K step (round 4 counters:
+  // these kernels are bound by their issue slots).
+  template <bool KFULL>
   __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid,
                                        const unsigned char* __restrict__ S, int rpm, const int (&mo)[4]) {
-    ok = 0;
+    ok = KFULL ? 0xffffu : 0u;
     if (MODE == 0) {
       const int kq = (tid & 7) * 4;                   // 4 consecutive k
       const unsigned pitch = (unsigned)srow;
@@ -120,9 +126,9 @@ struct Stager {
         const unsigned ro = (unsigned)min(r, rows - 1) * pitch;
 #pragma unroll
         for (int j = 0; j < 4; j += VW) {
-          const int kk = k + j, kc = min(kk, K - VW);
+          const int kk = k + j, kc = KFULL ? kk : min(kk, K - VW);
           ldv(P + (ro + (unsigned)kc), &v[p * 4 + j]);
-          if ((r < rows) && (kk < K)) ok |= ((1u << VW) - 1u) << (p * 4 + j);     // extent % VW == 0: inside or outside as a whole
+          if (!KFULL && kk < K) ok |= ((1u << VW) - 1u) << (p * 4 + j);           // extent % VW == 0: inside or outside as a whole
           if (MASKED) mb[(p * 4 + j) / VW] = ldm(S + (unsigned)(mo[p] + kc));
         }
       }
@@ -133,20 +139,21 @@ struct Stager {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int k = k0 + 2 * (tid / (TM / 4)) + (p & 1) + 16 * (p >> 1), r = r0 + m4;
-        const int kc = min(k, K - 1);
+        const int kc = KFULL ? k : min(k, K - 1);
         const unsigned ko = (unsigned)kc * pitch;
         const unsigned so = MASKED ? (unsigned)(div_rpm(kc, inv) * rows) : 0u;
+        if (!KFULL && k < K) ok |= 0xfu << (p * 4);
 #pragma unroll
         for (int j = 0; j < 4; j += VW) {
-          const int rr = r + j, rrc = min(rr, rows - VW);
+          const int rrc = min(r + j, rows - VW);
           ldv(P + (ko + (unsigned)rrc), &v[p * 4 + j]);
-          if ((k < K) && (rr < rows)) ok |= ((1u << VW) - 1u) << (p * 4 + j);
           if (MASKED) mb[(p * 4 + j) / VW] = ldm(S + (so + (unsigned)rrc));
         }
       }
     }
   }
 
+  template <bool KFULL>
   __device__ __forceinline__ void store(char* hi_img, char* lo_img, int tid, bool with_lo = true, float scale = 1.f) const {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -155,13 +162,10 @@ struct Stager {
       for (int i = 0; i < 4; ++i) {
         bf16_t a, b;
         const int e = p * 4 + i;
-        bool keep = (ok >> e) & 1u;
         float x = v[e];
-        if (MASKED) {
-          keep = keep && ((mb[e / VW] >> (8 * (e % VW))) & 0xffu);
-          x *= scale;
-        }
-        split_bf16(keep ? x : 0.f, a, b);
+        if (MASKED) x = ((mb[e / VW] >> (8 * (e % VW))) & 0xffu) ? x * scale : 0.f;
+        if (!KFULL) x = ((ok >> e) & 1u) ? x : 0.f;
+        split_bf16(x, a, b);
         h[i] = a;
         l[i] = b;
       }
@@ -267,11 +271,11 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
   if constexpr (TM == 128) {
     Stager<TM, AMODE, VWA, MSK == 1> sa0, sa1;
     Stager<TM, BMODE, VWB, MSK == 2> sb0, sb1;
-    sa0.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
-    sb0.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
-    sa1.load(A, a_srow, a_sk, m0, M, (kbeg + 1) * XBK, K, tid, a_scale, rpm, moa);
-    sb1.load(B, b_srow, b_sk, n0, N, (kbeg + 1) * XBK, K, tid, b_scale, rpm, mob);
-    // No branch inside the pair loop: the loads past the slice's end are issued all the same (their addresses are clamped into the
+    sa0.template load<false>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
+    sb0.template load<false>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
+    sa1.template load<false>(A, a_srow, a_sk, m0, M, (kbeg + 1) * XBK, K, tid, a_scale, rpm, moa);
+    sb1.template load<false>(B, b_srow, b_sk, n0, N, (kbeg + 1) * XBK, K, tid, b_scale, rpm, mob);
+    // No branch inside a pair loop: the loads past the slice's end are issued all the same (their addresses are clamped into the
     // matrix, their elements are never stored), so hipcc can count vmcnt exactly - a load behind a run-time condition makes it
     // assume the fewest outstanding loads at the join and wait for the YOUNGER set as well.
     char* const st0 = smem;
@@ -279,29 +283,36 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
     int t = kbeg;
     // sched_barrier(0) pins the order  store | barrier | issue the loads of two steps ahead | MFMAs : left alone, hipcc sinks a
     // set's loads below the MFMAs they are meant to run beside and hoists the NEXT store (with its vmcnt wait) above them.
-    for (; t + 1 < kend; t += 2) {
-      sa0.store(st0, st0 + ARR, tid, NP == 3, keep_scale);
-      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);
-      __syncthreads();                                // one barrier per step: the other stage was last read two steps ago
-      __builtin_amdgcn_sched_barrier(0);
-      sa0.load(A, a_srow, a_sk, m0, M, (t + 2) * XBK, K, tid, a_scale, rpm, moa);
-      sb0.load(B, b_srow, b_sk, n0, N, (t + 2) * XBK, K, tid, b_scale, rpm, mob);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(st0);
-      __builtin_amdgcn_sched_barrier(0);
-      sa1.store(st1, st1 + ARR, tid, NP == 3, keep_scale);
-      sb1.store(st1 + 2 * ARR, st1 + 3 * ARR, tid, NP == 3, keep_scale);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      sa1.load(A, a_srow, a_sk, m0, M, (t + 3) * XBK, K, tid, a_scale, rpm, moa);
-      sb1.load(B, b_srow, b_sk, n0, N, (t + 3) * XBK, K, tid, b_scale, rpm, mob);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(st1);
-      __builtin_amdgcn_sched_barrier(0);
+    // The pair loop exists twice: while all four K steps an iteration touches (stores t, t + 1; loads t + 2, t + 3) lie inside K it runs
+    // the KFULL forms - no k clamp, no validity bits, no select per element -, the last iterations the general ones.
+#define X3_PAIR(KF)                                                                                       \
+    {                                                                                                     \
+      sa0.template store<KF>(st0, st0 + ARR, tid, NP == 3, keep_scale);                                   \
+      sb0.template store<KF>(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);                     \
+      __syncthreads();                /* one barrier per step: the other stage was last read two steps ago */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      sa0.template load<KF>(A, a_srow, a_sk, m0, M, (t + 2) * XBK, K, tid, a_scale, rpm, moa);            \
+      sb0.template load<KF>(B, b_srow, b_sk, n0, N, (t + 2) * XBK, K, tid, b_scale, rpm, mob);            \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      compute(st0);                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      sa1.template store<KF>(st1, st1 + ARR, tid, NP == 3, keep_scale);                                   \
+      sb1.template store<KF>(st1 + 2 * ARR, st1 + 3 * ARR, tid, NP == 3, keep_scale);                     \
+      __syncthreads();                                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      sa1.template load<KF>(A, a_srow, a_sk, m0, M, (t + 3) * XBK, K, tid, a_scale, rpm, moa);            \
+      sb1.template load<KF>(B, b_srow, b_sk, n0, N, (t + 3) * XBK, K, tid, b_scale, rpm, mob);            \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      compute(st1);                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
+    const int kfull = K / XBK;                        // steps [0, kfull) lie inside K
+    for (; t + 1 < kend && t + 3 < kfull; t += 2) X3_PAIR(true)
+    for (; t + 1 < kend; t += 2) X3_PAIR(false)
+#undef X3_PAIR
     if (t < kend) {                                   // odd step count: the last step's operands are in set 0
-      sa0.store(st0, st0 + ARR, tid, NP == 3, keep_scale);
-      sb0.store(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);
+      sa0.template store<false>(st0, st0 + ARR, tid, NP == 3, keep_scale);
+      sb0.template store<false>(st0 + 2 * ARR, st0 + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();
       compute(st0);
     }
@@ -311,17 +322,28 @@ __device__ __forceinline__ void x3_tile(const float* __restrict__ A, long sam, l
     Stager<TM, AMODE, VWA, MSK == 1> sa;
     Stager<TM, BMODE, VWB, MSK == 2> sb;
     if (kbeg < kend) {
-      sa.load(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
-      sb.load(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
+      sa.template load<false>(A, a_srow, a_sk, m0, M, kbeg * XBK, K, tid, a_scale, rpm, moa);
+      sb.template load<false>(B, b_srow, b_sk, n0, N, kbeg * XBK, K, tid, b_scale, rpm, mob);
     }
-    for (int t = kbeg; t < kend; ++t) {
+    const int kfull = K / XBK;
+    int t = kbeg;
+    for (; t + 1 < kend && t + 1 < kfull; ++t) {        // this step and the next lie inside K: the KFULL forms (see Stager)
       char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
-      sa.store(st, st + ARR, tid, NP == 3, keep_scale);
-      sb.store(st + 2 * ARR, st + 3 * ARR, tid, NP == 3, keep_scale);
+      sa.template store<true>(st, st + ARR, tid, NP == 3, keep_scale);
+      sb.template store<true>(st + 2 * ARR, st + 3 * ARR, tid, NP == 3, keep_scale);
       __syncthreads();                                  // one barrier per step: the other stage was last read two steps ago
+      sa.template load<true>(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm, moa);
+      sb.template load<true>(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm, mob);
+      compute(st);
+    }
+    for (; t < kend; ++t) {
+      char* st = smem + ((t - kbeg) & 1) * (4 * ARR);
+      sa.template store<false>(st, st + ARR, tid, NP == 3, keep_scale);
+      sb.template store<false>(st + 2 * ARR, st + 3 * ARR, tid, NP == 3, keep_scale);
+      __syncthreads();
       if (t + 1 < kend) {
-        sa.load(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm, moa);
-        sb.load(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm, mob);
+        sa.template load<false>(A, a_srow, a_sk, m0, M, (t + 1) * XBK, K, tid, a_scale, rpm, moa);
+        sb.template load<false>(B, b_srow, b_sk, n0, N, (t + 1) * XBK, K, tid, b_scale, rpm, mob);
       }
       compute(st);
     }
