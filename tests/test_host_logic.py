@@ -177,6 +177,51 @@ def test_packed_token_plan_on_cpu():
     assert p2.T == 24 and (p2.key_bias.numpy() == np.where((ids[:3, :8] != 0).reshape(-1), 0, -10000)).all()
 
 
+def test_train_plan_windows_and_chunks_on_cpu():
+    """PackedTokens.train_plan (the attention plan of the 16-bit trainable encoder): whole short sequences in windows, every longer
+    sequence in consecutive <= 64-token chunks that start at its first token - the same plan from both block layouts of the stream
+    (128-query long blocks of the 16-bit frozen path, 64-query chunks of the fp32 / fp16c path); masked-fill dropout masks carry their
+    byte twin."""
+    from ruart_amd.bert import PackedTokens
+    from ruart_amd import layers as L
+    g = np.random.default_rng(2)
+    lens = [3, 65, 64, 130, 7, 512, 30, 128, 1]
+    ids = np.zeros((len(lens), 512), dtype=np.int64)
+    for i, l in enumerate(lens):
+        ids[i, :l] = g.integers(1, 99, size=l)
+    plans = []
+    for mfma_long in (True, False):
+        p = PackedTokens([(torch.from_numpy(ids), torch.from_numpy(ids != 0))], "cpu", mfma_long=mfma_long)
+        plan = p.train_plan(torch.device("cpu"))
+        assert plan["ok"] and plan["n_chunks"] == 2 + 3 + 8 + 2
+        q0, q1, k0, k1, first = (t.numpy() for t in plan["chunks"])
+        w0, w1 = (t.numpy() for t in plan["win"])
+        covered = np.zeros(p.T, dtype=int)
+        for a, b in zip(w0, w1):
+            assert 0 < b - a <= 64
+            covered[a:b] += 1
+        lo, hi = p.tok_lo.numpy(), p.tok_hi.numpy()
+        for i in range(len(q0)):
+            assert 0 < q1[i] - q0[i] <= 64 and (q0[i] - k0[i]) % 64 == 0 and (q0[i] - k0[i]) // 64 == i - first[i]
+            assert (lo[q0[i]:q1[i]] == k0[i]).all() and (hi[q0[i]:q1[i]] == k1[i]).all() and q0[first[i]] == k0[i]
+            covered[q0[i]:q1[i]] += 1
+        assert (covered == 1).all()
+        plans.append((sorted(zip(w0.tolist(), w1.tolist())), list(zip(q0.tolist(), q1.tolist(), k0.tolist(), k1.tolist(), first.tolist()))))
+    assert plans[0] == plans[1]
+    # the mask bank: every mask starts 16-byte aligned and carries keep bytes + scale (what ops._Linear hands to ruart_gemm_x3)
+    bank = L.MaskBank()
+    like = torch.zeros(1)
+    bank.take(3, 5, 0.3, like)
+    bank.take(7, 2, 0.3, like)
+    torch.manual_seed(0)
+    bank.begin_step(torch.device("cpu"))
+    m1, m2 = bank.take(3, 5, 0.3, like), bank.take(7, 2, 0.3, like)
+    for m in (m1, m2):
+        assert m.keep.dtype == torch.uint8 and m.keep.shape == m.shape and torch.equal(m.keep != 0, m != 0)
+        assert abs(m.keep_scale - 1 / 0.7) < 1e-12 and m.storage_offset() % 4 == 0
+        assert bool(((m == 0) | ((m - m.keep_scale).abs() < 1e-6)).all())
+
+
 def test_packed_tokens_window_rows_longer_than_512():
     """Models/Bert/Bert.py:18, 96-99, 133-138: a row longer than 512 word pieces is encoded as independent 512-windows whose
     positions restart at 0.  In the packed stream every (row, window) is its own sequence; the row's pieces stay contiguous."""
