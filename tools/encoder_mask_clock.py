@@ -15,11 +15,12 @@ from ruart_amd.bert import bert_encode, _Buffers
 ap = argparse.ArgumentParser()
 ap.add_argument("--cus", default="128,160,192,224,240,256")
 ap.add_argument("--passes", type=int, default=10)
+ap.add_argument("--batch", type=int, default=64, help="samples in the packed stream (128: what one pass over two batches would encode)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_size=64)
+opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_size=a.batch)
 tr, _ = bench.build_trainer(opt, synth.bert_config(), dev)
-b = tr.ToCUDA(synth.synthetic_batch(opt, 64, seed=7, n_q=30, n_ocr=100, n_od=36))
+b = tr.ToCUDA(synth.synthetic_batch(opt, a.batch, seed=7, n_q=30, n_ocr=100, n_od=36))
 packed = b[0]["_ruart_index"].packed
 W = tr.network.Bert.weights
 W.c_model.tail_cus = 0
@@ -50,6 +51,6 @@ for cus in [int(c) for c in a.cus.split(",")]:
     k = max(1, cnt.value // 4)
     tiles = [(packed.Tp // 256) * nn for nn in (9, 3, 12, 3)]
     rounds = " ".join("%.2f" % (t / cus) for t in tiles)
-    print("%3d CUs: pass %6.2f ms | QKV %5.0f  AO %5.0f  FF1 %5.0f  FF2 %5.0f us | tiles / CUs: %s" % (cus, dt, per[0] / k, per[1] / k, per[2] / k, per[3] / k, rounds),
+    print("B %d rows %d, %3d CUs: pass %6.2f ms | QKV %5.0f  AO %5.0f  FF1 %5.0f  FF2 %5.0f us | tiles / CUs: %s" % (a.batch, packed.Tp, cus, dt, per[0] / k, per[1] / k, per[2] / k, per[3] / k, rounds),
           flush=True)
 tr.close()
