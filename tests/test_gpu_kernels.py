@@ -889,3 +889,20 @@ def test_gemm_x1_layouts(layout):
     assert float((got - ref).abs().max()) < 3e-5 * float(ref.abs().max()) + 1e-4
     full = ops.mm(a.to(d), b.to(d), mode="x3").cpu().double()
     assert float((full - a.double() @ b.double()).abs().max()) < 2e-4 * float(ref.abs().max())      # the three-product form stays fp32-class
+
+
+def test_priority_streams():
+    """ruart_stream_create_priority: the LOW level torch's stream pool lacks (the trunk's streams beside the CU-masked encoder pass,
+    SDNet.trunk_stream_priority) - granted levels are ordered high < normal < low, work enqueued on such a stream runs and joins."""
+    from ruart_amd import hip
+    d = torch.device("cuda:0")
+    hi, no, lo = (hip.priority_stream(p, d) for p in (-1, 0, 1))
+    assert hi._ruart_level <= no._ruart_level <= lo._ruart_level and lo._ruart_level > hi._ruart_level
+    x = torch.arange(1 << 20, device=d, dtype=torch.float32)
+    lo.wait_stream(torch.cuda.current_stream(d))
+    with torch.cuda.stream(lo):
+        y = (x * 2).sum()
+    torch.cuda.current_stream(d).wait_stream(lo)
+    assert float(y) == float((1 << 20) * ((1 << 20) - 1))
+    for st in (hi, no, lo):
+        hip.destroy_stream(st)
