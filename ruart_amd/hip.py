@@ -180,10 +180,30 @@ def check(rc, what):
         raise HipError("%s failed with hipError_t %d" % (what, rc))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def stream_handle(device=None):
+    """Raw handle (int) of the current stream of ``device`` (a tensor's device; None: the current device).  Every kernel launch of a step
+    asks for it - ~200 times per step -, so it goes through torch's C entry point where there is one (0.3 us) instead of building a
+    torch.cuda.Stream object through three layers of device-index helpers (8 us: 1 ms of a step's enqueue time, which is partly on
+    the pipelined step's critical path - profiles/r04_host_delay.log)."""
+    if _raw_stream is not None:
+        if device is None:
+            idx = _cur_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = device.index if getattr(device, "index", None) is not None else _cur_device()
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream_ptr(device=None):
     """The current stream of ``device`` (a tensor's device), not of whichever device happens to be current: a rank whose GPU is
     not the current device must not launch on device 0's stream with pointers into its own memory."""
-    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return c_void_p(stream_handle(device))
 
 
 _DTYPE_CODE = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}

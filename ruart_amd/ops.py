@@ -17,13 +17,14 @@ import torch
 from . import hip
 
 _WS = {}
+_PLAN_BYTES = {}      # (M, N, K, a K-contiguous, b K-contiguous) -> split-K workspace bytes of ruart_gemm_x3_plan
 # Timing diagnostics only (tools/r04_abl.sh, r04_abl2.sh): RUART_ABL_SKIP=lstm,x3,attn (here), pool (bert.py), trunk (sdnet.py) leaves out the launches of a kernel class - outputs are
 # zero-filled, results are WRONG - to read a class's marginal cost in the pipelined step.  Empty in every product run.
 _ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)
 
 
 def _scratch(device, n, tag=""):
-    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)      # per stream: branches run concurrently
+    key = (device, hip.stream_handle(device), tag)      # per stream: branches run concurrently
     t = _WS.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 4096), dtype=torch.float32, device=device)
@@ -261,9 +262,13 @@ def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scal
     for sc, shape, dt in ((a_keep, (M // rpm, K), torch.uint8), (b_keep, (K // rpm, N), torch.uint8), (c_scale, (M // rpm, N), torch.float32)):
         if sc is not None and not (sc.is_contiguous() and tuple(sc.shape) == shape and sc.dtype == dt):
             raise ValueError("mm: a fused mask must be a contiguous %s %s tensor" % (dt, shape))
-    nbytes = ctypes.c_size_t(0)
-    hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
-    ws = _scratch(a.device, nbytes.value // 4, "x3") if nbytes.value else None
+    pkey = (M, N, K, sak == 1, sbk == 1)
+    ws_bytes = _PLAN_BYTES.get(pkey)
+    if ws_bytes is None:                                   # (the plan is a pure function of the shape and the two layouts: asked once)
+        nbytes = ctypes.c_size_t(0)
+        hip.check(lib.ruart_gemm_x3_plan(M, N, K, int(sak == 1), int(sbk == 1), None, ctypes.byref(nbytes)), "ruart_gemm_x3_plan")
+        ws_bytes = _PLAN_BYTES[pkey] = int(nbytes.value)
+    ws = _scratch(a.device, ws_bytes // 4, "x3") if ws_bytes else None
     fn = lib.ruart_gemm_x1 if mode == "x1" else lib.ruart_gemm_x3
     ldr = 0
     if residual is not None:
@@ -273,7 +278,7 @@ def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scal
     if "x3" in _ABL_SKIP:
         return out.zero_()
     hip.check(fn(hip.ptr(a), sam, sak, hip.ptr(b), sbk, sbn, hip.ptr(bias), hip.ptr(residual), ldr, hip.ACT_NONE, hip.ptr(out), N,
-                 M, N, K, hip.ptr(ws), nbytes.value, hip.ptr(a_keep), hip.ptr(b_keep), float(keep_scale), hip.ptr(c_scale), int(rpm),
+                 M, N, K, hip.ptr(ws), ws_bytes, hip.ptr(a_keep), hip.ptr(b_keep), float(keep_scale), hip.ptr(c_scale), int(rpm),
                  hip.stream_ptr()), "ruart_gemm_x3")
     return out
 

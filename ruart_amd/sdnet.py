@@ -37,6 +37,8 @@ from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RN
 if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
+_HOST_DELAY_US = float(os.environ.get("RUART_ABL_HOST_DELAY_US", 0) or 0)
+
 _UNSUPPORTED = ("img_feature", "fixed_answers", "ModelParallel", "PRE_ALIGN_after_rnn", "label_yesno", "no_Context_Self_Attention",
                 "no_DeepAttention")
 
@@ -409,6 +411,11 @@ class SDNet(nn.Module):
         else:
             layers = self.Bert.layers_for(bi.packed)
         self.launch_prefetch()               # the following step's encoder pass starts now, beside this step's trunk
+        if _HOST_DELAY_US:                   # timing diagnostics only (tools/r04_hostdelay.sh): is the host's enqueue time on the step's critical path?
+            import time
+            t_end = time.perf_counter() + _HOST_DELAY_US * 1e-6
+            while time.perf_counter() < t_end:
+                pass
         if "trunk" in ops._ABL_SKIP:          # timing diagnostics only (ops._ABL_SKIP, empty in every product run): no trunk work at all
             Bq = q_list[opt["q_emb_initial"]].shape[0]
             return torch.zeros(Bq, bi.ocr_mask.shape[1] + 1, device=dev) + lw.sum() * 0.0, None

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Python-level host cost of a training step (cProfile, sorted by own time): where the ~15 ms of enqueue time go."""
-import cProfile, os, pstats, sys, time
+"""Python-level host cost of the trunk's FORWARD (the part of a pipelined step that is paced by the host's enqueue rate,
+profiles/r04_host_delay.log): cProfile over SDNet.forward of 8 steps, top functions by own time and by cumulative time."""
+import cProfile, io, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -12,20 +13,31 @@ opt = default_opt(vocab_size=20000, cuda=True, device=dev, max_od_num=36, batch_
 tr, _ = bench.build_trainer(opt, synth.bert_config(), dev)
 batches = [tr.ToCUDA(synth.synthetic_batch(opt, 64, seed=7 + i, n_q=30, n_ocr=100, n_od=36)) for i in range(2)]
 for i in range(4):
-    tr.update(batches[i % 2], i)
-torch.cuda.synchronize()
-N = 8
-t0 = time.perf_counter()
-for i in range(N):
     tr.update(batches[i % 2], i, next_batch=batches[(i + 1) % 2])
 torch.cuda.synchronize()
-print("plain: %.2f ms per step" % ((time.perf_counter() - t0) * 1e3 / N))
+net = tr.network
+orig = net.forward
 pr = cProfile.Profile()
-pr.enable()
-for i in range(N):
+acc = {"t": 0.0, "n": 0}
+
+
+def timed(*a, **k):
+    t0 = time.perf_counter()
+    pr.enable()
+    out = orig(*a, **k)
+    pr.disable()
+    acc["t"] += time.perf_counter() - t0
+    acc["n"] += 1
+    return out
+
+
+net.forward = timed
+t0 = time.perf_counter()
+for i in range(8):
     tr.update(batches[i % 2], i, next_batch=batches[(i + 1) % 2])
 torch.cuda.synchronize()
-pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
-tr.close()
+print("step %.2f ms (profiled), SDNet.forward host time %.2f ms per step" % ((time.perf_counter() - t0) / 8 * 1e3, acc["t"] / acc["n"] * 1e3))
+for key in ("tottime", "cumulative"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28)
+    print("\n".join(l[:170] for l in s.getvalue().splitlines()[:48]))
