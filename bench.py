@@ -386,10 +386,14 @@ def main():
         note("warmup step %d done" % i)
     sync()
     t0 = time.perf_counter()
+    marks = []
     for i in range(a.steps):
         step(i)
+        marks.append(time.perf_counter())     # (host time at which step i's call returned: update() ends with the step's loss readback)
     sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("RUART_BENCH_STEP_TIMES"):      # diagnostics: the spread of the timed steps (stderr)
+        note("per-step ms: " + " ".join("%.1f" % ((b - a_) * 1e3) for a_, b in zip([t0] + marks[:-1], marks)))
     if dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
