@@ -40,6 +40,7 @@ PEAK_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); 
 DTYPE = {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA",
          "fp16c": "f16 MFMA + block-scaled fp8 (e4m3) MFMA correction, f32 accumulate / residual stream"}
 GEMM_KERNEL = {"fp16": "gemm_16_nt_256p8", "bf16": "gemm_16_nt_256p8", "fp16c": "gemm_16c_nt_256p8"}
+TRAFFIC_FILE = "r04_gemm_traffic.json"
 
 
 def parse():
@@ -78,6 +79,10 @@ def parse():
     ap.add_argument("--unlock-bert", action="store_true",
                     help="secondary: conf without LOCK_BERT - the encoder is trained too (fp32 storage, split-bf16 MFMA products)")
     ap.add_argument("--graph-trunk", type=int, default=None, help="1/0: replay the fixed-shape trunk as captured hipGraphs")
+    ap.add_argument("--no-timeline", action="store_true", help="skip the timeline pass (device times of the step's two chains)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="plumbing check of the --gpus N self-launch: rendezvous (gloo on the CPU when there is no GPU), count the ranks "
+                         "with an all-reduce, print {launch_check, ranks_seen} on rank 0 and exit - no product code runs")
     return ap.parse_args()
 
 
@@ -248,16 +253,94 @@ def _claim_stdout():
     return real
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this file under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) as CHILD processes and hand their exit code back.  Runs before anything touches the GPU; the children
+    inherit stdout, so rank 0's JSON line is this process's line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    note("--gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:8])))
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(a, out_stream, world, rank):
+    """--launch-check: what the self-launch has to get right, without the product - every rank arrives, sees the others, and rank 0
+    alone writes the line."""
+    import torch.distributed as dist
+    n = 1
+    if world > 1:
+        gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+        if gpu:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl" if gpu else "gloo")
+        t = torch.ones(1, device="cuda" if gpu else "cpu")
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "ranks_seen": n, "n_gpus": a.gpus}), file=out_stream, flush=True)
+    return 0 if n == a.gpus else 1
+
+
+def _dist(ms):
+    """{min, median, p90, max, first} of a list of per-step times (ms)."""
+    v = sorted(ms)
+    return {"min": round(v[0], 3), "median": round(v[len(v) // 2], 3), "p90": round(v[min(len(v) - 1, int(0.9 * len(v)))], 3),
+            "max": round(v[-1], 3), "first": round(ms[0], 3)}
+
+
+def _timeline(b, e, f):
+    """Medians over the steps of one profiled pass of the timed schedule (records of ruart_prof_timeline: encoder GEMM launches
+    with flops > 0, step-stream marks with flops = -tag), every time in ms from the step's own start (mark 1, forward start on the
+    step stream).  The encoder pass launched inside step t serves batch t+1: its last GEMM ends step t's device work."""
+    marks = [(float(t), int(-fl)) for t, fl in zip(b, f) if fl < 0]
+    starts = [t for t, tag in marks if tag == 1]
+    rows = []
+    for k in range(1, len(starts) - 1):                  # (the first step of the pass refills the pipeline after a sync)
+        s0, s1 = starts[k], starts[k + 1]
+        m = {tag: t - s0 for t, tag in marks if s0 <= t < s1}
+        g = [(bb - s0, ee - s0) for bb, ee, fl in zip(b, e, f) if fl > 0 and s0 <= bb < s1]
+        if not g or 2 not in m or 3 not in m or 4 not in m:
+            continue
+        beside = [ee - bb for bb, ee in g if bb < m[4]]
+        after = [ee - bb for bb, ee in g if bb >= m[4]]
+        rows.append((s1 - s0, m[2], m[3], m[4], g[0][0], g[-1][1], 1e3 * float(np.mean(beside)) if beside else float("nan"),
+                     1e3 * float(np.mean(after)) if after else float("nan"), len(after)))
+    if not rows:
+        return {}
+    med = [float(np.nanmedian([r[i] for r in rows])) for i in range(9)]
+    return {"steps": len(rows), "step": round(med[0], 3), "step_max": round(max(r[0] for r in rows), 3),
+            "trunk_forward_end": round(med[1], 3), "trunk_backward_end": round(med[2], 3),
+            "optimizer_end": round(med[3], 3), "encoder_first_gemm_start": round(med[4], 3), "encoder_last_gemm_end": round(med[5], 3),
+            "gemm_us_beside_trunk": round(med[6], 1), "gemm_us_after_trunk": round(med[7], 1), "gemms_after_trunk": int(med[8]),
+            "what": "medians over the steps of a separate pass of the timed schedule with hipEvents on the step stream and around "
+                    "every encoder GEMM; ms from the step's forward start; the encoder pass is the one launched in that step (batch t+1)"}
+
+
 def main():
     a = parse()
-    out_stream = _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))           # (no GPU call has been made yet: children are fresh processes)
+    out_stream = _claim_stdout()
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if a.launch_check:
+        raise SystemExit(launch_check(a, out_stream, world, rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback of the product path"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -386,18 +469,30 @@ def main():
         note("warmup step %d done" % i)
     sync()
     t0 = time.perf_counter()
-    marks = []
+    marks, enq = [], []
     for i in range(a.steps):
+        ts = time.perf_counter()
         step(i)
         marks.append(time.perf_counter())     # (host time at which step i's call returned: update() ends with the step's loss readback)
+        enq.append((getattr(tr, "host_enqueued_at", ts) - ts) * 1e3)      # host time until the whole step was enqueued (train mode)
     sync()
     dt = time.perf_counter() - t0
-    if os.environ.get("RUART_BENCH_STEP_TIMES"):      # diagnostics: the spread of the timed steps (stderr)
-        note("per-step ms: " + " ".join("%.1f" % ((b - a_) * 1e3) for a_, b in zip([t0] + marks[:-1], marks)))
+    # the spread of the timed steps, always on the line: a uniform slow run, a transient and a slow first step look different here
+    per_step = [(b - a_) * 1e3 for a_, b in zip([t0] + marks[:-1], marks)]
+    step_ms = _dist(per_step)
+    step_ms["what"] = "host time between the returns of consecutive update() calls in the timed region (each ends with its step's loss readback)"
+    if a.mode == "train":
+        step_ms["host_enqueue_median"] = round(sorted(enq)[len(enq) // 2], 3)
+    if os.environ.get("RUART_BENCH_STEP_TIMES"):      # diagnostics: every timed step (stderr)
+        note("per-step ms: " + " ".join("%.1f" % t for t in per_step))
+    ranks_seen = 1
     if dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        t = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(t)                         # every rank that timed the region counts itself
+        ranks_seen = int(t.item())
         dist.barrier()
 
     note("timed region: %.3f s for %d steps" % (dt, a.steps))
@@ -406,35 +501,67 @@ def main():
     #    position (roofline.achieved / frac / avg_launch_us);
     #  * "timed": the schedule of the timed region (encoder of the next batch beside the trunk).  There a GEMM shares the CUs
     #    with the trunk's kernels, so its launch-to-finish time also contains the trunk's work (roofline.timed_region).
-    roof = None
+    roof = timeline = None
     if not a.no_roofline and a.precision in GEMM_KERNEL:
-        def gemm_pass(prefetch):
+        def gemm_pass(prefetch, timeline=None):
+            """K more steps with a hipEvent pair around every encoder GEMM launch.  ``timeline`` (a dict): also mark the step stream at
+            forward start / forward end / backward end / optimizer end and return every step's device times on one time base."""
             saved = a.no_prefetch
             a.no_prefetch = not prefetch
-            step(0)                                                   # settle the pipeline state of this schedule
-            torch.cuda.synchronize()
-            hip.check(lib.ruart_prof_enable(1), "prof_enable")
-            for i in range(a.steps):
-                step(i + 1)
-            torch.cuda.synchronize()
-            ms, n, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
-            hip.check(lib.ruart_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
-            lib.ruart_prof_enable(0)
-            a.no_prefetch = saved
-            return ms.value, int(n.value), fl.value
+            net, optim = tr.network, tr.optimizer
+            orig_fwd, orig_cs = net.forward, getattr(optim, "clip_and_step", None)
+            if timeline is not None and orig_cs is not None:
+                def mark(tag):
+                    lib.ruart_prof_mark(tag, hip.stream_ptr(device))
+
+                def fwd(*x, **k):
+                    mark(1)
+                    out = orig_fwd(*x, **k)
+                    mark(2)
+                    return out
+
+                def cs(*x, **k):
+                    mark(3)
+                    out = orig_cs(*x, **k)
+                    mark(4)
+                    return out
+                net.forward, optim.clip_and_step = fwd, cs
+            try:
+                step(0)                                                   # settle the pipeline state of this schedule
+                torch.cuda.synchronize()
+                hip.check(lib.ruart_prof_enable(1), "prof_enable")
+                for i in range(a.steps):
+                    step(i + 1)
+                torch.cuda.synchronize()
+                M = 8192
+                b_, e_, f_, n_ = (ctypes.c_float * M)(), (ctypes.c_float * M)(), (ctypes.c_double * M)(), ctypes.c_int(0)
+                hip.check(lib.ruart_prof_timeline(b_, e_, f_, M, ctypes.byref(n_)), "prof_timeline")
+                lib.ruart_prof_enable(0)
+            finally:
+                a.no_prefetch = saved
+                if timeline is not None and orig_cs is not None:
+                    del net.forward                       # (instance attributes shadowing the class's methods)
+                    del optim.clip_and_step
+            b_, e_, f_ = np.array(b_[:n_.value]), np.array(e_[:n_.value]), np.array(f_[:n_.value])
+            g = f_ > 0
+            if timeline is not None:
+                timeline.update(_timeline(b_, e_, f_))
+            return float((e_[g] - b_[g]).sum()), int(g.sum()), float(f_[g].sum())
 
         ms_i, n_i, fl_i = gemm_pass(False)
         pipelined = a.mode == "train" and not a.no_prefetch
-        ms_t, n_t, fl_t = gemm_pass(True) if pipelined else (ms_i, n_i, fl_i)
+        timeline = {} if (pipelined and not a.no_timeline) else None
+        ms_t, n_t, fl_t = gemm_pass(True, timeline) if pipelined else (ms_i, n_i, fl_i)
         if n_i and n_t:
             ach = fl_i / (ms_i * 1e-3) / 1e12
             ach_t = fl_t / (ms_t * 1e-3) / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r04_gemm_traffic.json")       # PMC passes cannot run inside this process:
+            traffic = traffic_source = None
+            tf = os.path.join(ROOT, "profiles", TRAFFIC_FILE)                    # PMC passes cannot run inside this process:
             if os.path.exists(tf) and a.batch == 64 and not a.stress:           # the committed rocprofv3 summary of this shape
                 traffic = json.load(open(tf)).get(GEMM_KERNEL[a.precision], {}).get("avg_bytes_per_launch")
+                traffic_source = "profiles/%s: a committed rocprofv3 --pmc summary of this kernel on this workload, NOT measured in this run" % TRAFFIC_FILE
             roof = {"bound": "mfma", "kernel": GEMM_KERNEL[a.precision], "achieved": round(ach_t, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach_t / PEAK_TFLOPS, 4), "traffic": traffic, "launches": n_t,
+                    "frac": round(ach_t / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "launches": n_t,
                     "avg_launch_us": round(ms_t * 1e3 / n_t, 2),
                     "schedule": "the timed region's: encoder of batch t+1 beside the trunk of batch t" if pipelined else "encoder inline",
                     "flops": "algorithmic, 2 * real_rows * N * K per launch" + (
@@ -457,7 +584,7 @@ def main():
 
     if rank == 0:
         out = {"metric": ("VQA samples/sec fwd+bwd (B=64, q=30, ocr=%d)" if a.mode == "train" else "VQA samples/sec fwd-only (B=64, q=30, ocr=%d)") % n_ocr,
-               "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+               "value": round(world * a.batch * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": ("f16 activations / bf16 gradients, fp32 accumulate and master weights" if a.train_gemm == "16"
@@ -469,6 +596,7 @@ def main():
                                          "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
                           "parallelism": "dp%d" % world, "mode": a.mode},
+               "step_ms": step_ms, "timeline_ms": timeline if roof is not None else None,
                "roofline": roof, "parity": parity, "bert512": b512,
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
         if world == 1 and not a.no_cpu_baseline:

@@ -337,7 +337,13 @@ class BatchIndex:
             last_start = [np.zeros(0, dtype=np.int32)] * len(spans)
             # (the C side compacts only when a layer precedes the last one, bert_forward.hip last_layer_rows: same rule here, so the
             # compacted starts are never paired with an uncompacted layer)
-            if frozen and opt.get("bert_last_rows", True) and T > 0 and int((opt.get("bert_config") or {}).get("num_hidden_layers", 12)) >= 2:
+            # layer count: the loaded encoder's when the model hands it over, else the conf's (``Bert`` accepts only the 12 / 24 layers
+            # its BERT / BERT_LARGE flag names, so a checkpoint read from bert_config.json on disk agrees with this default)
+            if bert is not None:
+                n_layers = int(bert.weights.n_layers)
+            else:
+                n_layers = int((opt.get("bert_config") or {}).get("num_hidden_layers", 24 if "BERT_LARGE" in opt else 12))
+            if frozen and opt.get("bert_last_rows", True) and T > 0 and n_layers >= 2:
                 mark = np.zeros(T + 1, dtype=np.int64)
                 for (s_, l_, _, _) in spans:
                     np.add.at(mark, s_, 1)

@@ -402,7 +402,7 @@ def bert_encode(weights, packed, buffers=None):
     return layers
 
 
-_ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)      # timing diagnostics (ops._ABL_SKIP)
+from .ops import _ABL_SKIP      # timing diagnostics (refused without RUART_DIAGNOSTICS=1, ops.py)
 
 
 class _PoolMix(torch.autograd.Function):

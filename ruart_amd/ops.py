@@ -21,6 +21,15 @@ _PLAN_BYTES = {}      # (M, N, K, a K-contiguous, b K-contiguous) -> split-K wor
 # Timing diagnostics only (tools/r04_abl.sh, r04_abl2.sh): RUART_ABL_SKIP=lstm,x3,attn (here), pool (bert.py), trunk (sdnet.py) leaves out the launches of a kernel class - outputs are
 # zero-filled, results are WRONG - to read a class's marginal cost in the pipelined step.  Empty in every product run.
 _ABL_SKIP = frozenset(x for x in os.environ.get("RUART_ABL_SKIP", "").split(",") if x)
+_HOST_DELAY_US = float(os.environ.get("RUART_ABL_HOST_DELAY_US", 0) or 0)
+if _ABL_SKIP or _HOST_DELAY_US:
+    # a stray variable must not corrupt a real run silently: the knobs work only next to an explicit RUART_DIAGNOSTICS=1, and say so
+    if os.environ.get("RUART_DIAGNOSTICS") != "1":
+        raise RuntimeError("RUART_ABL_SKIP / RUART_ABL_HOST_DELAY_US are timing-only ablations that produce WRONG results; "
+                           "set RUART_DIAGNOSTICS=1 beside them to confirm, or unset them")
+    import sys as _sys
+    print("ruart_amd: TIMING DIAGNOSTICS ACTIVE (RUART_ABL_SKIP=%s, RUART_ABL_HOST_DELAY_US=%g): outputs of this process are wrong"
+          % (",".join(sorted(_ABL_SKIP)), _HOST_DELAY_US), file=_sys.stderr, flush=True)
 
 
 def _scratch(device, n, tag=""):
@@ -211,6 +220,14 @@ def _one_unit_stride(t):
     return t.contiguous()
 
 
+_X3_SPAN_LIMIT = 1 << 30
+
+
+def _span(t):
+    """elements between the first and the last element of a 2-D view, inclusive"""
+    return (t.shape[0] - 1) * abs(t.stride(0)) + (t.shape[1] - 1) * abs(t.stride(1)) + 1 if t.numel() else 0
+
+
 def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scale=1.0, c_scale=None, rpm=1, residual=None):
     """a (M,K) . b (K,N) (+ bias (N,)) (+ residual (M,N)) -> (M,N) fp32 on the split-bf16 MFMA kernel - every size, down to a
     single row: no product of a step goes to the vendor library (see the module docstring).
@@ -234,6 +251,20 @@ def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scal
 
     if use_x3:
         a, b = _one_unit_stride(a), _one_unit_stride(b)
+        # the kernels address an operand as base + 32-bit element offset (< 2^30 elements from the first to the last one, include/ruart_hip.h):
+        # a view with a huge pitch is compacted here; an operand that is itself that large is split over its rows
+        if _span(a) >= _X3_SPAN_LIMIT and a.numel() < _X3_SPAN_LIMIT:
+            a = a.contiguous()
+        if _span(b) >= _X3_SPAN_LIMIT and b.numel() < _X3_SPAN_LIMIT:
+            b = b.contiguous()
+        if _span(a) >= _X3_SPAN_LIMIT and a_keep is None and c_scale is None and M > 1:
+            out = torch.empty(M, N, dtype=torch.float32, device=a.device) if out is None else out
+            h = M // 2
+            mm(a[:h], b, bias, mode, out[:h], residual=None if residual is None else residual[:h])
+            mm(a[h:], b, bias, mode, out[h:], residual=None if residual is None else residual[h:])
+            return out
+        if max(_span(a), _span(b)) >= _X3_SPAN_LIMIT:
+            raise ValueError("ops.mm: an operand spans >= 2^30 elements in a layout the split-bf16 kernel cannot address; split the product")
         # the fused operand masks follow the operand's natural orientation only (and one operand at a time): otherwise multiply first
         if a_keep is not None and (a.stride(1) != 1 or b_keep is not None or max(M, K) >= (1 << 20)):
             a, a_keep = _one_unit_stride(apply_keep(a, a_keep)), None

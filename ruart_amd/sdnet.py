@@ -37,7 +37,7 @@ from .layers import Attention, DeepAttention, GetFinalScores, LinearSelfAttn, RN
 if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
-_HOST_DELAY_US = float(os.environ.get("RUART_ABL_HOST_DELAY_US", 0) or 0)
+_HOST_DELAY_US = ops._HOST_DELAY_US          # timing diagnostics only; refused without RUART_DIAGNOSTICS=1 (ops.py)
 
 _UNSUPPORTED = ("img_feature", "fixed_answers", "ModelParallel", "PRE_ALIGN_after_rnn", "label_yesno", "no_Context_Self_Attention",
                 "no_DeepAttention")

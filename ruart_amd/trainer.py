@@ -18,6 +18,7 @@ import json
 import logging
 import os
 import random
+import time
 
 import numpy as np
 import torch
@@ -62,12 +63,33 @@ class _PendingLoss:
     def __truediv__(self, o): return self.item() / o
     def __rtruediv__(self, o): return o / self.item()
     def __neg__(self): return -self.item()
-    def __lt__(self, o): return self.item() < float(o)
-    def __le__(self, o): return self.item() <= float(o)
-    def __gt__(self, o): return self.item() > float(o)
-    def __ge__(self, o): return self.item() >= float(o)
-    def __eq__(self, o): return self.item() == float(o)
-    __hash__ = None
+    # comparisons with anything that is not a number answer as a plain float's would (NotImplemented -> False / TypeError from
+    # Python itself), and the value hashes as the float it stands for: ``loss == None``, ``loss in some_list`` and set / dict
+    # membership stay legal, as they are for the float the reference's update() returns
+    @staticmethod
+    def _num(o):
+        if isinstance(o, _PendingLoss):
+            return o.item()
+        if isinstance(o, (bool, int, float)):
+            return float(o)
+        try:
+            import numbers
+            if isinstance(o, numbers.Real) or (hasattr(o, "__float__") and getattr(o, "ndim", 0) == 0):
+                return float(o)
+        except (TypeError, ValueError):
+            pass
+        return None
+
+    def _cmp(self, o, op):
+        v = self._num(o)
+        return NotImplemented if v is None else op(self.item(), v)
+
+    def __lt__(self, o): return self._cmp(o, lambda a, b: a < b)
+    def __le__(self, o): return self._cmp(o, lambda a, b: a <= b)
+    def __gt__(self, o): return self._cmp(o, lambda a, b: a > b)
+    def __ge__(self, o): return self._cmp(o, lambda a, b: a >= b)
+    def __eq__(self, o): return self._cmp(o, lambda a, b: a == b)
+    def __hash__(self): return hash(self.item())
 
 
 class AverageMeter:
@@ -273,7 +295,7 @@ class SDNetTrainer(BaseTrainer):
         0.5-0.7 ms of host time per step, which delays the next encoder launch by as much when it sits between two ``update`` calls and
         nothing when it sits where the host waits anyway.  Its return value is kept in ``self.staged``.  ``next_batch`` (already through ToCUDA) lets the frozen BERT pass of the following step run
         concurrently with this step's SDNet trunk, on its own stream.  The step runs on a stream of its own too, whose priority ``SDNet.trunk_stream_priority``
-        chooses (normal beside the CU-masked encoder stream of the fp16c schedule, high otherwise)."""
+        chooses (see there and DESIGN.md section 5)."""
         self.network.train()                      # (the step stream's priority depends on the mode: set it before choosing)
         return self.on_step_stream(self._update, batch, batch_i, next_batch, stage_next)
 
@@ -340,6 +362,7 @@ class SDNetTrainer(BaseTrainer):
             return lazy
         if stage_next is not None:
             self.staged = stage_next()
+        self.host_enqueued_at = time.perf_counter()      # (bench.py: how long the host took to enqueue the step)
         # the reference's NaN contract (SDNetTrainer.py:339-359 + the asserts inside forward): one sync, here
         loss_val = loss.item()
         self.network.check_nan()

@@ -53,4 +53,6 @@ for cus in [int(c) for c in a.cus.split(",")]:
     rounds = " ".join("%.2f" % (t / cus) for t in tiles)
     print("B %d rows %d, %3d CUs: pass %6.2f ms | QKV %5.0f  AO %5.0f  FF1 %5.0f  FF2 %5.0f us | tiles / CUs: %s" % (a.batch, packed.Tp, cus, dt, per[0] / k, per[1] / k, per[2] / k, per[3] / k, rounds),
           flush=True)
+    if cus < 256:
+        hip.destroy_stream(st)          # a CU-masked queue alive at exit takes rocprofv3's teardown down (hip.destroy_stream)
 tr.close()

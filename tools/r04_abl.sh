@@ -5,7 +5,7 @@ O=gpurun_out/r04; mkdir -p $O; rm -f $O/abl_*.json
 B="python3 bench.py --no-cpu-baseline --no-bert512 --no-parity"
 for i in 1 2; do
   for v in none lstm x3 attn lstm,x3 lstm,x3,attn; do
-    RUART_ABL_SKIP=$v $B > $O/abl_${v//,/+}_$i.json 2> $O/abl_${v//,/+}_$i.err || tail -3 $O/abl_${v//,/+}_$i.err
+    RUART_DIAGNOSTICS=1 RUART_ABL_SKIP=$v $B > $O/abl_${v//,/+}_$i.json 2> $O/abl_${v//,/+}_$i.err || tail -3 $O/abl_${v//,/+}_$i.err
   done
 done
 python3 - <<'PY'

@@ -5,7 +5,7 @@ O=gpurun_out/r04; mkdir -p $O; rm -f $O/abl2_*.json
 B="python3 bench.py --no-cpu-baseline --no-bert512 --no-parity"
 for i in 1 2; do
   for v in none trunk pool lstm,x3,attn lstm,x3,attn,pool; do
-    RUART_ABL_SKIP=$v $B > $O/abl2_${v//,/+}_$i.json 2> $O/abl2_${v//,/+}_$i.err || tail -3 $O/abl2_${v//,/+}_$i.err
+    RUART_DIAGNOSTICS=1 RUART_ABL_SKIP=$v $B > $O/abl2_${v//,/+}_$i.json 2> $O/abl2_${v//,/+}_$i.err || tail -3 $O/abl2_${v//,/+}_$i.err
   done
 done
 python3 - <<'PY'

@@ -6,7 +6,7 @@ B="python3 bench.py --no-cpu-baseline --no-bert512 --no-parity"
 $B > /dev/null 2>&1
 for i in 1 2; do
   for d in 0 1000 2000 4000; do
-    RUART_ABL_HOST_DELAY_US=$d $B > $O/hd_${d}_$i.json 2> $O/hd.err || tail -3 $O/hd.err
+    RUART_DIAGNOSTICS=1 RUART_ABL_HOST_DELAY_US=$d $B > $O/hd_${d}_$i.json 2> $O/hd.err || tail -3 $O/hd.err
   done
 done
 python3 - <<'PY'
