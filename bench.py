@@ -463,6 +463,23 @@ def main():
         if dp:
             dist.barrier()
 
+    # Host pauses: a full (generation-2) collection of the interpreter walks every container object alive - the model, the staged
+    # batches with the reference's nested python lists of word-piece offsets (~10^5 lists per batch) - and stops the host for tens
+    # of ms once per ~25 steps: a 60 ms step in a 20-step run (round 5).  What is alive here stays alive for the
+    # whole run, so it is moved out of the collector's sight (gc.freeze: a permanent generation), as a long-running trainer would do
+    # after its set-up; collections still run, over the objects a step creates.  Every pause is logged and reported on the line.
+    import gc
+    gc_log = []
+
+    def _gc_cb(phase, info, _t=[0.0]):
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_log.append((time.perf_counter(), info["generation"], (time.perf_counter() - _t[0]) * 1e3))
+    gc.callbacks.append(_gc_cb)
+    if os.environ.get("RUART_BENCH_GC_FREEZE", "1") != "0":
+        gc.collect()
+        gc.freeze()
     for i in range(a.warmup):
         step(i)
         torch.cuda.synchronize()
@@ -483,6 +500,10 @@ def main():
     step_ms["what"] = "host time between the returns of consecutive update() calls in the timed region (each ends with its step's loss readback)"
     if a.mode == "train":
         step_ms["host_enqueue_median"] = round(sorted(enq)[len(enq) // 2], 3)
+    pauses = [(g, ms) for t, g, ms in gc_log if t0 <= t <= t0 + dt]
+    step_ms["gc"] = {"collections": len(pauses), "full_collections": sum(1 for g, _ in pauses if g == 2),
+                     "total_ms": round(sum(ms for _, ms in pauses), 3), "longest_ms": round(max([ms for _, ms in pauses] + [0.0]), 3),
+                     "frozen_setup": os.environ.get("RUART_BENCH_GC_FREEZE", "1") != "0"}
     if os.environ.get("RUART_BENCH_STEP_TIMES"):      # diagnostics: every timed step (stderr)
         note("per-step ms: " + " ".join("%.1f" % t for t in per_step))
     ranks_seen = 1
