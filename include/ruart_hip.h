@@ -158,6 +158,9 @@ int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc, int dtype,
 int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16, void* ctx8, int ldc, int H, int n_heads, int n_blocks,
                                const int* blk_q0, const int* blk_q1, const int* blk_k0, const int* blk_k1, const int* tok_lo,
                                const int* tok_hi, const float* key_bias, void* stream);
+/* heads one workgroup of ruart_bert_attention_split walks (the next head's loads in flight under this head's products; rounded down
+ * to a divisor of n_heads): 0 or 1 = the one-head kernel of rounds 2-4.  Results are bit-identical for every setting. */
+int ruart_bert_attention_split_set_heads(int heads_per_workgroup);
 /* Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581: out[dst_row[w]] = sum_l layer_w[l] *
  * mean(layer_l[span_start[w] .. +span_len[w])).  layers = n_layers matrices [rows, H], layer_stride elements apart.
  * span_start_last (optional): the spans' first rows inside the LAST layer's matrix when ruart_bert_forward left it compacted

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void rows_layernorm_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < MAXG; ++i) {
     const int c = (i * 64 + lane) * 4;
+#if defined(RUART_NT_LN) && RUART_NT_LN
+    v[i] = (c < H) ? load4_stream(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#else
     v[i] = (c < H) ? load4(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#endif
   }
   ln_row_finish(v, H, lane, gamma, beta, eps, RowStorePlain<TOut>{out + (size_t)row * ldo});
 }
@@ -102,7 +106,11 @@ __global__ __launch_bounds__(256) void rows_layernorm_split_kernel(const float* 
 #pragma unroll
   for (int i = 0; i < MAXG; ++i) {
     const int c = (i * 64 + lane) * 4;
+#if defined(RUART_NT_LN) && RUART_NT_LN
+    v[i] = (c < H) ? load4_stream(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#else
     v[i] = (c < H) ? load4(x + (size_t)row * ldx + c) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#endif
   }
   ln_row_finish(v, H, lane, gamma, beta, eps,
                 RowStoreSplit{o32 + (size_t)row * ldo, o16 + (size_t)row * ldo, o8 + (size_t)row * 2 * ldo, H});
@@ -484,6 +492,13 @@ __device__ __forceinline__ void split_f16x8(const f32x4_t a, const f32x4_t b, f1
   }
 }
 
+#ifdef RUART_ABL_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;
+extern "C" int ruart_attn_set_stamps(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p));
+}
+#endif
+#define ATTN_LD4(p) load4_stream(p)          // the fp32 Q / K / V rows are read once per layer (common.h)
 __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
                                                                   unsigned char* __restrict__ ctx8, int ldc, int H,
                                                                   const int* __restrict__ bq0, const int* __restrict__ bq1,
@@ -497,6 +512,14 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   __shared__ __attribute__((aligned(16))) float Bs[64];
   __shared__ __attribute__((aligned(16))) int Ls[64];
   typedef f16x8_t frag_t;
+#ifdef RUART_ABL_ATTN_STAMPS           // diagnostic build: s_memrealtime (100 MHz) at five points of every workgroup + its HW_ID
+#define ATTN_STAMP(i) do { if (g_attn_stamps && threadIdx.x == 0) g_attn_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  ATTN_STAMP(0);
+  if (g_attn_stamps && threadIdx.x == 0) g_attn_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+  if (g_attn_stamps && threadIdx.x == 0) g_attn_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+#else
+#define ATTN_STAMP(i)
+#endif
   int b, h;
   attn_block_head(H >> 6, false, 0, b, h);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -505,6 +528,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   const int tq = q0 + wave * 16 + fr;
   const bool qvalid = tq < q1;
   const int lo_tok = tok_lo[qvalid ? tq : q0];
+#ifdef RUART_ABL_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  ATTN_STAMP(1);
 
   // staging K and V: lane -> (row 16 wave + 4 i + lane / 16, 16-byte piece lane % 16): one load instruction covers four whole
   // 256-byte row slices (8 cache lines, every byte used) where the first form - a lane taking 64 contiguous bytes in four
@@ -519,9 +546,27 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = wave * 16 + i * 4 + prow;
+#ifdef RUART_ABL_ATTN_L2LOADS        // diagnostic build: every workgroup reads the window of token 0 (L2 hits: the time without HBM reads)
+      const float* kp = qkv + (size_t)(min(row, tn - 1)) * ld + H + h * 64 + piece * 4;
+#elif defined(RUART_ABL_ATTN_HEADMAJOR)   // diagnostic build (= the stream's row count): the same bytes read as if Q / K / V were stored
+      // [part][head][row][64] - a window's K tile of a head is then ONE contiguous 16 KB block (wrong numbers, the time of that layout)
+      const float* kp = qkv + ((size_t)((H >> 6) + h) * RUART_ABL_ATTN_HEADMAJOR + (kt + min(row, tn - 1))) * 64 + piece * 4 - H;
+      #define RUART_HM_VOFF ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64)
+#else
       const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
-      kx[i] = load4(kp);
-      vx[i] = load4(kp + H);
+#endif
+#ifdef RUART_ABL_ATTN_NOLOADS         // diagnostic build: operands without memory traffic (the kernel's on-chip time)
+      kx[i] = (f32x4_t){(float)((size_t)kp & 255), 1.f, 2.f, 3.f} * 0.01f;
+      vx[i] = (f32x4_t){(float)((size_t)kp & 127), 3.f, 2.f, 1.f} * 0.01f;
+#else
+      kx[i] = ATTN_LD4(kp);
+#ifdef RUART_ABL_ATTN_HEADMAJOR
+      kx[i] = load4(kp + H);
+      vx[i] = load4(kp + H + ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64));
+#else
+      vx[i] = ATTN_LD4(kp + H);
+#endif
+#endif
     }
     if (tid < 64) {
       const bool in = tid < tn;
@@ -531,11 +576,20 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   };
   f32x4_t qx[4];
   {
+#ifdef RUART_ABL_ATTN_HEADMAJOR
+    const float* qp = qkv + ((size_t)h * RUART_ABL_ATTN_HEADMAJOR + (qvalid ? tq : q0)) * 64 + g * 8;
+#else
     const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qx[2 * ks] = load4(qp + ks * 32);
-      qx[2 * ks + 1] = load4(qp + ks * 32 + 4);
+#ifdef RUART_ABL_ATTN_NOLOADS
+      qx[2 * ks] = (f32x4_t){(float)((size_t)qp & 255), 1.f, 2.f, 3.f} * 0.01f;
+      qx[2 * ks + 1] = (f32x4_t){(float)((size_t)qp & 63), 1.f, 2.f, 3.f} * 0.01f;
+#else
+      qx[2 * ks] = ATTN_LD4(qp + ks * 32);
+      qx[2 * ks + 1] = ATTN_LD4(qp + ks * 32 + 4);
+#endif
     }
   }
   load_kv(k0, min(64, k1 - k0));
@@ -553,6 +607,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
       load_kv(kt, tn);
       __syncthreads();                  // every wave is done reading the previous tile's images
     }
+#ifdef RUART_ABL_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt == k0) ATTN_STAMP(2);
+#endif
     {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -587,6 +645,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
       }
     }
     __syncthreads();
+#ifdef RUART_ABL_ATTN_STAMPS
+    if (kt == k0) ATTN_STAMP(3);
+#endif
+#ifdef RUART_ABL_ATTN_NOCOMPUTE        // diagnostic build: loads, split and LDS images only (the memory side's own time)
+    l = 1.f;
+    for (int r = 0; r < 64; r += 4)
+      o[0][0] += (float)*reinterpret_cast<const f16_t*>(Kh + r * RS + (tid & 63) * 2) + (float)*reinterpret_cast<const f16_t*>(Kl + r * RS + (tid & 63) * 2) +
+                 (float)*reinterpret_cast<const f16_t*>(Vh + r * RS + (tid & 63) * 2) + (float)*reinterpret_cast<const f16_t*>(Vl + r * RS + (tid & 63) * 2);
+    o[1][1] += qx[0][0] + qx[1][1] + qx[2][2] + qx[3][3];
+    continue;
+#endif
 
     f32x4_t sacc[4];
 #pragma unroll
@@ -634,13 +703,269 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
         o[dt] = mfma_16x16x32(uh.f, ph[s2], o[dt]);
       }
   }
+  ATTN_STAMP(4);
+#ifdef RUART_ABL_ATTN_TINYSTORE       // diagnostic build: one 2-byte store per workgroup keeps everything before it alive
+  if (tid == 0) ctx16[(size_t)q0 * ldc + h * 64] = (f16_t)(o[0][0] + o[1][1] + o[2][2] + o[3][3] + l);
+  if (qvalid && l == 12345.678f) {
+#elif defined(RUART_ABL_ATTN_NOSTORE)         // diagnostic build: nothing is written (the condition is never true, the compiler cannot know)
+  if (qvalid && l == 12345.678f) {
+#else
   if (qvalid) {
+#endif
     const float inv = 1.0f / l;
     const size_t col = (size_t)h * 64 + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       store_split4(ctx16 + (size_t)tq * ldc + col + dt * 16, ctx8 + (size_t)tq * 2 * ldc + col + dt * 16, H, o[dt] * inv);
   }
+#ifdef RUART_ABL_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(5);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// attn_flash_split_kernel, several heads per workgroup (round 5).  One window of <= 64 queries per workgroup as before, but the
+// workgroup walks HPG consecutive heads (x the window's key tiles) and the global loads of step j + 1 - the next head's K / V
+// slices, and its Q rows once the score products of step j have consumed the current ones - are issued as soon as step j's
+// operands have left their registers for LDS: they are in flight under step j's MFMAs, softmax and stores.  The one-head kernel
+// runs load -> split -> LDS -> MFMA -> store strictly one after the other inside a workgroup and relies on the four workgroups
+// of a CU to overlap them (47 % of the HBM rate, waves at issue 55 % of their cycles: profiles/r04_pmc_per_kernel.csv).
+// A head's context rows are converted when its last tile is done and WRITTEN one step later, just before that step issues its own
+// prefetch: gfx9 counts loads and stores in one in-order vmcnt queue, so stores issued at the end of a step would be drained by the
+// next step's first wait for its operands (2-3 us per step, measured with s_memrealtime stamps); issued ahead of the prefetch they
+// have a whole step to complete.
+// The arithmetic of a (window, head) is the one-head kernel's, instruction for instruction: the outputs are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int HPG>
+__global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
+                                                                     unsigned char* __restrict__ ctx8, int ldc, int H,
+                                                                     const int* __restrict__ bq0, const int* __restrict__ bq1,
+                                                                     const int* __restrict__ bk0, const int* __restrict__ bk1,
+                                                                     const int* __restrict__ tok_lo, const float* __restrict__ key_bias) {
+  constexpr int RS = 144;
+  __shared__ __attribute__((aligned(16))) char Kh[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Kl[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vh[64 * RS];
+  __shared__ __attribute__((aligned(16))) char Vl[64 * RS];
+  __shared__ __attribute__((aligned(16))) float Bs[64];
+  __shared__ __attribute__((aligned(16))) int Ls[64];
+  typedef f16x8_t frag_t;
+  const int n_groups = (H >> 6) / HPG;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);          // XCD-contiguous ids, the head GROUP fastest (neighbours share token rows)
+  const int b = id / n_groups, h0 = (id - b * n_groups) * HPG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
+  const int tq = q0 + wave * 16 + fr;
+  const bool qvalid = tq < q1;
+  const int lo_tok = tok_lo[qvalid ? tq : q0];
+  const int prow = lane >> 4, piece = lane & 15;
+  const int n_tiles = (k1 - k0 + 63) >> 6, n_steps = n_tiles * HPG;
+
+  f32x4_t kx[4], vx[4], qx[4];
+  int ls_v = -1;
+  float bs_v = 0.f;
+  auto load_kv = [&](int h, int kt, int tn) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 16 + i * 4 + prow;
+#ifdef RUART_ABL_ATTN_L2LOADS        // diagnostic build (see the one-head kernel)
+      const float* kp = qkv + (size_t)(min(row, tn - 1)) * ld + H + h * 64 + piece * 4;
+#elif defined(RUART_ABL_ATTN_HEADMAJOR)
+      const float* kp = qkv + ((size_t)((H >> 6) + h) * RUART_ABL_ATTN_HEADMAJOR + (kt + min(row, tn - 1))) * 64 + piece * 4 - H;
+#else
+      const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
+#endif
+#ifdef RUART_ABL_ATTN_NOLOADS         // diagnostic build: operands without memory traffic (the kernel's on-chip time)
+      kx[i] = (f32x4_t){(float)((size_t)kp & 255), 1.f, 2.f, 3.f} * 0.01f;
+      vx[i] = (f32x4_t){(float)((size_t)kp & 127), 3.f, 2.f, 1.f} * 0.01f;
+#else
+      kx[i] = ATTN_LD4(kp);
+#ifdef RUART_ABL_ATTN_HEADMAJOR
+      kx[i] = load4(kp + H);
+      vx[i] = load4(kp + H + ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64));
+#else
+      vx[i] = ATTN_LD4(kp + H);
+#endif
+#endif
+    }
+    if (tid < 64) {
+      const bool in = tid < tn;
+      ls_v = in ? tok_lo[kt + tid] : -1;
+      bs_v = (in && key_bias) ? key_bias[kt + tid] : 0.f;
+    }
+  };
+  auto load_q = [&](int h) {
+#ifdef RUART_ABL_ATTN_HEADMAJOR
+    const float* qp = qkv + ((size_t)h * RUART_ABL_ATTN_HEADMAJOR + (qvalid ? tq : q0)) * 64 + g * 8;
+#else
+    const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#ifdef RUART_ABL_ATTN_NOLOADS
+      qx[2 * ks] = (f32x4_t){(float)((size_t)qp & 255), 1.f, 2.f, 3.f} * 0.01f;
+      qx[2 * ks + 1] = (f32x4_t){(float)((size_t)qp & 63), 1.f, 2.f, 3.f} * 0.01f;
+#else
+      qx[2 * ks] = ATTN_LD4(qp + ks * 32);
+      qx[2 * ks + 1] = ATTN_LD4(qp + ks * 32 + 4);
+#endif
+    }
+  };
+  load_q(h0);
+  load_kv(h0, k0, min(64, k1 - k0));
+  frag_t qh[2], ql[2];
+  float m = -1e30f, l = 0.f;
+  f32x4_t o[4];
+
+#ifdef RUART_ABL_ATTN_STAMPS           // diagnostic build: slots 0..5 of steps 0..3 (24 values) + HW_ID in slot 30, XCC_ID in 31
+#define MH_STAMP(i) do { if (g_attn_stamps && threadIdx.x == 0 && j < 4) g_attn_stamps[(size_t)blockIdx.x * 32 + j * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  if (g_attn_stamps && threadIdx.x == 0) {
+    g_attn_stamps[(size_t)blockIdx.x * 32 + 30] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    g_attn_stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    g_attn_stamps[(size_t)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_memrealtime();
+  }
+#else
+#define MH_STAMP(i)
+#endif
+  // a finished head's context rows in their stored form (f16 x 4, e4m3 lo x 4, e4m3 hi x 4 per 16-column group), written one step later
+  f16x4_t pend16[4];
+  unsigned pend_lo[4], pend_hi[4];
+  int pend_h = -1;
+  auto flush_pending = [&]() {
+    if (pend_h >= 0 && qvalid) {
+      const size_t col = (size_t)pend_h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f16x4_t*>(ctx16 + (size_t)tq * ldc + col + dt * 16) = pend16[dt];
+        unsigned char* p8 = ctx8 + (size_t)tq * 2 * ldc + col + dt * 16;
+        *reinterpret_cast<unsigned*>(p8) = pend_lo[dt];
+        *reinterpret_cast<unsigned*>(p8 + H) = pend_hi[dt];
+      }
+    }
+    pend_h = -1;
+  };
+  int hh = 0, t = 0;                       // head within the group, key tile within the window
+  for (int j = 0; j < n_steps; ++j) {
+    MH_STAMP(0);
+#ifdef RUART_ABL_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MH_STAMP(1);
+    const int h = h0 + hh, kt = k0 + t * 64;
+    const int tn = min(64, k1 - kt);
+    const bool last_tile = t == n_tiles - 1;
+    if (t == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) split_f16x8(qx[2 * ks], qx[2 * ks + 1], qh[ks], ql[ks]);
+      m = -1e30f;
+      l = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 16 + i * 4 + prow;
+        if (row >= tn) kx[i] = vx[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};       // rows past the window: zero keys / values
+        f16x4_t kh4, kl4, vh4, vl4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          kh4[e] = (f16_t)kx[i][e];
+          kl4[e] = (f16_t)(kx[i][e] - (float)kh4[e]);
+          vh4[e] = (f16_t)vx[i][e];
+          vl4[e] = (f16_t)(vx[i][e] - (float)vh4[e]);
+        }
+        const int off = row * RS + piece * 8;
+        *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
+        *reinterpret_cast<f16x4_t*>(Kl + off) = kl4;
+        *reinterpret_cast<f16x4_t*>(Vh + off) = vh4;
+        *reinterpret_cast<f16x4_t*>(Vl + off) = vl4;
+      }
+      if (tid < 64) {
+        Ls[tid] = ls_v;
+        Bs[tid] = bs_v;
+      }
+    }
+    flush_pending();                      // the previous head's rows: ahead of the prefetch in the vmcnt queue
+    // the next step's K / V slices: in flight from here on (the registers they land in are free)
+    const int t_n = last_tile ? 0 : t + 1, hh_n = last_tile ? hh + 1 : hh;
+    if (j + 1 < n_steps) {
+      load_kv(h0 + hh_n, k0 + t_n * 64, min(64, k1 - (k0 + t_n * 64)));
+      if (last_tile) load_q(h + 1);       // the next head's Q rows too (qx is free since this head's split)
+    }
+    __syncthreads();
+    MH_STAMP(3);
+
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      sacc[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (it * 16 + fr) * RS + (ks * 32 + g * 8) * 2;
+        const frag_t kfh = *reinterpret_cast<const frag_t*>(Kh + off);
+        const frag_t kfl = *reinterpret_cast<const frag_t*>(Kl + off);
+        sacc[it] = mfma_16x16x32(kfl, qh[ks], sacc[it]);        // small terms first
+        sacc[it] = mfma_16x16x32(kfh, ql[ks], sacc[it]);
+        sacc[it] = mfma_16x16x32(kfh, qh[ks], sacc[it]);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const i32x4_t lk = *reinterpret_cast<const i32x4_t*>(&Ls[it * 16 + g * 4]);
+      if (key_bias) sacc[it] += *reinterpret_cast<const f32x4_t*>(&Bs[it * 16 + g * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[it][r] = lk[r] == lo_tok ? sacc[it][r] : -1e30f;
+    }
+    frag_t ph[2];
+    flash_softmax_step<f16_t>(sacc, m, l, o, ph);             // sacc now holds the fp32 probabilities, ph their f16 roundings
+    frag_t pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        pl[s2][jj] = (f16_t)(sacc[2 * s2][jj] - (float)ph[s2][jj]);
+        pl[s2][4 + jj] = (f16_t)(sacc[2 * s2 + 1][jj] - (float)ph[s2][4 + jj]);
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int off = (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
+        union { struct { tr16x4_t a, b; } s; frag_t f; } uh, ul;
+        uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off));
+        uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off + 16 * RS));
+        ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off));
+        ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off + 16 * RS));
+        o[dt] = mfma_16x16x32(ul.f, ph[s2], o[dt]);
+        o[dt] = mfma_16x16x32(uh.f, pl[s2], o[dt]);
+        o[dt] = mfma_16x16x32(uh.f, ph[s2], o[dt]);
+      }
+    if (last_tile) {                      // (uniform) convert now, write at the next step
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const f32x4_t v = o[dt] * inv;
+        const f16x4_t hv = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+        pend16[dt] = hv;
+        const f32x4_t lo = {v[0] - (float)hv[0], v[1] - (float)hv[1], v[2] - (float)hv[2], v[3] - (float)hv[3]};
+        pend_lo[dt] = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
+        pend_hi[dt] = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
+      }
+#ifdef RUART_ABL_ATTN_NOSTORE
+      pend_h = l == 12345.678f ? h : -1;
+#else
+      pend_h = h;
+#endif
+    }
+    __syncthreads();                      // every wave is done reading this step's images
+    MH_STAMP(5);
+    t = t_n;
+    hh = hh_n;
+  }
+  flush_pending();
 }
 
 template <typename T16>
@@ -799,8 +1124,8 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
         const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-          v[j][0][i] = load4(base + col[i]);
-          if (TWO) v[j][TWO ? 1 : 0][i] = load4(base + (size_t)ldl + col[i]);
+          v[j][0][i] = load4_stream(base + col[i]);
+          if (TWO) v[j][TWO ? 1 : 0][i] = load4_stream(base + (size_t)ldl + col[i]);
         }
       }
 #pragma unroll
@@ -812,7 +1137,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(const T* __restrict__ lay
           const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
           for (int p = 2; p < n; ++p)
 #pragma unroll
-            for (int i = 0; i < NG; ++i) acc[i] += load4(base + (size_t)p * ldl + col[i]) * wgt[j];
+            for (int i = 0; i < NG; ++i) acc[i] += load4_stream(base + (size_t)p * ldl + col[i]) * wgt[j];
         }
       }
     }
@@ -863,15 +1188,15 @@ __global__ __launch_bounds__(256) void pool_mix_cols_kernel(const T* __restrict_
         const int l = min(lb + j, NL - 1);
         wgt[j] = (lb + j < NL) ? wl[l] * inv : 0.f;
         const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl + col;
-        v[j][0] = load4(base);
-        if (TWO) v[j][TWO ? 1 : 0] = load4(base + (size_t)ldl);
+        v[j][0] = load4_stream(base);
+        if (TWO) v[j][TWO ? 1 : 0] = load4_stream(base + (size_t)ldl);
       }
 #pragma unroll
       for (int j = 0; j < LB; ++j) acc += (TWO ? v[j][0] + v[j][TWO ? 1 : 0] : v[j][0]) * wgt[j];
       if (TWO && n > 2) {
         for (int j = 0; j < LB && lb + j < NL; ++j) {
           const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl + col;
-          for (int p = 2; p < n; ++p) acc += load4(base + (size_t)p * ldl) * wgt[j];
+          for (int p = 2; p < n; ++p) acc += load4_stream(base + (size_t)p * ldl) * wgt[j];
         }
       }
     }
@@ -915,8 +1240,8 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__
         const T* base = layers + (size_t)l * layer_stride + (size_t)(l == NL - 1 ? st_last : st) * ldl;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-          v[j][0][i] = load4(base + col[i]);
-          if (TWO) v[j][TWO ? 1 : 0][i] = load4(base + (size_t)ldl + col[i]);
+          v[j][0][i] = load4_stream(base + col[i]);
+          if (TWO) v[j][TWO ? 1 : 0][i] = load4_stream(base + (size_t)ldl + col[i]);
         }
       }
 #pragma unroll
@@ -928,7 +1253,7 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(const T* __restrict__
           const T* base = layers + (size_t)(lb + j) * layer_stride + (size_t)(lb + j == NL - 1 ? st_last : st) * ldl;
           for (int p = 2; p < n; ++p)
 #pragma unroll
-            for (int i = 0; i < NG; ++i) s4 += load4(base + (size_t)p * ldl + col[i]) * gv[i];
+            for (int i = 0; i < NG; ++i) s4 += load4_stream(base + (size_t)p * ldl + col[i]) * gv[i];
         }
         const float d = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) * inv;
         if (lane == 0 && lb + j < l1) partial[(size_t)w * NL + lb + j] = d;
@@ -974,6 +1299,9 @@ extern "C" int ruart_rows_layernorm(const float* x, int ldx, const float* gamma,
 }
 
 static const bool g_attn_split_valu = getenv("RUART_ATTN_SPLIT_VALU") != nullptr;
+// heads per workgroup of the split attention kernel: 2 = the multi-head form with the next head's loads in flight (bit-identical to the
+// one-head kernel; on the bench stream 124 against 131 us per call with the non-temporal loads, equal inside a whole pass - DESIGN.md section 5)
+static int g_attn_split_hpg = getenv("RUART_ATTN_SPLIT_HEADS") ? atoi(getenv("RUART_ATTN_SPLIT_HEADS")) : 2;
 
 extern "C" int ruart_rows_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* out32,
                                           void* out16, void* out8, int ldo, int rows, int H, void* stream) {
@@ -1004,10 +1332,35 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
   if (g_attn_split_valu)       // diagnostic: the fp32 VALU kernel (lane = query) instead of the split-f16 MFMA kernel
     hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr,
                        ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
-  else
-    hipLaunchKernelGGL(attn_flash_split_kernel, attn_grid(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16,
-                       (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
+  else {
+    // heads per workgroup: g_attn_split_hpg (ruart_bert_attention_split_set_heads; 0 = the one-head kernel), lowered to a divisor of n_heads
+    int hpg = g_attn_split_hpg;
+    while (hpg > 1 && n_heads % hpg) --hpg;
+#define RUART_MH(N) hipLaunchKernelGGL(attn_flash_split_mh_kernel<N>, dim3((unsigned)n_blocks * (unsigned)(n_heads / N)), dim3(256), 0,  \
+                                       (hipStream_t)stream, qkv, ld, (f16_t*)ctx16, (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, \
+                                       tok_lo, key_bias)
+    switch (hpg) {
+      case 2: RUART_MH(2); break;
+      case 3: RUART_MH(3); break;
+      case 4: RUART_MH(4); break;
+      case 6: RUART_MH(6); break;
+      case 8: RUART_MH(8); break;
+      case 12: RUART_MH(12); break;
+      case 16: RUART_MH(16); break;
+      default:
+        hipLaunchKernelGGL(attn_flash_split_kernel, attn_grid(n_blocks, n_heads), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16,
+                           (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias);
+    }
+#undef RUART_MH
+  }
   RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_attention_split_set_heads(int heads_per_workgroup) {
+  RUART_ENTRY();
+  if (heads_per_workgroup < 0 || heads_per_workgroup > 16) return (int)hipErrorInvalidValue;
+  g_attn_split_hpg = heads_per_workgroup;
   return 0;
 }
 

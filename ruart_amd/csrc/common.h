@@ -70,6 +70,20 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ---- typed 4-element row access (float or bf16 storage, fp32 math) ----
 __device__ __forceinline__ f32x4_t load4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+// Once-read streams (the encoder's fp32 Q / K / V rows in the attention kernel, the twelve layer matrices in sub-word pooling): the
+// non-temporal cache policy.  With the default policy every line of such a stream is allocated in L2 and the Infinity Cache and pushes
+// out lines other kernels still want; measured on attn_flash_split_kernel: 155 -> 124-131 us per call (profiles/r05_attn_split_nt.log).
+// RUART_NT_STREAM=0 (a -D flag) restores the default policy everywhere (A/B builds).
+#ifndef RUART_NT_STREAM
+#define RUART_NT_STREAM 1
+#endif
+__device__ __forceinline__ f32x4_t load4_stream(const float* p) {
+#if RUART_NT_STREAM
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+#else
+  return load4(p);
+#endif
+}
 __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
   bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
   f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
@@ -79,6 +93,24 @@ __device__ __forceinline__ f32x4_t load4(const f16_t* p) {
   f16x4_t v = *reinterpret_cast<const f16x4_t*>(p);
   f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return r;
+}
+__device__ __forceinline__ f32x4_t load4_stream(const bf16_t* p) {
+#if RUART_NT_STREAM
+  bf16x4_t v = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_t*>(p));
+  f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+#else
+  return load4(p);
+#endif
+}
+__device__ __forceinline__ f32x4_t load4_stream(const f16_t* p) {
+#if RUART_NT_STREAM
+  f16x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f16x4_t*>(p));
+  f32x4_t r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+#else
+  return load4(p);
+#endif
 }
 __device__ __forceinline__ void store4(f16_t* p, f32x4_t v) {
   f16x4_t r = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};

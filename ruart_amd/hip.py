@@ -69,6 +69,7 @@ _SIGNATURES = {
     "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_embed_ln_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_attention_split": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ruart_bert_attention_split_set_heads": (_I, [_I]),
     "ruart_gemm_16_nt_splitk": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16_nt_gelu2": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_gemm_16_nt_gelu_bwd_ws_floats": (c_size_t, [_I, _I]),

@@ -906,3 +906,56 @@ def test_priority_streams():
     assert float(y) == float((1 << 20) * ((1 << 20) - 1))
     for st in (hi, no, lo):
         hip.destroy_stream(st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("long_rows", [False, True])
+def test_attention_split_heads_per_workgroup_bit_identical(long_rows):
+    """ruart_bert_attention_split (fp16c mode: fp32 Q/K/V rows in, f16 + 2 x e4m3 context rows out): the multi-head workgroup forms
+    (next head's loads in flight, context rows written one step late) produce the one-head kernel's bits for every heads-per-workgroup
+    setting - ragged windows of whole short sequences, and 64-query blocks of long sequences (several key tiles) - and the one-head
+    kernel itself agrees with a float64 softmax(QK^T)V on the window's keys."""
+    from ruart_amd.bert import PackedTokens
+    lib = hip.load()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    lens = [3, 5, 8, 1, 64, 17, 2, 9, 33, 4, 6, 7, 12, 30, 5, 5] * 6
+    if long_rows:
+        lens = lens[:20] + [200, 130, 65, 512]
+    L = max(lens)
+    ids = torch.zeros(len(lens), L, dtype=torch.int64)
+    mask = torch.zeros(len(lens), L, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        ids[i, :n] = torch.randint(5, 1000, (n,), generator=g)
+        mask[i, :n] = True
+    p = PackedTokens([(ids, mask)], d, mfma_long=False)          # long rows as 64-query blocks of the short-window kernel
+    H, NH = 768, 12
+    T, Tp, nb = p.T, p.Tp, p.n_blocks
+    qkv = (torch.randn(Tp, 3 * H, generator=g) * 1.2).to(d)
+    outs = {}
+    try:
+        for hpg in (0, 2, 3, 4, 6, 12):
+            hip.check(lib.ruart_bert_attention_split_set_heads(hpg), "set_heads")
+            c16 = torch.zeros(Tp, H, dtype=torch.float16, device=d)
+            c8 = torch.zeros(Tp, 2 * H, dtype=torch.uint8, device=d)
+            hip.check(lib.ruart_bert_attention_split(hip.ptr(qkv), 3 * H, hip.ptr(c16), hip.ptr(c8), H, H, NH, nb, hip.ptr(p.blk[0]), hip.ptr(p.blk[1]),
+                                                     hip.ptr(p.blk[2]), hip.ptr(p.blk[3]), hip.ptr(p.tok_lo), hip.ptr(p.tok_hi), None, hip.stream_ptr()),
+                      "ruart_bert_attention_split")
+            torch.cuda.synchronize()
+            outs[hpg] = (c16[:T].cpu(), c8[:T].cpu())
+    finally:
+        hip.check(lib.ruart_bert_attention_split_set_heads(2), "set_heads")
+    for hpg, (a16, a8) in outs.items():
+        assert torch.equal(a16.view(torch.int16), outs[0][0].view(torch.int16)), hpg
+        assert torch.equal(a8, outs[0][1]), hpg
+    # the one-head kernel against float64 (Q is stored pre-scaled: the kernel applies no 1/sqrt(d))
+    x = qkv[:T].double().cpu()
+    lo, hi = p.tok_lo.cpu().numpy(), p.tok_hi.cpu().numpy()
+    ref = torch.zeros(T, H, dtype=torch.float64)
+    for s0 in sorted(set(lo.tolist())):
+        s1 = int(hi[s0])
+        for h in range(NH):
+            q, k, v = (x[s0:s1, i * H + h * 64:i * H + (h + 1) * 64] for i in range(3))
+            ref[s0:s1, h * 64:(h + 1) * 64] = torch.softmax(q @ k.t(), 1) @ v
+    err = (outs[0][0].double() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err          # f16 storage of the context rows
