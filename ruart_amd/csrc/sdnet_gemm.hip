@@ -544,7 +544,10 @@ struct Plan { int tm, tiles, splitk; };
 // small output and a long reduction (weight gradients) are split along K, at least 4 steps of 32 per slice.
 Plan make_plan(int M, int N, int K, int amode, int bmode) {
   const int ksteps = (K + XBK - 1) / XBK;
-  static const int fill = [] { const char* e = getenv("RUART_X3_FILL"); return e ? atoi(e) : 448; }();        // (experiments)
+  // workgroups a split-K plan aims at.  128 since round 5 (448 before: "two small workgroups per CU"): beside the encoder pass what a trunk
+  // product costs the step is the CUs it occupies, not its own latency - 23.58-23.64 ms per step at 128 / 224 against 23.85 at 448, 24.2 at 64,
+  // 28.1 without any split (the trunk's chain becomes the longer one); profiles/r05_knob_sweep.log.  RUART_X3_FILL overrides (experiments).
+  static const int fill = [] { const char* e = getenv("RUART_X3_FILL"); return e ? atoi(e) : 128; }();
   static const int nosplit = [] { const char* e = getenv("RUART_X3_NOSPLIT_TILES"); return e ? atoi(e) : 160; }();
   auto split_for = [&](int tiles) {
     if (tiles >= nosplit || ksteps < 16) return 1;

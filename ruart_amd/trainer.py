@@ -554,6 +554,14 @@ class SDNetTrainer(BaseTrainer):
             train_loader = self._loader(train_data, sampler, workers=self.opt.get("num_worker", 0))
             val_loader = VQA_Dataset(self._records("val"), self.opt)
         it = iter(train_loader)
+        # Everything alive at this point - the model, the optimizer state, the dataset records with the reference's nested python lists -
+        # stays alive for the whole run: move it out of the garbage collector's sight (a permanent generation), or every full collection
+        # walks all of it and stops the host for ~45 ms, i.e. one 70 ms step in ~25 (measured).  The
+        # collector keeps running over what the steps themselves create.  opt['ruart_gc_freeze'] = False leaves the interpreter alone.
+        if self.opt.get("ruart_gc_freeze", True):
+            import gc
+            gc.collect()
+            gc.freeze()
 
         def stage():                                                  # the next batch of the loader, shipped to the device (or None)
             b = next(it, None)
