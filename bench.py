@@ -301,32 +301,54 @@ def _dist(ms):
             "max": round(v[-1], 3), "first": round(ms[0], 3)}
 
 
-def _timeline(b, e, f):
-    """Medians over the steps of one profiled pass of the timed schedule (records of ruart_prof_timeline: encoder GEMM launches
-    with flops > 0, step-stream marks with flops = -tag), every time in ms from the step's own start (mark 1, forward start on the
-    step stream).  The encoder pass launched inside step t serves batch t+1: its last GEMM ends step t's device work."""
+def _steps_of(b, f):
     marks = [(float(t), int(-fl)) for t, fl in zip(b, f) if fl < 0]
     starts = [t for t, tag in marks if tag == 1]
+    return marks, starts
+
+
+def _timeline(b, e, f):
+    """Medians over the steps of one marks-only pass of the timed schedule (records of ruart_prof_timeline: markers with flops = -tag),
+    every time in ms from the step's own start (mark 1: the step stream reaches the forward, i.e. the previous encoder pass has
+    ended).  The encoder pass launched inside step t serves batch t+1: its end ends step t's device work."""
+    marks, starts = _steps_of(b, f)
     rows = []
     for k in range(1, len(starts) - 1):                  # (the first step of the pass refills the pipeline after a sync)
         s0, s1 = starts[k], starts[k + 1]
         m = {tag: t - s0 for t, tag in marks if s0 <= t < s1}
-        g = [(bb - s0, ee - s0) for bb, ee, fl in zip(b, e, f) if fl > 0 and s0 <= bb < s1]
-        if not g or 2 not in m or 3 not in m or 4 not in m:
+        if not all(t in m for t in (2, 3, 4, 5, 6)):
+            continue
+        rows.append((s1 - s0, m[2], m[3], m[4], m[5], m[6]))
+    if not rows:
+        return {}
+    med = [float(np.median([r[i] for r in rows])) for i in range(6)]
+    return {"steps": len(rows), "step": round(med[0], 3), "step_max": round(max(r[0] for r in rows), 3),
+            "trunk_forward_end": round(med[1], 3), "trunk_backward_end": round(med[2], 3), "optimizer_end": round(med[3], 3),
+            "encoder_pass_start": round(med[4], 3), "encoder_pass_end": round(med[5], 3),
+            "what": "medians over the steps of a separate pass of the timed schedule with six hipEvents per step (step stream: forward "
+                    "start / forward end / backward end / optimizer end; encoder stream: before / after the pass launched in the step, "
+                    "which encodes batch t+1); ms from the step's forward start"}
+
+
+def _gemm_split(b, e, f):
+    """From the GEMM-bracketed pass: mean launch-to-finish time of the encoder GEMMs that start while the trunk is on the device and of
+    those that start after its optimizer step, medians over the steps."""
+    marks, starts = _steps_of(b, f)
+    rows = []
+    for k in range(1, len(starts) - 1):
+        s0, s1 = starts[k], starts[k + 1]
+        m = {tag: t for t, tag in marks if s0 <= t < s1}
+        g = [(bb, ee) for bb, ee, fl in zip(b, e, f) if fl > 0 and s0 <= bb < s1]
+        if not g or 4 not in m:
             continue
         beside = [ee - bb for bb, ee in g if bb < m[4]]
         after = [ee - bb for bb, ee in g if bb >= m[4]]
-        rows.append((s1 - s0, m[2], m[3], m[4], g[0][0], g[-1][1], 1e3 * float(np.mean(beside)) if beside else float("nan"),
-                     1e3 * float(np.mean(after)) if after else float("nan"), len(after)))
+        rows.append((1e3 * float(np.mean(beside)) if beside else float("nan"), 1e3 * float(np.mean(after)) if after else float("nan"), len(after), s1 - s0))
     if not rows:
         return {}
-    med = [float(np.nanmedian([r[i] for r in rows])) for i in range(9)]
-    return {"steps": len(rows), "step": round(med[0], 3), "step_max": round(max(r[0] for r in rows), 3),
-            "trunk_forward_end": round(med[1], 3), "trunk_backward_end": round(med[2], 3),
-            "optimizer_end": round(med[3], 3), "encoder_first_gemm_start": round(med[4], 3), "encoder_last_gemm_end": round(med[5], 3),
-            "gemm_us_beside_trunk": round(med[6], 1), "gemm_us_after_trunk": round(med[7], 1), "gemms_after_trunk": int(med[8]),
-            "what": "medians over the steps of a separate pass of the timed schedule with hipEvents on the step stream and around "
-                    "every encoder GEMM; ms from the step's forward start; the encoder pass is the one launched in that step (batch t+1)"}
+    return {"beside_trunk": round(float(np.nanmedian([r[0] for r in rows])), 1), "after_trunk": round(float(np.nanmedian([r[1] for r in rows])), 1),
+            "launches_after_trunk": int(np.median([r[2] for r in rows])), "step_ms_of_this_pass": round(float(np.median([r[3] for r in rows])), 3),
+            "note": "the ~100 events per step of this pass stretch the step; timeline_ms is the unperturbed schedule"}
 
 
 def main():
@@ -524,33 +546,44 @@ def main():
     #    with the trunk's kernels, so its launch-to-finish time also contains the trunk's work (roofline.timed_region).
     roof = timeline = None
     if not a.no_roofline and a.precision in GEMM_KERNEL:
-        def gemm_pass(prefetch, timeline=None):
-            """K more steps with a hipEvent pair around every encoder GEMM launch.  ``timeline`` (a dict): also mark the step stream at
-            forward start / forward end / backward end / optimizer end and return every step's device times on one time base."""
+        def profiled_pass(prefetch, mode):
+            """K more steps under the library's event recorder.  mode 1: a hipEvent pair around every encoder GEMM launch (the roofline
+            figures; ~100 events per step, which stretch the pipelined step by 2-3 ms) plus the step-stream marks; mode 2: marks only -
+            step stream at forward start / forward end / backward end / optimizer end, encoder stream before / after the pass that
+            is launched in the step (six events per step: the schedule as it is timed).  Returns the recorder's arrays."""
+            import ruart_amd.bert as bert_mod
             saved = a.no_prefetch
             a.no_prefetch = not prefetch
             net, optim = tr.network, tr.optimizer
-            orig_fwd, orig_cs = net.forward, getattr(optim, "clip_and_step", None)
-            if timeline is not None and orig_cs is not None:
-                def mark(tag):
-                    lib.ruart_prof_mark(tag, hip.stream_ptr(device))
+            orig_fwd, orig_cs, orig_enc = net.forward, getattr(optim, "clip_and_step", None), bert_mod.bert_encode
 
-                def fwd(*x, **k):
-                    mark(1)
-                    out = orig_fwd(*x, **k)
-                    mark(2)
-                    return out
+            def mark(tag):
+                lib.ruart_prof_mark(tag, hip.stream_ptr(device))
 
-                def cs(*x, **k):
-                    mark(3)
-                    out = orig_cs(*x, **k)
-                    mark(4)
-                    return out
+            def fwd(*x, **k):
+                mark(1)
+                out = orig_fwd(*x, **k)
+                mark(2)
+                return out
+
+            def cs(*x, **k):
+                mark(3)
+                out = orig_cs(*x, **k)
+                mark(4)
+                return out
+
+            def enc(*x, **k):
+                mark(5)
+                out = orig_enc(*x, **k)
+                mark(6)
+                return out
+            if orig_cs is not None:
                 net.forward, optim.clip_and_step = fwd, cs
+                bert_mod.bert_encode = enc
             try:
                 step(0)                                                   # settle the pipeline state of this schedule
                 torch.cuda.synchronize()
-                hip.check(lib.ruart_prof_enable(1), "prof_enable")
+                hip.check(lib.ruart_prof_enable(mode), "prof_enable")
                 for i in range(a.steps):
                     step(i + 1)
                 torch.cuda.synchronize()
@@ -560,19 +593,25 @@ def main():
                 lib.ruart_prof_enable(0)
             finally:
                 a.no_prefetch = saved
-                if timeline is not None and orig_cs is not None:
+                bert_mod.bert_encode = orig_enc
+                if orig_cs is not None:
                     del net.forward                       # (instance attributes shadowing the class's methods)
                     del optim.clip_and_step
-            b_, e_, f_ = np.array(b_[:n_.value]), np.array(e_[:n_.value]), np.array(f_[:n_.value])
+            return np.array(b_[:n_.value]), np.array(e_[:n_.value]), np.array(f_[:n_.value])
+
+        def gemm_pass(prefetch, gemm_split=None):
+            b_, e_, f_ = profiled_pass(prefetch, 1)
             g = f_ > 0
-            if timeline is not None:
-                timeline.update(_timeline(b_, e_, f_))
+            if gemm_split is not None:
+                gemm_split.update(_gemm_split(b_, e_, f_))
             return float((e_[g] - b_[g]).sum()), int(g.sum()), float(f_[g].sum())
 
         ms_i, n_i, fl_i = gemm_pass(False)
         pipelined = a.mode == "train" and not a.no_prefetch
-        timeline = {} if (pipelined and not a.no_timeline) else None
-        ms_t, n_t, fl_t = gemm_pass(True, timeline) if pipelined else (ms_i, n_i, fl_i)
+        gsplit = {}
+        ms_t, n_t, fl_t = gemm_pass(True, gsplit) if pipelined else (ms_i, n_i, fl_i)
+        if pipelined and not a.no_timeline:
+            timeline = _timeline(*profiled_pass(True, 2))
         if n_i and n_t:
             ach = fl_i / (ms_i * 1e-3) / 1e12
             ach_t = fl_t / (ms_t * 1e-3) / 1e12
@@ -591,6 +630,8 @@ def main():
                     "alone": {"schedule": "encoder inline (each GEMM alone on the device), same K steps", "achieved": round(ach, 1),
                               "frac": round(ach / PEAK_TFLOPS, 4), "avg_launch_us": round(ms_i * 1e3 / n_i, 2), "launches": n_i},
                     "gemm_share_of_step": round(ms_i / a.steps / (dt / a.steps * 1e3), 3)}
+            if gsplit:
+                roof["timed_gemm_us"] = gsplit
 
     b512 = None
     if rank == 0 and world == 1 and not a.no_bert512 and a.mode == "train" and not a.stress and not a.unlock_bert:

@@ -117,7 +117,8 @@ int ruart_gemm_f32_nt(const float* A, int lda, const float* W, int ldw, const fl
 /* Live timing of the dominant kernel for bench.py's roofline: while enabled, every ruart_gemm_16_nt launch is
  * bracketed by a hipEvent pair on its stream (pool of 8192 launches).  ruart_prof_read synchronises on those events,
  * returns the summed kernel time, launch count and ALGORITHMIC flops (2 * real_rows * N * K), and resets the pool.
- * The only entry points that synchronise or allocate; never call them inside a timed or captured region. */
+ * The only entry points that synchronise or allocate; never call them inside a timed or captured region.
+ * on = 2: only the markers of ruart_prof_mark are recorded, the GEMM launches are left alone (six events per step instead of ~100). */
 int ruart_prof_enable(int on);
 int ruart_prof_read(double* total_ms, long long* launches, double* flops);
 /* Diagnostics on the same record pool: ruart_prof_mark puts a marker (flops = -tag) on any stream; ruart_prof_timeline returns every

@@ -776,6 +776,7 @@ struct ProfRec { hipEvent_t a, b; double flops; };
 std::vector<ProfRec> g_prof_pool;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
+bool g_prof_marks_only = false;      // ruart_prof_enable(2): markers are recorded, the GEMM launches are not bracketed
 }  // namespace
 #ifdef RUART_P8_STAMPS
 unsigned long long* g_p8_stamps = nullptr;   // diagnostic build only: 4 x s_memrealtime per workgroup
@@ -815,13 +816,14 @@ extern "C" int ruart_prof_enable(int on) {
     }
   }
   g_prof_on = on != 0;
+  g_prof_marks_only = on == 2;
   g_prof_used = 0;
   return 0;
 }
 
 // shared with gemm_corr.hip: bracket one launch of an encoder GEMM (NULL when profiling is off)
 void* ruart_prof_begin_(hipStream_t s, int M, int N, int K) {
-  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return nullptr;
+  if (!g_prof_on || g_prof_marks_only || g_prof_used >= g_prof_pool.size()) return nullptr;
   ProfRec* rec = &g_prof_pool[g_prof_used++];
   const int rows = (ruart_prof_real_rows > 0 && ruart_prof_real_rows <= M) ? ruart_prof_real_rows : M;
   rec->flops = 2.0 * rows * (double)N * K;

@@ -67,6 +67,11 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
 // Epilogue of one 256 x 256 tile through LDS, eight rows per pass (as gemm_16_nt_256p8): bias, then per EPI the residual / GELU + split
 // stores.  Shared by the GEMM kernel and by the fix-up kernel of its split tail tiles.  `smem`: >= 8 x 32 x 272 bytes, no longer read as
 // operand tiles by any wave.
+// Cache policy of the epilogue's streams (experiments, round 5): bit 0 the fp32 QKV rows (394 MB per launch, read once by the attention
+// kernel), bit 1 the fp32 pre-LayerNorm rows of the two N = 768 products, bit 3 their residual loads - non-temporal when set.
+#ifndef RUART_NT_EPI
+#define RUART_NT_EPI 0
+#endif
 template <int EPI>
 __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, const float* __restrict__ bias,
                                               const float* __restrict__ R, int ldr, void* __restrict__ C, int ldc,
@@ -92,7 +97,9 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
     const int mrow = m0 + wm * 128 + hh * 32 + rrow;
     if (EPI == 1) {
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) res[rr] = load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
+      for (int rr = 0; rr < 8; ++rr)
+        res[rr] = (RUART_NT_EPI & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(R + (size_t)(mrow + rr * 4) * ldr + ncol))
+                                     : load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
@@ -112,6 +119,8 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
 #else
         store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
 #endif
+      else if ((EPI == 0 && (RUART_NT_EPI & 1)) || (EPI == 1 && (RUART_NT_EPI & 2)))
+        __builtin_nontemporal_store(v[rr], reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(C) + row * ldc + ncol));
       else
         store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
     }
