@@ -324,6 +324,9 @@ int ruart_attn_fwd(const float* pa, const float* pk, const float* v, const unsig
 int ruart_attn_bwd(const float* pa, const float* pk, const float* v, const float* probs, const float* grad_out, const float* diag,
                    int diag_len, int relu, float* grad_pa, float* grad_pk, float* grad_v, float* grad_diag_partial,
                    float* ds_ws /* (B,L1,L2) scratch */, int B, int L1, int L2, int h, int D3, void* stream);
+/* ruart_attn_fwd / _bwd kernel form: 1 (default) = operand chunks register-prefetched under the previous chunk's MFMAs (key panels of up
+ * to 128 rows), 0 = the forms of rounds 1-4.  Bit-identical results. */
+int ruart_attn_set_prefetch(int on);
 /* The same pair with a multiplier on the probabilities, for attention-probability dropout (Models/Bert/modeling.py:244-246):
  * out = (P * prob_scale) . v with prob_scale (B, L1, L2) fp32 holding 0 or 1/(1-p) (NULL: plain call); the saved `probs` are the
  * pre-dropout P, which is what the softmax backward needs; the backward takes the same prob_scale. */

@@ -15,6 +15,7 @@
 //   B-type reads  [(4*kk + (lane>>4)) * ld + (lane&15)] want ld % 32 == 16.
 // Backward: kernel A per (batch, 16 query rows): dP = gO . v^T, dS = P * (dP - rowsum(dP * P)), grad_a = dS . k;
 // kernel B per (batch, 16 key rows): grad_k = dS^T . a, grad_v = P^T . gO.  No atomics, deterministic.
+#include <cstdlib>
 #include "common.h"
 #include "ruart_hip.h"
 
@@ -351,6 +352,335 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: the three kernels above with their operand chunks REGISTER-PREFETCHED.  The forms above stage a 64-wide chunk (global loads
+// -> wait -> LDS), synchronise, multiply, synchronise - a workgroup's ~8 chunks are ~8 exposed L2 / HBM round trips and the kernels ran
+// at 13-15 % of the HBM rate for 41-45 us (profiles/r04_pmc_hbm_per_kernel.csv).  Here a chunk's loads are issued right after the
+// previous chunk's registers have gone to LDS, i.e. they fly under that chunk's MFMAs (and the first chunk of a kernel's NEXT product
+// under the softmax / dS arithmetic); every load is unconditional (clamped addresses, validity bits applied at the LDS store), and the
+// arithmetic - operand values, MFMA order, reductions - is the old kernels' exactly: bit-identical outputs (tested).
+// A panel of nr_pad x 64 elements needs nr_pad / 4 registers per thread: instantiated for key counts up to 48 / 64 / 112 / 128; longer
+// key panels take the forms above.
+template <int U, bool DIAG = false>
+struct Panel {
+  float v[U];
+  float dv[DIAG ? U : 1];
+  unsigned ok;
+  // rows [r0, r0 + nr_pad) x cols [c0, c0 + CH) of a row-major (rows x cols, ld) matrix; nr_pad * CH <= U * 256
+  __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int nr_pad, int r0, int rows, int c0, int cols,
+                                       const float* __restrict__ diag = nullptr, int diag_len = 0) {
+    ok = 0;
+    const int total = nr_pad * CH;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = (int)threadIdx.x + u * 256;
+      const int r = e / CH, c = e % CH;
+      const int gr = r0 + r, gc = c0 + c;
+      if (e < total && gr < rows && gc < cols) ok |= 1u << u;
+      v[u] = src[(size_t)min(gr, rows - 1) * ld + min(gc, cols - 1)];
+      if (DIAG) dv[u] = diag_len > 1 ? diag[min(gc, cols - 1)] : (diag_len == 1 ? diag[0] : 1.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int ldd, int nr_pad, int relu) const {
+    const int total = nr_pad * CH;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = (int)threadIdx.x + u * 256;
+      float x = v[u];
+      if (relu) x = fmaxf(x, 0.f);
+      x *= DIAG ? dv[u] : 1.f;
+      if (e < total) dst[(e / CH) * ldd + (e % CH)] = ((ok >> u) & 1u) ? x : 0.f;
+    }
+  }
+};
+
+template <int UK>
+__global__ __launch_bounds__(256) void attn_fwd_pf_kernel(const float* __restrict__ a, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ out, float* __restrict__ probs, int L1, int L2, int h,
+                                                          int D3, int* __restrict__ nan_flag, int relu, const float* __restrict__ diag,
+                                                          int diag_len, const float* __restrict__ pscale) {
+  const int b = blockIdx.y, i0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
+  float* a_s = dsm;                       // [16][LDA_]
+  float* S_s = a_s + 16 * LDA_;           // [16][ldS]
+  float* kv_s = S_s + 16 * ldS;           // [L2p][LDB_]  (keys use stride LDA_, values LDB_)
+  const float* ab = a + (size_t)b * L1 * h;
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  const int ntile = L2p / 16;
+
+  Panel<4, true> pa;
+  Panel<UK> pk;
+  pa.load(ab, h, 16, i0, L1, 0, h, diag, diag_len);
+  pk.load(kb, h, L2p, 0, L2, 0, h);
+  f32x4_t acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < h; c0 += CH) {
+    __syncthreads();
+    pa.store(a_s, LDA_, 16, relu);
+    pk.store(kv_s, LDA_, L2p, relu);
+    {                                       // the next chunk - or the first chunk of the value panel - in flight under the MFMAs
+      const bool more = c0 + CH < h;
+      pa.load(ab, h, 16, i0, L1, more ? c0 + CH : 0, h, diag, diag_len);
+      pk.load(more ? kb : vb, more ? h : D3, L2p, 0, L2, more ? c0 + CH : 0, more ? h : D3);
+    }
+    __syncthreads();
+    const int kc = min(CH, (h - c0 + 3) & ~3);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int jt = wave + 4 * t;
+      if (jt < ntile) acc[t] = mma16(a_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S_s[((lane >> 4) * 4 + r) * ldS + jt * 16 + (lane & 15)] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const unsigned char* mb = mask + (size_t)b * L2;
+    float* Sr = S_s + row * ldS;
+    float mx = -INFINITY;
+    for (int j = c; j < L2; j += 16) {
+      const float s = mb[j] ? Sr[j] : -INFINITY;
+      Sr[j] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = c; j < L2; j += 16) {
+      const float e = expf(Sr[j] - mx);
+      Sr[j] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    const bool live = (i0 + row) < L1;
+    bool bad = false;
+    for (int j = c; j < L2p; j += 16) {
+      const float p = (j < L2) ? Sr[j] * inv : 0.f;
+      const float ps = (pscale && live && j < L2) ? pscale[((size_t)b * L1 + i0 + row) * L2 + j] : 1.f;
+      Sr[j] = live ? p * ps : 0.f;
+      bad |= live && !(p == p);
+      if (probs && live && j < L2) probs[((size_t)b * L1 + i0 + row) * L2 + j] = p;
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+  }
+  for (int d0 = 0; d0 < D3; d0 += CH) {
+    __syncthreads();
+    pk.store(kv_s, LDB_, L2p, 0);
+    pk.load(vb, D3, L2p, 0, L2, d0 + CH < D3 ? d0 + CH : 0, D3);
+    __syncthreads();
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    o = mma16(S_s, ldS, kv_s + wave * 16, LDB_, 1, L2p, o);
+    const int d = d0 + wave * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + (lane >> 4) * 4 + r;
+      if (i < L1 && d < D3) out[((size_t)b * L1 + i) * D3 + d] = o[r];
+    }
+  }
+}
+
+template <int UK>
+__global__ __launch_bounds__(256) void attn_bwd_q_pf_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ probs, const float* __restrict__ gout,
+                                                            float* __restrict__ grad_a, float* __restrict__ dS, int L1, int L2, int h,
+                                                            int D3, const float* __restrict__ pa_, int relu,
+                                                            const float* __restrict__ diag, int diag_len,
+                                                            float* __restrict__ grad_diag, const float* __restrict__ pscale) {
+  const int b = blockIdx.y, i0 = blockIdx.x * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int L2p = (L2 + 15) & ~15, ldS = lds_probs_stride(L2p);
+  float* g_s = dsm;                       // [16][LDA_]   grad_out chunk
+  float* S_s = g_s + 16 * LDA_;           // [16][ldS]    dP then dS
+  float* kv_s = S_s + 16 * ldS;           // [L2p][LDB_]
+  const float* kb = k + (size_t)b * L2 * h;
+  const float* vb = v + (size_t)b * L2 * D3;
+  const float* gb = gout + (size_t)b * L1 * D3;
+  const int ntile = L2p / 16;
+
+  Panel<4> pg;
+  Panel<UK> pk;
+  pg.load(gb, D3, 16, i0, L1, 0, D3);
+  pk.load(vb, D3, L2p, 0, L2, 0, D3);
+  f32x4_t acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < D3; c0 += CH) {     // dP = gO . v^T
+    __syncthreads();
+    pg.store(g_s, LDA_, 16, 0);
+    pk.store(kv_s, LDA_, L2p, 0);
+    {
+      const bool more = c0 + CH < D3;       // next chunk, or the first key chunk of grad_a = dS . k
+      pg.load(gb, D3, 16, i0, L1, more ? c0 + CH : 0, D3);
+      pk.load(more ? vb : kb, more ? D3 : h, L2p, 0, L2, more ? c0 + CH : 0, more ? D3 : h);
+    }
+    __syncthreads();
+    const int kc = min(CH, (D3 - c0 + 3) & ~3);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int jt = wave + 4 * t;
+      if (jt < ntile) acc[t] = mma16(g_s, LDA_, kv_s + jt * 16 * LDA_, 1, LDA_, kc, acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S_s[((lane >> 4) * 4 + r) * ldS + jt * 16 + (lane & 15)] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const bool live = (i0 + row) < L1;
+    const float* Pr = probs + ((size_t)b * L1 + (live ? i0 + row : 0)) * L2;
+    float* Sr = S_s + row * ldS;
+    float dot = 0.f;
+    if (pscale && live) {
+      const float* Mr = pscale + ((size_t)b * L1 + i0 + row) * L2;
+      for (int j = c; j < L2; j += 16) Sr[j] *= Mr[j];
+    }
+    for (int j = c; j < L2; j += 16) dot += Sr[j] * Pr[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    for (int j = c; j < L2p; j += 16) {
+      float d = 0.f;
+      if (live && j < L2) {
+        const float p = Pr[j];
+        d = p * (Sr[j] - dot);
+        dS[((size_t)b * L1 + i0 + row) * L2 + j] = d;
+      }
+      Sr[j] = d;
+    }
+  }
+  for (int d0 = 0; d0 < h; d0 += CH) {      // grad_a = dS . k
+    __syncthreads();
+    pk.store(kv_s, LDB_, L2p, relu);
+    pk.load(kb, h, L2p, 0, L2, d0 + CH < h ? d0 + CH : 0, h);
+    __syncthreads();
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    o = mma16(S_s, ldS, kv_s + wave * 16, LDB_, 1, L2p, o);
+    const int d = d0 + wave * 16 + (lane & 15);
+    float gd = 0.f;
+    const float dsc = (d < h) ? (diag_len == 1 ? diag[0] : (diag_len > 1 ? diag[d] : 1.f)) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + (lane >> 4) * 4 + r;
+      if (i < L1 && d < h) {
+        const size_t at = ((size_t)b * L1 + i) * h + d;
+        float g = o[r];
+        if (pa_) {
+          const float pv = pa_[at];
+          gd += g * (relu ? fmaxf(pv, 0.f) : pv);
+          g = (relu && pv <= 0.f) ? 0.f : g * dsc;
+        }
+        grad_a[at] = g;
+      }
+    }
+    if (grad_diag) {
+      gd += __shfl_xor(gd, 16, 64);
+      gd += __shfl_xor(gd, 32, 64);
+      if ((lane >> 4) == 0 && d < h) grad_diag[((size_t)b * gridDim.x + blockIdx.x) * h + d] = gd;
+    }
+  }
+}
+
+// backward B with prefetch: the (n0, r0) chunk pairs of a product in one flattened walk, the next pair's operands in flight under this
+// pair's MFMAs.  X^T tile: 16 source columns x 64 rows (4 elements per thread, optionally times `xmul`), Y chunk: 64 x 64 (16 per thread).
+struct PanelT16 {
+  float v[4], m[4];
+  unsigned ok;
+  __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int r0, int rows, int c0, int cols, const float* __restrict__ mul) {
+    ok = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = (int)threadIdx.x + u * 256;
+      const int c = e & 15, r = e >> 4;
+      const int gr = r0 + r, gc = c0 + c;
+      if (gr < rows && gc < cols) ok |= 1u << u;
+      const size_t at = (size_t)min(gr, rows - 1) * ld + min(gc, cols - 1);
+      v[u] = src[at];
+      m[u] = mul ? mul[at] : 1.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int ldd) const {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = (int)threadIdx.x + u * 256;
+      dst[(e & 15) * ldd + (e >> 4)] = ((ok >> u) & 1u) ? v[u] * m[u] : 0.f;
+    }
+  }
+};
+
+__device__ __forceinline__ void tn_product_pf(const float* X, int L1, int L2, int j0, const float* Y, int N, float* C, float* xt_s,
+                                              float* y_s, Act yact, const float* out_gate, const float* xmul) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nr = (L1 + CH - 1) / CH, nn = (N + CH - 1) / CH, steps = nr * nn;
+  PanelT16 px;
+  Panel<16, true> py;
+  px.load(X, L2, 0, L1, j0, L2, xmul);
+  py.load(Y, N, CH, 0, L1, 0, N, yact.diag, yact.diag_len);
+  f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+  int ri = 0, ni = 0;
+  for (int s = 0; s < steps; ++s) {
+    const int r0 = ri * CH, n0 = ni * CH;
+    __syncthreads();
+    px.store(xt_s, LDA_);
+    py.store(y_s, LDB_, CH, yact.relu);
+    int rn = ri + 1, nx = ni;
+    if (rn == nr) { rn = 0; nx = ni + 1; }
+    if (nx == nn) { rn = 0; nx = 0; }              // (past the end: a clamped re-read of the first pair, never stored)
+    px.load(X, L2, rn * CH, L1, j0, L2, xmul);
+    py.load(Y, N, CH, rn * CH, L1, nx * CH, N, yact.diag, yact.diag_len);
+    __syncthreads();
+    const int kc = min(CH, (L1 - r0 + 3) & ~3);
+    o = mma16(xt_s, LDA_, y_s + wave * 16, LDB_, 1, kc, o);
+    if (ri == nr - 1) {                              // the chunk column is complete
+      const int n = n0 + wave * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + (lane >> 4) * 4 + r;
+        if (j < L2 && n < N) {
+          const size_t at = (size_t)j * N + n;
+          C[at] = (out_gate && out_gate[at] <= 0.f) ? 0.f : o[r];
+        }
+      }
+      o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    ri = rn;
+    ni = nx;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_pf_kernel(const float* __restrict__ a, const float* __restrict__ probs,
+                                                             const float* __restrict__ dS, const float* __restrict__ gout,
+                                                             float* __restrict__ grad_k, float* __restrict__ grad_v, int L1, int L2, int h,
+                                                             int D3, const float* __restrict__ pk, int relu,
+                                                             const float* __restrict__ diag, int diag_len,
+                                                             const float* __restrict__ pscale) {
+  const int b = blockIdx.y, j0 = blockIdx.x * 16;
+  float* xt_s = dsm;                   // [16][LDA_]
+  float* y_s = xt_s + 16 * LDA_;       // [CH][LDB_]
+  const size_t pb = (size_t)b * L1 * L2;
+  tn_product_pf(dS + pb, L1, L2, j0, a + (size_t)b * L1 * h, h, grad_k + (size_t)b * L2 * h, xt_s, y_s, Act{relu, diag, diag_len},
+                (relu && pk) ? pk + (size_t)b * L2 * h : nullptr, nullptr);
+  tn_product_pf(probs + pb, L1, L2, j0, gout + (size_t)b * L1 * D3, D3, grad_v + (size_t)b * L2 * D3, xt_s, y_s, no_act(), nullptr,
+                pscale ? pscale + pb : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Whole-tensor layer norm (Layers.py:167-168): mean / biased variance over ALL n elements, no affine.
 // Two-pass (mean, then centred sum of squares) with fixed-order partials => deterministic.
 // ------------------------------------------------------------------------------------------------
@@ -488,9 +818,13 @@ __global__ __launch_bounds__(256) void wln_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+static bool g_attn_prefetch = !(getenv("RUART_ATTN_PREFETCH") && atoi(getenv("RUART_ATTN_PREFETCH")) == 0);
+template <typename K> static void attn_big_lds(K kern) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 static void attn_allow_big_lds() {
-  static bool done = (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                      hipFuncSetAttribute((const void*)attn_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  static bool done = (attn_big_lds(attn_fwd_kernel), attn_big_lds(attn_bwd_q_kernel), attn_big_lds(attn_fwd_pf_kernel<12>),
+                      attn_big_lds(attn_fwd_pf_kernel<16>), attn_big_lds(attn_fwd_pf_kernel<28>), attn_big_lds(attn_fwd_pf_kernel<32>),
+                      attn_big_lds(attn_bwd_q_pf_kernel<12>), attn_big_lds(attn_bwd_q_pf_kernel<16>), attn_big_lds(attn_bwd_q_pf_kernel<28>),
+                      attn_big_lds(attn_bwd_q_pf_kernel<32>), true);
   (void)done;
 }
 
@@ -639,9 +973,24 @@ extern "C" int ruart_attn_fwd_pscale(const float* a, const float* k, const float
   }
   const dim3 grid(ceil_div(L1, 16), B), block(256);
   attn_allow_big_lds();
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
-                     ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len, prob_scale);
+  const int L2p = (L2 + 15) & ~15;
+#define RUART_AF(U) hipLaunchKernelGGL(attn_fwd_pf_kernel<U>, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, \
+                                       L1, L2, h, D3, ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len, prob_scale)
+  if (!g_attn_prefetch || L2p > 128)
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, attn_lds_bytes(L2), (hipStream_t)stream, a, k, v, mask, out, probs, L1, L2, h, D3,
+                       ruart_nan_flag_ptr, relu, diag_len ? diag : nullptr, diag_len, prob_scale);
+  else if (L2p <= 48) RUART_AF(12);
+  else if (L2p <= 64) RUART_AF(16);
+  else if (L2p <= 112) RUART_AF(28);
+  else RUART_AF(32);
+#undef RUART_AF
   RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_attn_set_prefetch(int on) {
+  RUART_ENTRY();
+  g_attn_prefetch = on != 0;
   return 0;
 }
 
@@ -669,13 +1018,27 @@ extern "C" int ruart_attn_bwd_pscale(const float* a, const float* k, const float
   const bool act = relu || diag_len;
   const float* dg = diag_len ? diag : nullptr;
   attn_allow_big_lds();
-  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
-                     grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,
-                     (diag_len > 1) ? grad_diag : nullptr, prob_scale);
+  const int L2p = (L2 + 15) & ~15;
+#define RUART_AQ(U) hipLaunchKernelGGL(attn_bwd_q_pf_kernel<U>, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, \
+                                       k, v, probs, grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,           \
+                                       (diag_len > 1) ? grad_diag : nullptr, prob_scale)
+  if (!g_attn_prefetch || L2p > 128)
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(ceil_div(L1, 16), B), dim3(256), attn_lds_bytes(L2), (hipStream_t)stream, k, v, probs,
+                       grad_out, grad_a, ds_ws, L1, L2, h, D3, act ? a : nullptr, relu, dg, diag_len,
+                       (diag_len > 1) ? grad_diag : nullptr, prob_scale);
+  else if (L2p <= 48) RUART_AQ(12);
+  else if (L2p <= 64) RUART_AQ(16);
+  else if (L2p <= 112) RUART_AQ(28);
+  else RUART_AQ(32);
+#undef RUART_AQ
   RUART_CHECK_LAUNCH();
   const size_t lds = sizeof(float) * (16 * LDA_ + CH * LDB_);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
-                     grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len, prob_scale);
+  if (g_attn_prefetch)
+    hipLaunchKernelGGL(attn_bwd_kv_pf_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
+                       grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len, prob_scale);
+  else
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(ceil_div(L2, 16), B), dim3(256), lds, (hipStream_t)stream, a, probs, ds_ws, grad_out,
+                       grad_k, grad_v, L1, L2, h, D3, k, relu, dg, diag_len, prob_scale);
   RUART_CHECK_LAUNCH();
   return 0;
 }

@@ -106,6 +106,7 @@ _SIGNATURES = {
     "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),
     "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ruart_attn_set_prefetch": (_I, [_I]),
     "ruart_attn_fwd_pscale": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_attn_bwd_pscale": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_whole_ln_fwd": (_I, [_P, _P, _P, _P, _LL, _F, _P]),

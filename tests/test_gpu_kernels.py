@@ -959,3 +959,46 @@ def test_attention_split_heads_per_workgroup_bit_identical(long_rows):
             ref[s0:s1, h * 64:(h + 1) * 64] = torch.softmax(q @ k.t(), 1) @ v
     err = (outs[0][0].double() - ref).abs().max().item()
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), err          # f16 storage of the context rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 100, 40, 250, 250, "vec"), (64, 36, 40, 250, 250, "vec"), (8, 100, 100, 250, 250, "vec"),
+                                   (4, 224, 40, 300, 300, "one"), (64, 100, 36, 125, 250, "one"), (3, 37, 53, 70, 33, None),
+                                   (2, 17, 128, 64, 64, "vec"), (2, 5, 7, 3, 5, None)])
+def test_sdnet_attention_prefetch_forms_bit_identical(shape):
+    """ruart_attn_fwd / _bwd: the register-prefetched kernels (round 5; next chunk's loads under this chunk's MFMAs) against the staged
+    forms of rounds 1-4 - same bits in the context rows, the probabilities and every gradient, over the step's shapes (deep attention,
+    self attention, pre-align with its scalar diagonal, the 125-wide object / position attention) and ragged odd ones."""
+    from ruart_amd import ops
+    B, L1, L2, h, D3, diag_kind = shape
+    lib = hip.load()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(B, L1, h, generator=g).to(d).requires_grad_(True)
+    k = torch.randn(B, L2, h, generator=g).to(d).requires_grad_(True)
+    v = torch.randn(B, L2, D3, generator=g).to(d).requires_grad_(True)
+    mask = (torch.rand(B, L2, generator=g) > 0.2).to(torch.uint8)
+    mask[:, 0] = 1
+    mask = mask.to(d)
+    diag = None
+    if diag_kind == "vec":
+        diag = torch.randn(1, 1, h, generator=g).to(d).requires_grad_(True)
+    elif diag_kind == "one":
+        diag = torch.full((1, 1, 1), 0.06, device=d)
+    gout = torch.randn(B, L1, D3, generator=g).to(d)
+    res = {}
+    try:
+        for on in (0, 1):
+            hip.check(lib.ruart_attn_set_prefetch(on), "ruart_attn_set_prefetch")
+            for t in (a, k, v, diag):
+                if t is not None:
+                    t.grad = None
+            y = ops.fused_attention(a, k, v, mask, diag=diag, relu=diag is not None)
+            y.backward(gout)
+            torch.cuda.synchronize()
+            res[on] = [y.detach().clone(), a.grad.clone(), k.grad.clone(), v.grad.clone()] + (
+                [diag.grad.clone()] if diag is not None and diag.requires_grad else [])
+    finally:
+        hip.check(lib.ruart_attn_set_prefetch(1), "ruart_attn_set_prefetch")
+    for t0, t1 in zip(res[0], res[1]):
+        assert torch.equal(t0.view(torch.int32), t1.view(torch.int32))

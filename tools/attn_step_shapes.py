@@ -31,16 +31,25 @@ def timeit(f, n=10):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-tot = 0
+from ruart_amd import hip
+FORMS = [int(x) for x in os.environ.get("ATTN_FORMS", "0,1").split(",")]      # ruart_attn_set_prefetch settings to time
+tot = {f: 0.0 for f in FORMS}
 for (sa, sk, sv, hasd, relu), cnt in sorted(calls.items(), key=lambda kv: -kv[1]):
     a = torch.randn(*sa, device=dev, requires_grad=True); k = torch.randn(*sk, device=dev, requires_grad=True)
     v = torch.randn(*sv, device=dev, requires_grad=True); m = torch.ones(sk[0], sk[1], dtype=torch.uint8, device=dev)
     d = torch.randn(sa[2], device=dev, requires_grad=True) if hasd else None
-    tf = timeit(lambda: orig(a.detach(), k.detach(), v.detach(), m, diag=None if d is None else d.detach(), relu=relu))
     out = orig(a, k, v, m, diag=d, relu=relu); g = torch.randn_like(out)
     def fb():
         o = orig(a, k, v, m, diag=d, relu=relu); o.backward(g)
-    tfb = timeit(fb)
-    tot += cnt * tfb
-    print("x%d  a %s k %s v %s diag %s relu %s: fwd %.1f us, fwd+bwd %.1f us" % (cnt, sa, sk, sv, hasd, relu, tf, tfb))
-print("sum fwd+bwd over the step: %.2f ms (standalone, includes host launch gaps)" % (tot / 1e3))
+    line = "x%d  a %s k %s v %s diag %s relu %s:" % (cnt, sa, sk, sv, hasd, relu)
+    for f in FORMS:
+        hip.check(hip.load().ruart_attn_set_prefetch(f), "set_prefetch")
+        tf = timeit(lambda: orig(a.detach(), k.detach(), v.detach(), m, diag=None if d is None else d.detach(), relu=relu))
+        tfb = timeit(fb)
+        tot[f] += cnt * tfb
+        line += "  [form %d] fwd %.1f us, fwd+bwd %.1f us" % (f, tf, tfb)
+    print(line)
+for f in FORMS:
+    print("form %d: sum fwd+bwd over the step: %.2f ms (standalone, includes host launch gaps)" % (f, tot[f] / 1e3))
+hip.check(hip.load().ruart_attn_set_prefetch(1), "set_prefetch")
+tr.close()
