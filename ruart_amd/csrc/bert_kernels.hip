@@ -482,22 +482,58 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const T16* __restric
 // ~0.1 % of the encoder's flops at item lengths of 3-8 pieces, so the 3x MFMA count is free; the kernel is bound by its HBM
 // bytes (9 KB in, 3 KB out per word piece and layer).
 // ---------------------------------------------------------------------------------------------
+// hi = f16(x), lo = f16(x - hi) for two values at a time: one v_cvt_pk_f16_f32 and two v_fma_mix{lo,hi}_f16 (x * 1.0 - hi with the f16
+// operand read straight from the packed register: the difference is exact in fp32, so the single rounding to f16 is the one the C++
+// form (f16)(x - (float)hi) makes - same bits, 1.5 instead of 3.25 VALU instructions per element (hipcc converts every element twice
+// and back for that form).  Round 5: these kernels are bound by their VALU issue slots once the loads are out of the way (section 5 (4)).
+#ifndef RUART_ATTN_MIX
+#define RUART_ATTN_MIX 1
+#endif
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hi2, unsigned& lo2) {
+  typedef f16_t f16x2v __attribute__((ext_vector_type(2)));
+  const f16x2v h = {(f16_t)x0, (f16_t)x1};
+  hi2 = __builtin_bit_cast(unsigned, h);
+#if RUART_ATTN_MIX
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(hi2));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(hi2));
+  lo2 = r;
+#else
+  const f16x2v l = {(f16_t)(x0 - (float)h[0]), (f16_t)(x1 - (float)h[1])};
+  lo2 = __builtin_bit_cast(unsigned, l);
+#endif
+}
+__device__ __forceinline__ void split_f16x4(const f32x4_t a, f16x4_t& hi, f16x4_t& lo) {
+  union { f16x4_t v; unsigned u[2]; } h, l;
+  split2_f16(a[0], a[1], h.u[0], l.u[0]);
+  split2_f16(a[2], a[3], h.u[1], l.u[1]);
+  hi = h.v;
+  lo = l.v;
+}
 __device__ __forceinline__ void split_f16x8(const f32x4_t a, const f32x4_t b, f16x8_t& hi, f16x8_t& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hi[i] = (f16_t)a[i];
-    hi[4 + i] = (f16_t)b[i];
-    lo[i] = (f16_t)(a[i] - (float)hi[i]);
-    lo[4 + i] = (f16_t)(b[i] - (float)hi[4 + i]);
-  }
+  union { f16x8_t v; unsigned u[4]; } h, l;
+  split2_f16(a[0], a[1], h.u[0], l.u[0]);
+  split2_f16(a[2], a[3], h.u[1], l.u[1]);
+  split2_f16(b[0], b[1], h.u[2], l.u[2]);
+  split2_f16(b[2], b[3], h.u[3], l.u[3]);
+  hi = h.v;
+  lo = l.v;
+}
+// lo half of an already rounded pair: lo2 = f16x2(x0 - hi2.lo, x1 - hi2.hi)
+__device__ __forceinline__ unsigned lo2_of(float x0, float x1, unsigned hi2) {
+#if RUART_ATTN_MIX
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(hi2));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(hi2));
+  return r;
+#else
+  typedef f16_t f16x2v __attribute__((ext_vector_type(2)));
+  const f16x2v h = __builtin_bit_cast(f16x2v, hi2);
+  const f16x2v l = {(f16_t)(x0 - (float)h[0]), (f16_t)(x1 - (float)h[1])};
+  return __builtin_bit_cast(unsigned, l);
+#endif
 }
 
-#ifdef RUART_ABL_ATTN_STAMPS
-__device__ unsigned long long* g_attn_stamps = nullptr;
-extern "C" int ruart_attn_set_stamps(unsigned long long* p) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p));
-}
-#endif
 #define ATTN_LD4(p) load4_stream(p)          // the fp32 Q / K / V rows are read once per layer (common.h)
 __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
                                                                   unsigned char* __restrict__ ctx8, int ldc, int H,
@@ -615,7 +651,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 16 + i * 4 + prow;
-        if (row >= tn) kx[i] = vx[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};       // rows past the window: zero keys / values
+        // (rows past the window are clamped copies of its last row - finite - and their keys are masked through Ls = -1: their
+        //  probabilities are exactly 0, so they need no zero-fill; 32 selects per thread and step less)
         f16x4_t kh4, kl4, vh4, vl4;
 #ifdef RUART_ABL_ATTN_NOSPLIT        // diagnostic build: the loaded bytes go to LDS as they are (wrong numbers; the time of a kernel whose
         {                            // producer had written the hi / lo pair itself: 136.9 -> 132.5 us - the split is not what costs)
@@ -625,13 +662,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
           kh4 = uk.h.a; kl4 = uk.h.b; vh4 = uv.h.a; vl4 = uv.h.b;
         }
 #else
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          kh4[e] = (f16_t)kx[i][e];
-          kl4[e] = (f16_t)(kx[i][e] - (float)kh4[e]);
-          vh4[e] = (f16_t)vx[i][e];
-          vl4[e] = (f16_t)(vx[i][e] - (float)vh4[e]);
-        }
+        split_f16x4(kx[i], kh4, kl4);
+        split_f16x4(vx[i], vh4, vl4);
 #endif
         const int off = row * RS + piece * 8;
         *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
@@ -682,12 +714,15 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
     flash_softmax_step<f16_t>(sacc, m, l, o, ph);             // sacc now holds the fp32 probabilities, ph their f16 roundings
     frag_t pl[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pl[s2][j] = (f16_t)(sacc[2 * s2][j] - (float)ph[s2][j]);
-        pl[s2][4 + j] = (f16_t)(sacc[2 * s2 + 1][j] - (float)ph[s2][4 + j]);
-      }
+    for (int s2 = 0; s2 < 2; ++s2) {
+      union { frag_t v; unsigned u[4]; } hh, ll;
+      hh.v = ph[s2];
+      ll.u[0] = lo2_of(sacc[2 * s2][0], sacc[2 * s2][1], hh.u[0]);
+      ll.u[1] = lo2_of(sacc[2 * s2][2], sacc[2 * s2][3], hh.u[1]);
+      ll.u[2] = lo2_of(sacc[2 * s2 + 1][0], sacc[2 * s2 + 1][1], hh.u[2]);
+      ll.u[3] = lo2_of(sacc[2 * s2 + 1][2], sacc[2 * s2 + 1][3], hh.u[3]);
+      pl[s2] = ll.v;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -868,15 +903,11 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 16 + i * 4 + prow;
-        if (row >= tn) kx[i] = vx[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};       // rows past the window: zero keys / values
+        // (rows past the window are clamped copies of its last row - finite - and their keys are masked through Ls = -1: their
+        //  probabilities are exactly 0, so they need no zero-fill; 32 selects per thread and step less)
         f16x4_t kh4, kl4, vh4, vl4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          kh4[e] = (f16_t)kx[i][e];
-          kl4[e] = (f16_t)(kx[i][e] - (float)kh4[e]);
-          vh4[e] = (f16_t)vx[i][e];
-          vl4[e] = (f16_t)(vx[i][e] - (float)vh4[e]);
-        }
+        split_f16x4(kx[i], kh4, kl4);
+        split_f16x4(vx[i], vh4, vl4);
         const int off = row * RS + piece * 8;
         *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
         *reinterpret_cast<f16x4_t*>(Kl + off) = kl4;
@@ -923,12 +954,15 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
     flash_softmax_step<f16_t>(sacc, m, l, o, ph);             // sacc now holds the fp32 probabilities, ph their f16 roundings
     frag_t pl[2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        pl[s2][jj] = (f16_t)(sacc[2 * s2][jj] - (float)ph[s2][jj]);
-        pl[s2][4 + jj] = (f16_t)(sacc[2 * s2 + 1][jj] - (float)ph[s2][4 + jj]);
-      }
+    for (int s2 = 0; s2 < 2; ++s2) {
+      union { frag_t v; unsigned u[4]; } hh, ll;
+      hh.v = ph[s2];
+      ll.u[0] = lo2_of(sacc[2 * s2][0], sacc[2 * s2][1], hh.u[0]);
+      ll.u[1] = lo2_of(sacc[2 * s2][2], sacc[2 * s2][3], hh.u[1]);
+      ll.u[2] = lo2_of(sacc[2 * s2 + 1][0], sacc[2 * s2 + 1][1], hh.u[2]);
+      ll.u[3] = lo2_of(sacc[2 * s2 + 1][2], sacc[2 * s2 + 1][3], hh.u[3]);
+      pl[s2] = ll.v;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
