@@ -222,6 +222,7 @@ class ItemIndex:
         tok_start = np.concatenate([[0], np.cumsum(wps)[:-1]])
         self.tok_in_sample = np.arange(self.W) - tok_start[self.sample_of_word]
         self.Tmax = int(wps.max()) if B else 0
+        self.flat_tok = self.sample_of_word * max(self.Tmax, 1) + self.tok_in_sample      # row of a word in the (B * Tmax, D) pre-align matrix
         # multi2one schedule: items sorted by word count (descending, stable); at step s the first n_active[s] are alive
         order = np.argsort(-lens, kind="stable")
         ls = lens[order]
@@ -230,6 +231,7 @@ class ItemIndex:
         self.step_rows = np.concatenate([word_start[order[:n]] + s for s, n in enumerate(self.n_active)]) if N else np.zeros(0, np.int64)
         self.sorted_sample = sample_of_item[order]
         self.sorted_slot = slot[order]
+        self.flat_slot = self.sorted_sample * max_num + self.sorted_slot                   # row of an item in the (B * max_num, D) matrix
         self.num_cnt = num_cnt
         Lw = items[word_key].shape[1]
         self.Lw = Lw
@@ -240,7 +242,8 @@ class ItemIndex:
         self.dev = None
         self.emb_sort = {}
 
-    _FIELDS = ("item_of_word", "sample_of_word", "tok_in_sample", "step_rows", "sorted_sample", "sorted_slot", "flat_word")
+    _FIELDS = ("item_of_word", "sample_of_word", "tok_in_sample", "step_rows", "sorted_sample", "sorted_slot", "flat_word", "flat_tok",
+               "flat_slot")
 
     def pack_host(self):
         return [getattr(self, f).astype(np.int64) for f in self._FIELDS]

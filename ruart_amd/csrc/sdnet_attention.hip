@@ -684,7 +684,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pf_kernel(const float* __rest
 // Whole-tensor layer norm (Layers.py:167-168): mean / biased variance over ALL n elements, no affine.
 // Two-pass (mean, then centred sum of squares) with fixed-order partials => deterministic.
 // ------------------------------------------------------------------------------------------------
+#ifndef WLN_BLOCKS
 #define WLN_BLOCKS 256
+#endif
 __device__ __forceinline__ float grid_partial_total(const float* part, float* red) {
   // every block re-reduces the WLN_BLOCKS partials in the same order
   float s = (threadIdx.x < WLN_BLOCKS) ? part[threadIdx.x] : 0.f;

@@ -558,16 +558,18 @@ Plan make_plan(int M, int N, int K, int amode, int bmode) {
   };
   const int t256 = ((M + 255) / 256) * ((N + 255) / 256), t128 = ((M + 127) / 128) * ((N + 127) / 128);
   Plan p;
+  static const int fill256 = [] { const char* e = getenv("RUART_X3_T256_FILL"); return e ? atoi(e) : 256; }();      // (experiments)
+  static const int min256 = [] { const char* e = getenv("RUART_X3_T256_MIN"); return e ? atoi(e) : 192; }();
   int s256 = 1;
   if (t256 < 200 && ksteps >= 16) {
-    s256 = (256 + t256 - 1) / t256;
+    s256 = (fill256 + t256 - 1) / t256;
     if (s256 > ksteps / 8) s256 = ksteps / 8;
     if (s256 < 1) s256 = 1;
   }
   // padding waste of the big tile must stay moderate, and it needs enough workgroups
   const double waste = (double)t256 * 65536.0 / ((double)M * N);
   // (measured: with a transposed-read B operand the big tile re-reads B's fragments twice per step and loses: 231 vs 203 us)
-  if (bmode == 0 && (long long)M * N >= 4096LL * 1024 && t256 * s256 >= 192 && waste < 1.25) {
+  if (bmode == 0 && (long long)M * N >= 4096LL * 1024 && t256 * s256 >= min256 && waste < 1.25) {
     (void)amode;
     p.tm = 256; p.tiles = t256; p.splitk = s256;
   } else {

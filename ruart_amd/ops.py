@@ -110,7 +110,7 @@ class _FusedAttention(torch.autograd.Function):
                                        hip.ptr(pscale), hip.ptr(ga), hip.ptr(gk), hip.ptr(gv), hip.ptr(gdiag), hip.ptr(ds), B, L1, L2,
                                        h, D3, hip.stream_ptr())
         hip.check(rc, "ruart_attn_bwd")
-        return ga, gk, gv, None, (gdiag.sum(0).view_as(diag) if gdiag is not None else None), None, None
+        return ga, gk, gv, None, (colsum(gdiag).view_as(diag) if gdiag is not None else None), None, None
 
 
 def fused_attention(a, k, v, mask, diag=None, relu=False, prob_scale=None):
