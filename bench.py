@@ -40,7 +40,7 @@ PEAK_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); 
 DTYPE = {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA",
          "fp16c": "f16 MFMA + block-scaled fp8 (e4m3) MFMA correction, f32 accumulate / residual stream"}
 GEMM_KERNEL = {"fp16": "gemm_16_nt_256p8", "bf16": "gemm_16_nt_256p8", "fp16c": "gemm_16c_nt_256p8"}
-TRAFFIC_FILE = "r04_gemm_traffic.json"
+TRAFFIC_FILE = "r05_gemm_traffic.json"
 
 
 def parse():
