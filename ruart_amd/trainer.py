@@ -352,10 +352,14 @@ class SDNetTrainer(BaseTrainer):
             self.optimizer.step()
         self.updates += 1
         if "TUNE_PARTIAL" in self.opt:
+            # Models/SDNetTrainer.py:369-373 re-pins the rows >= tune_partial after every step.  The fused optimizer never writes them
+            # (FusedAdamax(pinned=): their update is left out), so they still hold the pinned values: the two 23 MB copies per step
+            # are skipped for the tables it knows as pinned
             tp = self.opt["tune_partial"]
-            if "FastText" in self.opt:
+            kept = getattr(self.optimizer, "pinned", {})
+            if "FastText" in self.opt and id(self.network.fast_embed.weight) not in kept:
                 self.network.fast_embed.weight.data[tp:] = self.network.fixed_embedding_fast
-            if "GLOVE" in self.opt:
+            if "GLOVE" in self.opt and id(self.network.glove_embed.weight) not in kept:
                 self.network.glove_embed.weight.data[tp:] = self.network.fixed_embedding_glove
         if self._defer_readback():
             lazy = self._readback_later(loss, stage_next)
