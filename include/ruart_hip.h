@@ -386,6 +386,10 @@ int ruart_lstm_pack_params(const float* w_ih, const float* w_ih_r, const float* 
                            const float* b_hh_r, const float* w_hh, const float* w_hh_r, float* w, float* b, float* whh, int G, int K, int h,
                            void* stream);
 
+/* out[w][c] = x[w][c] * mask[row_of[w]][c] (fp32; row strides in elements; D % 4 == 0, 16-byte aligned rows; row_of int64): the
+ * variational dropout of a packed (words, D) matrix with one mask row per item (layers.row_dropout; Models/Layers.py:23-30). */
+int ruart_rows_scale(const float* x, int ldx, const float* mask, int ldm, const long long* row_of, float* out, int ldo, int rows, int D,
+                     void* stream);
 /* Pointwise part of ONE step of a wide LSTM over a ragged, length-sorted batch (the `multi2one` LSTM, Models/SDNet.py:137,
  * 269-271: hidden 300, 1-3 real words per item).  pre (n_active, 4h) = x W_ih^T + b + h_prev W_hh^T from the caller's GEMMs;
  * rows < n_active are advanced (acts (n_active,4h) = post-activation i,f,g,o saved for backward), rows >= n_active of

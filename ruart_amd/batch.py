@@ -236,6 +236,13 @@ class ItemIndex:
         Lw = items[word_key].shape[1]
         self.Lw = Lw
         self.flat_word = self.item_of_word * Lw + self.pos_in_item          # index into the flattened (N, Lw) id matrices
+        # the real words' ids of every id matrix the embedding layers look up, gathered here on the host: the device side did
+        # ``items[key].reshape(-1)[flat_word]`` per table and step (ten small index launches per step, round 5 op table)
+        self.word_ids = {}
+        for k in ("fasttext", "glove", "phoc", "pos", "ent"):
+            v = items.get(k)
+            if v is not None and tuple(v.shape) == (N, Lw):
+                self.word_ids[k] = _np(v).reshape(-1)[self.flat_word].astype(np.int64)
         mask = np.zeros((B, max_num), dtype=np.uint8)
         mask[np.arange(max_num)[None, :] < num_cnt[:, None]] = 1
         self.mask = mask
@@ -245,11 +252,14 @@ class ItemIndex:
     _FIELDS = ("item_of_word", "sample_of_word", "tok_in_sample", "step_rows", "sorted_sample", "sorted_slot", "flat_word", "flat_tok",
                "flat_slot")
 
+    def fields(self):
+        return list(self._FIELDS) + ["ids_" + k for k in sorted(self.word_ids)]
+
     def pack_host(self):
-        return [getattr(self, f).astype(np.int64) for f in self._FIELDS]
+        return [getattr(self, f).astype(np.int64) for f in self._FIELDS] + [self.word_ids[k] for k in sorted(self.word_ids)]
 
     def bind(self, tensors):
-        self.dev = dict(zip(self._FIELDS, tensors))
+        self.dev = dict(zip(self.fields(), tensors))
 
 
 def _sort_ids(ids, padding_idx=None, max_seg=64):
@@ -410,7 +420,7 @@ class BatchIndex:
         h = self._staged()
         buf = h["items"].to(self.device, non_blocking=True)
         parts = list(torch.split(buf, h["item_sizes"]))
-        n = len(ItemIndex._FIELDS)
+        n = len(self.ocr.fields())
         self.ocr.bind(parts[:n])
         self.od.bind(parts[n:])
         self.ocr_mask = h["ocr_mask"].to(self.device, non_blocking=True)

@@ -2,6 +2,7 @@
 // Reference path: Models/Bert/modeling.py:585-614 (BertModel.forward) -> :326-334 (all layer outputs kept,
 // because Models/Bert/Bert.py:137 concatenates every layer).  Seven launches per layer, no host sync,
 // no allocation: capturable into a hipGraph by the caller.
+#include <cstdlib>
 #include "common.h"
 #include "ruart_hip.h"
 
@@ -96,6 +97,10 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
   const size_t tws_bytes = tail_bytes(m);
   void* tws = tws_bytes ? c.take(tws_bytes) : nullptr;
   const int cus = m->tail_cus;
+  // which projections take the tail split when tail_cus > 0: bit 0 QKV, 1 attention output, 2 FFN intermediate, 3 FFN output (experiments)
+  static const int tail_sites = getenv("RUART_TAIL_SITES") ? atoi(getenv("RUART_TAIL_SITES")) : 15;
+  const int cus_qkv = (tail_sites & 1) ? cus : 0, cus_ao = (tail_sites & 2) ? cus : 0, cus_ff1 = (tail_sites & 4) ? cus : 0,
+            cus_ff2 = (tail_sites & 8) ? cus : 0;
   int rc = ruart_bert_embed_ln_split(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, m->ln_eps, x32,
                                      x16, x8, H, R, H, stream);
   if (rc) return rc;
@@ -107,7 +112,7 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
     const bool on = (g_corr_layers >> (l & 63)) & 1ull;
     const int c_qkv = on ? g_corr_site[0] : 0, c_ao = on ? g_corr_site[1] : 0, c_ff1 = on ? g_corr_site[2] : 0, c_ff2 = on ? g_corr_site[3] : 0;
     if ((rc = ruart_gemm_16c_nt_ws(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], nullptr, 0, qkv, 3 * H, nullptr, R, 3 * H, H,
-                                   RUART_ACT_NONE, c_qkv, tws, tws_bytes, cus, stream)))
+                                   RUART_ACT_NONE, c_qkv, tws, tws_bytes, cus_qkv, stream)))
       return rc;
     if ((rc = ruart_bert_attention_split(qkv, 3 * H, ctx16, ctx8, H, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
                                          b->tok_lo, b->tok_hi, b->key_bias, stream)))
@@ -128,14 +133,14 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
       ruart_prof_real_rows = n_last;
     }
     if ((rc = ruart_gemm_16c_nt_ws(a16, a8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], res, H, pre, H, nullptr, Rl, H, H, RUART_ACT_NONE,
-                                   c_ao, tws, tws_bytes, cus, stream)))
+                                   c_ao, tws, tws_bytes, cus_ao, stream)))
       return rc;
     if ((rc = ruart_rows_layernorm_split(pre, H, m->ln1_g[l], m->ln1_b[l], m->ln_eps, mid32, mid16, mid8, H, Rl, H, stream))) return rc;
     if ((rc = ruart_gemm_16c_nt_ws(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], nullptr, 0, ffn16, I, ffn8, Rl, I, H,
-                                   RUART_ACT_GELU, c_ff1, tws, tws_bytes, cus, stream)))
+                                   RUART_ACT_GELU, c_ff1, tws, tws_bytes, cus_ff1, stream)))
       return rc;
     if ((rc = ruart_gemm_16c_nt_ws(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], mid32, H, pre, H, nullptr, Rl, H, I,
-                                   RUART_ACT_NONE, c_ff2, tws, tws_bytes, cus, stream)))
+                                   RUART_ACT_NONE, c_ff2, tws, tws_bytes, cus_ff2, stream)))
       return rc;
     // (the last layer's GEMM-operand copies go to the dead context buffers: x16 / x8 may hold its compacted inputs)
     if ((rc = ruart_rows_layernorm_split(pre, H, m->ln2_g[l], m->ln2_b[l], m->ln_eps, out, Rl == R ? x16 : ctx16, Rl == R ? x8 : ctx8, H, Rl, H,

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "ruart_lstm_pack_params": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ruart_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ruart_rows_scale": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_set_nan_flag": (_I, [_P]),

@@ -98,7 +98,7 @@ def row_dropout(x, rows_of, n_rows, p, training):
         return x
     if not do_seq_dropout:
         return F.dropout(x, p=p, training=True)
-    return x * mask_bank.take(n_rows, x.size(1), p, x)[rows_of]
+    return ops.rows_scale(x, mask_bank.take(n_rows, x.size(1), p, x), rows_of)
 
 
 class StackedBRNN(nn.Module):

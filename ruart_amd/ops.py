@@ -744,6 +744,40 @@ def lstm_cell(pre, h_prev, c_prev, n_active):
 
 
 # ---------------------------------------------------------------------------------------------------------
+class _RowScale(torch.autograd.Function):
+    """y[w] = x[w] * mask[row_of[w]] for a packed (words, D) fp32 matrix and one mask row per item (ruart_rows_scale): the mask rows are
+    read through the index inside the kernel, in the forward and in the backward - no (words, D) copy of the mask exists."""
+
+    @staticmethod
+    def forward(ctx, x, mask, row_of):
+        y = torch.empty_like(x)
+        hip.check(hip.load().ruart_rows_scale(hip.ptr(x), x.stride(0), hip.ptr(mask), mask.stride(0), hip.ptr(row_of), hip.ptr(y), y.stride(0),
+                                              x.shape[0], x.shape[1], hip.stream_ptr(x.device)), "ruart_rows_scale")
+        ctx.save_for_backward(mask, row_of)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, row_of = ctx.saved_tensors
+        if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+            g = g.contiguous()
+        gx = torch.empty(g.shape, dtype=torch.float32, device=g.device)
+        hip.check(hip.load().ruart_rows_scale(hip.ptr(g), g.stride(0), hip.ptr(mask), mask.stride(0), hip.ptr(row_of), hip.ptr(gx), gx.stride(0),
+                                              g.shape[0], g.shape[1], hip.stream_ptr(g.device)), "ruart_rows_scale")
+        return gx, None, None
+
+
+def rows_scale(x, mask, row_of):
+    """x (W, D) * mask (N, D)[row_of (W,)] on the fused kernel when the layout allows it (fp32 device tensors, D % 4 == 0, aligned rows),
+    else the gather-and-multiply of torch."""
+    if (x.is_cuda and x.dtype == torch.float32 and mask.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] % 4 == 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and mask.stride(1) == 1 and mask.stride(0) % 4 == 0
+            and mask.data_ptr() % 16 == 0 and row_of.dtype == torch.int64 and row_of.is_contiguous()):
+        return _RowScale.apply(x, mask, row_of)
+    return x * mask[row_of]
+
+
+# ---------------------------------------------------------------------------------------------------------
 def embedding_grad(gy, sort, shape):
     """Gradient of an embedding table (``shape`` = (V, D)) from the (n, D) gradient rows of its lookups and the host-prepared sort of
     their ids (batch._sort_ids): 3 tensors = one workgroup per looked-up row; 4 tensors = the two-level form for rows with very many

@@ -340,7 +340,7 @@ class SDNet(nn.Module):
         p_emb = self.opt.get("dropout_emb", 0.0)
         for key in ("phoc", "fasttext", "glove"):
             if key in self.ocr_embedding:
-                ids = items[key].to(dev).reshape(-1)[d["flat_word"]]
+                ids = d["ids_" + key] if "ids_" + key in d else items[key].to(dev).reshape(-1)[d["flat_word"]]
                 e = ops.embedding(getattr(self, self._word_table(key)), ids, idx.emb_sort.get(key))
                 if key == self.opt["ocr_emb_initial"]:
                     raw = e
@@ -348,9 +348,11 @@ class SDNet(nn.Module):
         if "bert" in self.ocr_embedding:
             parts.append(row_dropout(bert_mix, d["item_of_word"], idx.N, p_emb, self.drop_emb))
         if "pos" in self.ocr_embedding:
-            parts.append(ops.embedding(self.pos_embedding, items["pos"].to(dev).reshape(-1)[d["flat_word"]], idx.emb_sort.get("pos")))
+            ids = d["ids_pos"] if "ids_pos" in d else items["pos"].to(dev).reshape(-1)[d["flat_word"]]
+            parts.append(ops.embedding(self.pos_embedding, ids, idx.emb_sort.get("pos")))
         if "ent" in self.ocr_embedding:
-            parts.append(ops.embedding(self.ent_embedding, items["ent"].to(dev).reshape(-1)[d["flat_word"]], idx.emb_sort.get("ent")))
+            ids = d["ids_ent"] if "ids_ent" in d else items["ent"].to(dev).reshape(-1)[d["flat_word"]]
+            parts.append(ops.embedding(self.ent_embedding, ids, idx.emb_sort.get("ent")))
         return torch.cat(parts, -1), raw
 
     def _prealign(self, raw_words, idx, q_raw, q_mask):

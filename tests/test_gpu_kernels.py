@@ -1002,3 +1002,23 @@ def test_sdnet_attention_prefetch_forms_bit_identical(shape):
         hip.check(lib.ruart_attn_set_prefetch(1), "ruart_attn_set_prefetch")
     for t0, t1 in zip(res[0], res[1]):
         assert torch.equal(t0.view(torch.int32), t1.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,N,D", [(12841, 6400, 1388), (3421, 2304, 300), (5, 3, 768), (1, 1, 4)])
+def test_rows_scale_equals_gather_and_multiply(W, N, D):
+    """ruart_rows_scale (the packed variational dropout, layers.row_dropout): x * mask[row_of] in one pass, forward and backward, bit
+    for bit what torch's gather + multiply computes; a column-slice view of a wider gradient goes in without a copy."""
+    from ruart_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(W, D, generator=g).to(d).requires_grad_(True)
+    mask = ((torch.rand(N, D, generator=g) > 0.3).float() / 0.7).to(d)
+    row_of = torch.sort(torch.randint(0, N, (W,), generator=g)).values.to(d)
+    y = ops.rows_scale(x, mask, row_of)
+    ref = x.detach() * mask[row_of]
+    assert torch.equal(y.detach().view(torch.int32), ref.view(torch.int32))
+    wide = torch.randn(W, D + 8, generator=g).to(d)
+    gy = wide[:, 4:4 + D]                                   # strided rows, 16-byte aligned start
+    y.backward(gy)
+    assert torch.equal(x.grad.view(torch.int32), (gy * mask[row_of]).view(torch.int32))
