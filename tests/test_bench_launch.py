@@ -28,3 +28,30 @@ def test_launch_check_single_process():
     r = _run(["--launch-check"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
+
+
+def test_bench_timeline_and_distribution_helpers():
+    """bench.py's helpers that turn the event recorder's arrays into the line's ``step_ms`` / ``timeline_ms`` / ``timed_gemm_us``:
+    synthetic records of four steps (marks 1-6 on two streams, GEMM launches with flops > 0)."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = bench._dist([24.0, 23.0, 25.0, 60.0, 23.5])
+    assert d["min"] == 23.0 and d["max"] == 60.0 and d["first"] == 24.0 and d["median"] == 24.0
+    b, e, f = [], [], []
+    for k in range(4):                      # a step every 24 ms: forward 0..6, backward ..19, optimizer ..19.2, encoder pass 0.3..23.8
+        t0 = 24.0 * k
+        for tag, t in ((1, 0.0), (5, 0.3), (2, 6.0), (3, 19.0), (4, 19.2), (6, 23.8)):
+            b.append(t0 + t); e.append(t0 + t); f.append(-float(tag))
+        for j in range(48):                 # 48 GEMMs: 0.44 ms while the trunk is there, 0.30 ms after it
+            st = t0 + 0.4 + j * 0.48
+            b.append(st); e.append(st + (0.44 if st < t0 + 19.2 else 0.30)); f.append(1e11)
+    b, e, f = np.array(b), np.array(e), np.array(f)
+    t = bench._timeline(b, e, f)
+    assert t["steps"] == 2 and abs(t["step"] - 24.0) < 1e-6
+    assert abs(t["trunk_forward_end"] - 6.0) < 1e-6 and abs(t["trunk_backward_end"] - 19.0) < 1e-6 and abs(t["optimizer_end"] - 19.2) < 1e-6
+    assert abs(t["encoder_pass_start"] - 0.3) < 1e-6 and abs(t["encoder_pass_end"] - 23.8) < 1e-6
+    g = bench._gemm_split(b, e, f)
+    assert abs(g["beside_trunk"] - 440.0) < 0.5 and abs(g["after_trunk"] - 300.0) < 0.5 and g["launches_after_trunk"] == 8
