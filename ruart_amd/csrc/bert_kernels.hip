@@ -584,10 +584,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
       const int row = wave * 16 + i * 4 + prow;
 #ifdef RUART_ABL_ATTN_L2LOADS        // diagnostic build: every workgroup reads the window of token 0 (L2 hits: the time without HBM reads)
       const float* kp = qkv + (size_t)(min(row, tn - 1)) * ld + H + h * 64 + piece * 4;
-#elif defined(RUART_ABL_ATTN_HEADMAJOR)   // diagnostic build (= the stream's row count): the same bytes read as if Q / K / V were stored
-      // [part][head][row][64] - a window's K tile of a head is then ONE contiguous 16 KB block (wrong numbers, the time of that layout)
-      const float* kp = qkv + ((size_t)((H >> 6) + h) * RUART_ABL_ATTN_HEADMAJOR + (kt + min(row, tn - 1))) * 64 + piece * 4 - H;
-      #define RUART_HM_VOFF ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64)
 #else
       const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
 #endif
@@ -596,12 +592,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
       vx[i] = (f32x4_t){(float)((size_t)kp & 127), 3.f, 2.f, 1.f} * 0.01f;
 #else
       kx[i] = ATTN_LD4(kp);
-#ifdef RUART_ABL_ATTN_HEADMAJOR
-      kx[i] = load4(kp + H);
-      vx[i] = load4(kp + H + ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64));
-#else
       vx[i] = ATTN_LD4(kp + H);
-#endif
 #endif
     }
     if (tid < 64) {
@@ -612,11 +603,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
   };
   f32x4_t qx[4];
   {
-#ifdef RUART_ABL_ATTN_HEADMAJOR
-    const float* qp = qkv + ((size_t)h * RUART_ABL_ATTN_HEADMAJOR + (qvalid ? tq : q0)) * 64 + g * 8;
-#else
     const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #ifdef RUART_ABL_ATTN_NOLOADS
@@ -807,8 +794,6 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
       const int row = wave * 16 + i * 4 + prow;
 #ifdef RUART_ABL_ATTN_L2LOADS        // diagnostic build (see the one-head kernel)
       const float* kp = qkv + (size_t)(min(row, tn - 1)) * ld + H + h * 64 + piece * 4;
-#elif defined(RUART_ABL_ATTN_HEADMAJOR)
-      const float* kp = qkv + ((size_t)((H >> 6) + h) * RUART_ABL_ATTN_HEADMAJOR + (kt + min(row, tn - 1))) * 64 + piece * 4 - H;
 #else
       const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
 #endif
@@ -817,12 +802,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
       vx[i] = (f32x4_t){(float)((size_t)kp & 127), 3.f, 2.f, 1.f} * 0.01f;
 #else
       kx[i] = ATTN_LD4(kp);
-#ifdef RUART_ABL_ATTN_HEADMAJOR
-      kx[i] = load4(kp + H);
-      vx[i] = load4(kp + H + ((size_t)(H >> 6) * RUART_ABL_ATTN_HEADMAJOR * 64));
-#else
       vx[i] = ATTN_LD4(kp + H);
-#endif
 #endif
     }
     if (tid < 64) {
@@ -832,11 +812,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
     }
   };
   auto load_q = [&](int h) {
-#ifdef RUART_ABL_ATTN_HEADMAJOR
-    const float* qp = qkv + ((size_t)h * RUART_ABL_ATTN_HEADMAJOR + (qvalid ? tq : q0)) * 64 + g * 8;
-#else
     const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #ifdef RUART_ABL_ATTN_NOLOADS
