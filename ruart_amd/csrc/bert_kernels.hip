@@ -33,7 +33,11 @@ struct RowStoreSplit {
   unsigned char* o8;
   int H;
   __device__ __forceinline__ void operator()(int c, f32x4_t o) const {
+#if defined(RUART_NT_LN_STORE) && RUART_NT_LN_STORE      // experiments: the fp32 rows (next read: a residual add ~0.6 ms later) past the caches
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(o32 + c));
+#else
     store4(o32 + c, o);
+#endif
     store_split4(o16 + c, o8 + c, H, o);
   }
 };
