@@ -1185,7 +1185,10 @@ __global__ __launch_bounds__(256) void pool_mix_cols_kernel(const T* __restrict_
                                                             const int* __restrict__ span_start, const int* __restrict__ span_start_last,
                                                             const int* __restrict__ span_len, const int* __restrict__ dst_row,
                                                             const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H) {
-  constexpr int LB = 6;
+#ifndef RUART_POOL_LB
+#define RUART_POOL_LB 6
+#endif
+  constexpr int LB = RUART_POOL_LB;
   const int w = blockIdx.x;
   const int st = span_start[w], n = span_len[w];
   const int st_last = span_start_last ? span_start_last[w] : st;
