@@ -282,6 +282,13 @@ typedef struct {
   int tail_cus;   /* CU count the encoder GEMMs plan their TAIL SPLIT for (ruart_gemm_16c_nt_ws / ruart_gemm_16_nt_ws): the CUs of the stream's
                      mask, or of the device; 0 = single-launch products.  The plan depends on (rows, N, K, tail_cus) only, so passes on
                      different streams of one model agree bit for bit.  Enlarges ruart_bert_workspace_bytes by tail_cus x 256 KB. */
+  int ln_fold;    /* corr8 only: != 0 = the weights are prepared for ruart_bert_forward_folded (the only forward such a model may be given
+                     to): for every layer l >= 1, w_qkv[l] / w8_qkv[l] hold W' = Wqkv diag(ln2_g[l-1]) 2^-s and b_qkv[l] holds
+                     d = b + Wqkv ln2_b[l-1]; for every layer, w_ff1 / w8_ff1 / b_ff1 the same with ln1_g[l] / ln1_b[l] */
+  const float* const* fold_c_qkv;   /* [3H] per layer: c_j = sum_i W'_ji (entry 0 unused: layer 0 reads the materialised embedding rows) */
+  const float* const* fold_c_ff1;   /* [intermediate] per layer */
+  const float* fold_s_qkv;          /* HOST arrays of n_layers floats: 2^s of the layer's folded QKV / intermediate weights */
+  const float* fold_s_ff1;
 } ruart_bert_model;
 
 typedef struct {
@@ -310,6 +317,36 @@ int ruart_bert_set_correction(int qkv, int ao, int ff1, int ff2, unsigned long l
 /* layers_out: [n_layers][n_rows][hidden] in m->dtype (fp32 when m->corr8).  `m` and `b` are HOST structs. */
 int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* The fp16c encoder with every LayerNorm (Models/Bert/modeling.py:164-168) folded into the projections around it (csrc/gemm_corr.hip,
+ * CorrFold): five launches per layer, no normalised row is ever written.  m->ln_fold != 0 (weights prepared accordingly), H % 256 == 0.
+ * layers_pre: [n_layers][n_rows][hidden] fp32 PRE-LayerNorm rows y; ln_stats: [n_layers][n_rows][2] floats (mu, rstd); the layer output
+ * the reference keeps is (y - mu) rstd ln2_g[l] + ln2_b[l] - formed on the fly by ruart_bert_pool_mix_ln.  Last layer compacted as in
+ * ruart_bert_forward when b->last_rows is set (its stats rows are compacted the same way). */
+size_t ruart_bert_workspace_bytes_folded(const ruart_bert_model* m, int n_rows);
+int ruart_bert_forward_folded(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_pre, float* ln_stats, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* One projection of that pass (see CorrFold in csrc/gemm_corr.hip): kind 0 fp32 out, kind 2 GELU + split out - with in_part != NULL the
+ * A rows are pre-LayerNorm rows and the epilogue finishes rstd 2^s (A W'^T - mu c) + d (`bias` = d, wscale = 2^s); kind 3: y = A W^T +
+ * bias + residual (the residual rows normalised with res_part / res_gamma / res_beta when res_part != NULL), written fp32 (C), split
+ * (C16, C8) and as row partials out_part.  Partials: [M][4][2] floats, slot t = (sum, sum of squares) of the row over columns
+ * 256 t .. 256 t + 255 (N <= 1024); in_np / res_np = slots in use; stat_len = the row length they cover. */
+int ruart_gemm_16c_nt_fold(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias, int kind,
+                           const float* in_part, int in_np, const float* colc, float wscale, const float* residual, int ldr,
+                           const float* res_part, int res_np, const float* res_gamma, const float* res_beta, void* C, int ldc, void* C16,
+                           void* C8, float* out_part, int M, int N, int K, int stat_len, float eps, void* stream);
+/* (mu, rstd) [rows][2] from such partials */
+int ruart_rows_stats_finish(const float* part, int np, int rows, float inv_h, float eps, float* stats, void* stream);
+/* ruart_bert_pool_mix / _bwd (Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581) over the pre-LayerNorm rows of the folded pass:
+ * ln_stats [n_layers][stats_stride][2], ln_gamma / ln_beta [n_layers][H] (the layers' output LayerNorm parameters); fp32, H % 256 == 0. */
+int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
+                           long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
+                           const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo,
+                           int n_words, int H, void* stream);
+int ruart_bert_pool_mix_ln_bwd(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
+                               long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
+                               const int* span_start_last, const int* span_len, const int* dst_row, const float* grad_out, int ldg,
+                               float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream);
 
 /* ---- SDNet kernels (Models/Layers.py) ---------------------------------------------------------------------- */
 /* Layers.py:228-231 + :244 + :275-288: for each batch b, with pa = x1 W^T (B,L1,h) and pk = x2 W^T (B,L2,h) from the caller,

@@ -48,10 +48,16 @@ def split_f16c(x, lo_shift=None, hi_shift=None):
 class BertEncoderWeights:
     """Device-resident encoder weights in the layout ruart_bert_forward expects."""
 
-    def __init__(self, state, cfg, device, dtype="fp16", check_range=True):
+    def __init__(self, state, cfg, device, dtype="fp16", check_range=True, ln_fold=False):
         """``check_range`` (fp16c): warn at load time when a projection weight exceeds the fp8 correction operand's range (one host
-        sync per matrix; off for the trainable encoder's per-step operand rebuilds)."""
+        sync per matrix; off for the trainable encoder's per-step operand rebuilds).
+        ``ln_fold`` (fp16c, hidden and intermediate sizes multiples of 256): prepare the weights for ``ruart_bert_forward_folded`` -
+        every LayerNorm of the encoder (modeling.py:164-168) folded into the projection that reads it: the QKV weights of layer l >= 1
+        become W' = Wqkv diag(ln2_g[l-1]) 2^-s (s >= 0: keeps |W'| inside the fp8 companion's range), their bias d = b + Wqkv ln2_b[l-1],
+        the intermediate dense the same with the layer's attention-output LayerNorm; c = row sums of W' (csrc/gemm_corr.hip, CorrFold)."""
         self._check_range = check_range
+        self.ln_fold = bool(ln_fold) and dtype == "fp16c" and cfg["hidden_size"] % 256 == 0 and cfg["intermediate_size"] % 256 == 0 \
+            and cfg["hidden_size"] <= 1024
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self.precision = dtype
@@ -91,32 +97,66 @@ class BertEncoderWeights:
         self.emb_ln_b = f32(e + "LayerNorm.beta")
         keys = ["w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2", "ln2_g", "ln2_b"]
         keys8 = ["w8_qkv", "w8_ao", "w8_ff1", "w8_ff2"] if self.corr8 else []
+        keysf = ["fold_c_qkv", "fold_c_ff1"] if self.ln_fold else []
         self._w_absmax = 0.0
-        self.layers = {k: [] for k in keys + keys8}
+        self.layers = {k: [] for k in keys + keys8 + keysf}
+        self.fold_scales = {"qkv": [], "ff1": []}
         scale = 1.0 / 8.0                      # 1/sqrt(head_dim = 64): a power of two, exact in fp32 and bf16
+
+        def folded(w, b, g, be):
+            """(W' = w diag(g) 2^-s, d = b + w be, c = row sums of W', 2^s) - sums in fp64"""
+            wf = w * g[None, :]
+            amax = float(wf.abs().max())
+            sh = 0
+            while amax * 2.0 ** -sh >= 3.4:     # e4m3(f16(w) 2^7) saturates at 3.5 (csrc/common.h)
+                sh += 1
+            wf = wf * float(2.0 ** -sh)
+            d = (b.double() + w.double() @ be.double()).float().contiguous()
+            c = wf.double().sum(1).float().contiguous()
+            return wf, d, c, float(2.0 ** sh)
+
+        prev_g = prev_b = None
         for l in range(cfg["num_hidden_layers"]):
             p = "encoder.layer.%d." % l
             wq, wk, wv = f32(p + "attention.self.query.weight"), f32(p + "attention.self.key.weight"), f32(p + "attention.self.value.weight")
             bq, bk, bv = f32(p + "attention.self.query.bias"), f32(p + "attention.self.key.bias"), f32(p + "attention.self.value.bias")
             L = self.layers
+            w_qkv, b_qkv = torch.cat([wq * scale, wk, wv], 0), torch.cat([bq * scale, bk, bv], 0).contiguous()
+            w_ff1, b_ff1 = f32(p + "intermediate.dense.weight"), f32(p + "intermediate.dense.bias")
+            g1, b1 = f32(p + "attention.output.LayerNorm.gamma"), f32(p + "attention.output.LayerNorm.beta")
+            g2, b2 = f32(p + "output.LayerNorm.gamma"), f32(p + "output.LayerNorm.beta")
+            if self.ln_fold:
+                if l > 0:
+                    w_qkv, b_qkv, c, sc = folded(w_qkv, b_qkv, prev_g, prev_b)
+                else:
+                    c, sc = torch.zeros(w_qkv.shape[0], dtype=torch.float32, device=self.device), 1.0
+                L["fold_c_qkv"].append(c)
+                self.fold_scales["qkv"].append(sc)
+                w_ff1, b_ff1, c, sc = folded(w_ff1, b_ff1, g1, b1)
+                L["fold_c_ff1"].append(c)
+                self.fold_scales["ff1"].append(sc)
+                prev_g, prev_b = g2, b2
             if self.corr8:
-                L["w8_qkv"].append(gemm_w8(torch.cat([wq * scale, wk, wv], 0)))
+                L["w8_qkv"].append(gemm_w8(w_qkv))
                 L["w8_ao"].append(gemm_w8(f32(p + "attention.output.dense.weight")))
-                L["w8_ff1"].append(gemm_w8(f32(p + "intermediate.dense.weight")))
+                L["w8_ff1"].append(gemm_w8(w_ff1))
                 L["w8_ff2"].append(gemm_w8(f32(p + "output.dense.weight")))
-            L["w_qkv"].append(gemm_w(torch.cat([wq * scale, wk, wv], 0)))
-            L["b_qkv"].append(torch.cat([bq * scale, bk, bv], 0).contiguous())
+            L["w_qkv"].append(gemm_w(w_qkv))
+            L["b_qkv"].append(b_qkv)
             L["w_ao"].append(gemm_w(f32(p + "attention.output.dense.weight")))
             L["b_ao"].append(f32(p + "attention.output.dense.bias"))
-            L["ln1_g"].append(f32(p + "attention.output.LayerNorm.gamma"))
-            L["ln1_b"].append(f32(p + "attention.output.LayerNorm.beta"))
-            L["w_ff1"].append(gemm_w(f32(p + "intermediate.dense.weight")))
-            L["b_ff1"].append(f32(p + "intermediate.dense.bias"))
+            L["ln1_g"].append(g1)
+            L["ln1_b"].append(b1)
+            L["w_ff1"].append(gemm_w(w_ff1))
+            L["b_ff1"].append(b_ff1)
             L["w_ff2"].append(gemm_w(f32(p + "output.dense.weight")))
             L["b_ff2"].append(f32(p + "output.dense.bias"))
-            L["ln2_g"].append(f32(p + "output.LayerNorm.gamma"))
-            L["ln2_b"].append(f32(p + "output.LayerNorm.beta"))
+            L["ln2_g"].append(g2)
+            L["ln2_b"].append(b2)
         nl = cfg["num_hidden_layers"]
+        if self.ln_fold:       # the output LayerNorms' parameters as two tables: the pooling kernel normalises the rows it reads
+            self.ln2_g_all = torch.stack(self.layers["ln2_g"]).contiguous()
+            self.ln2_b_all = torch.stack(self.layers["ln2_b"]).contiguous()
         self._arrays = {}
         m = hip.BertModelC()
         m.hidden, m.n_heads, m.n_layers, m.intermediate = H, nh, nl, cfg["intermediate_size"]
@@ -131,10 +171,16 @@ class BertEncoderWeights:
                           "(accuracy of the affected products degrades towards the plain f16 mode)" % self._w_absmax)
         for k in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b"):
             setattr(m, k, getattr(self, k).data_ptr())
-        for k in keys + keys8:
+        for k in keys + keys8 + keysf:
             arr = (c_void_p * nl)(*[t.data_ptr() for t in self.layers[k]])
             self._arrays[k] = arr
             setattr(m, k, ctypes.cast(arr, ctypes.POINTER(c_void_p)))
+        if self.ln_fold:
+            m.ln_fold = 1
+            for k in ("qkv", "ff1"):
+                arr = (ctypes.c_float * nl)(*self.fold_scales[k])
+                self._arrays["fold_s_" + k] = arr
+                setattr(m, "fold_s_" + k, ctypes.cast(arr, ctypes.POINTER(ctypes.c_float)))
         self.c_model = m
 
     @property
@@ -371,6 +417,7 @@ class _Buffers:
     def __init__(self):
         self.layers = None
         self.ws = None
+        self.stats = None
 
     def get(self, w, Tp):
         lib = hip.load()
@@ -378,10 +425,18 @@ class _Buffers:
         need_l = w.n_layers * Tp * w.hidden * es                      # bytes
         if self.layers is None or self.layers.numel() < need_l or self.layers.device != w.device:
             self.layers = torch.zeros(need_l, dtype=torch.uint8, device=w.device)
-        need_w = int(lib.ruart_bert_workspace_bytes(ctypes.byref(w.c_model), Tp))
+        fold = getattr(w, "ln_fold", False)
+        need_w = int((lib.ruart_bert_workspace_bytes_folded if fold else lib.ruart_bert_workspace_bytes)(ctypes.byref(w.c_model), Tp))
         if self.ws is None or self.ws.numel() < need_w or self.ws.device != w.device:
             self.ws = torch.zeros(need_w, dtype=torch.uint8, device=w.device)
+        if fold:
+            need_s = w.n_layers * Tp * 2
+            if self.stats is None or self.stats.numel() < need_s or self.stats.device != w.device:
+                self.stats = torch.zeros(need_s, dtype=torch.float32, device=w.device)
         return self.layers[:need_l].view(w.tdtype).view(w.n_layers, Tp, w.hidden), self.ws, need_w
+
+    def stats_for(self, w, Tp):
+        return self.stats[:w.n_layers * Tp * 2].view(w.n_layers, Tp, 2)
 
 
 _buffers = _Buffers()
@@ -396,10 +451,31 @@ def bert_encode(weights, packed, buffers=None):
                          % (packed.max_pos, weights.cfg["max_position_embeddings"]))
     buffers = buffers or _buffers
     layers, ws, ws_bytes = buffers.get(weights, packed.Tp)
+    if getattr(weights, "ln_fold", False):
+        # LayerNorm-folded pass: `layers` holds the PRE-LayerNorm rows of every layer's output, `layers._ln` = ((mu, rstd) per row, the
+        # output LayerNorms' gamma / beta tables) what turns them into the layer outputs - on the fly in the pooling kernel
+        # (_PoolMix), or materialised by layer_outputs() for tests
+        stats = buffers.stats_for(weights, packed.Tp)
+        rc = lib.ruart_bert_forward_folded(ctypes.byref(weights.c_model), ctypes.byref(packed.c_batch), hip.ptr(layers), hip.ptr(stats),
+                                           hip.ptr(ws), ws_bytes, hip.stream_ptr())
+        hip.check(rc, "ruart_bert_forward_folded")
+        layers._ln = (stats, weights.ln2_g_all, weights.ln2_b_all)
+        return layers
     rc = lib.ruart_bert_forward(ctypes.byref(weights.c_model), ctypes.byref(packed.c_batch), hip.ptr(layers), hip.ptr(ws),
                                 ws_bytes, hip.stream_ptr())
     hip.check(rc, "ruart_bert_forward")
     return layers
+
+
+def layer_outputs(layers, n_last=None):
+    """The encoder's layer outputs as the reference keeps them (modeling.py:326-334) from what ``bert_encode`` returned: the tensor itself,
+    or - after a LayerNorm-folded pass - (y - mu) rstd gamma + beta of its pre-LayerNorm rows (a new tensor; tests and tools, not the
+    product path, which normalises inside the pooling kernel)."""
+    ln = getattr(layers, "_ln", None)
+    if ln is None:
+        return layers
+    stats, g, b = ln
+    return (layers - stats[:, :, 0:1]) * stats[:, :, 1:2] * g[:, None, :] + b[:, None, :]
 
 
 from .ops import _ABL_SKIP      # timing diagnostics (refused without RUART_DIAGNOSTICS=1, ops.py)
@@ -410,37 +486,49 @@ class _PoolMix(torch.autograd.Function):
     Models/SDNet.py:91-94)."""
 
     @staticmethod
-    def forward(ctx, layer_w, layers, span_start, span_len, dst_row, n_rows, dtype_code, span_start_last=None):
+    def forward(ctx, layer_w, layers, span_start, span_len, dst_row, n_rows, dtype_code, span_start_last=None, ln_stats=None, ln_g=None,
+                ln_b=None):
         """``span_start_last``: the spans' first rows in the LAST layer's matrix when the encoder left it compacted
-        (PackedTokens.set_last_rows); None = as in every other layer."""
+        (PackedTokens.set_last_rows); None = as in every other layer.  ``ln_stats`` / ``ln_g`` / ``ln_b``: `layers` holds the
+        pre-LayerNorm rows of a folded pass (bert_encode) and the kernel normalises what it reads."""
         lib = hip.load()
         NL, Tp, H = layers.shape
         W = span_start.numel()
         out = torch.zeros(n_rows, H, dtype=torch.float32, device=layers.device)
         lw = layer_w.detach().to(torch.float32).contiguous()
         if W > 0 and "pool" not in _ABL_SKIP:          # (timing diagnostics only, see ops._ABL_SKIP: empty in every product run)
-            rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
-                                         hip.ptr(dst_row), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
+            if ln_stats is not None:
+                rc = lib.ruart_bert_pool_mix_ln(hip.ptr(layers), Tp * H, H, NL, hip.ptr(ln_stats), Tp, hip.ptr(ln_g), hip.ptr(ln_b),
+                                                hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len), hip.ptr(dst_row), hip.ptr(lw),
+                                                hip.ptr(out), H, W, H, hip.stream_ptr())
+            else:
+                rc = lib.ruart_bert_pool_mix(hip.ptr(layers), Tp * H, H, dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
+                                             hip.ptr(dst_row), hip.ptr(lw), hip.ptr(out), H, W, H, hip.stream_ptr())
             hip.check(rc, "ruart_bert_pool_mix")
-        ctx.save_for_backward(layers, span_start, span_len, dst_row, span_start_last)
+        ctx.save_for_backward(layers, span_start, span_len, dst_row, span_start_last, ln_stats, ln_g, ln_b)
         ctx.dtype_code = dtype_code
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = hip.load()
-        layers, span_start, span_len, dst_row, span_start_last = ctx.saved_tensors
+        layers, span_start, span_len, dst_row, span_start_last, ln_stats, ln_g, ln_b = ctx.saved_tensors
         NL, Tp, H = layers.shape
         W = span_start.numel()
         g = torch.zeros(NL, dtype=torch.float32, device=layers.device)
         if W > 0 and "pool" not in _ABL_SKIP:
             grad_out = grad_out.contiguous()
             partial = torch.empty(W * NL, dtype=torch.float32, device=layers.device)
-            rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
-                                             hip.ptr(dst_row), hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H,
-                                             hip.stream_ptr())
+            if ln_stats is not None:
+                rc = lib.ruart_bert_pool_mix_ln_bwd(hip.ptr(layers), Tp * H, H, NL, hip.ptr(ln_stats), Tp, hip.ptr(ln_g), hip.ptr(ln_b),
+                                                    hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len), hip.ptr(dst_row),
+                                                    hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H, hip.stream_ptr())
+            else:
+                rc = lib.ruart_bert_pool_mix_bwd(hip.ptr(layers), Tp * H, H, ctx.dtype_code, NL, hip.ptr(span_start), hip.ptr(span_start_last), hip.ptr(span_len),
+                                                 hip.ptr(dst_row), hip.ptr(grad_out), H, hip.ptr(partial), hip.ptr(g), W, H,
+                                                 hip.stream_ptr())
             hip.check(rc, "ruart_bert_pool_mix_bwd")
-        return g, None, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None, None, None, None
 
 
 def word_spans(packed, group, offsets, word_mask, offsets_arr=None):
@@ -496,7 +584,9 @@ class Bert(nn.Module):
                                                                               self.bert_layer, self.bert_dim))
         from . import precision_of
         precision = precision_of(opt, cfg["hidden_size"] if cfg["intermediate_size"] % 256 == 0 else 1)
-        self.weights = BertEncoderWeights(state, cfg, self._device, precision)
+        # LayerNorms folded into the projections (fp16c; csrc/gemm_corr.hip, CorrFold): on unless opt['bert_ln_fold'] / RUART_LN_FOLD say 0
+        fold = bool(int(opt.get("bert_ln_fold", os.environ.get("RUART_LN_FOLD", 1))))
+        self.weights = BertEncoderWeights(state, cfg, self._device, precision, ln_fold=fold)
         self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
         self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path
         self.pack = not opt.get("bert_no_pack", False)
@@ -665,7 +755,8 @@ class Bert(nn.Module):
             from .bert_train import pool_mix
             out = pool_mix(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows)
         else:
-            out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, hip.dtype_code(layers))
+            ln = getattr(layers, "_ln", None) or (None, None, None)
+            out = _PoolMix.apply(layer_w, layers, desc[:W], desc[W:2 * W], desc[2 * W:], rows, hip.dtype_code(layers), None, *ln)
         N, Lw = word_mask.shape
         return out.view(N, Lw, self.weights.hidden)
 

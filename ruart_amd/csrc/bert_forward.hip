@@ -152,9 +152,112 @@ static int bert_forward_corr(const ruart_bert_model* m, const ruart_bert_batch* 
   return 0;
 }
 
+// ---- the fp16c encoder with its LayerNorms folded into the projections around them (gemm_corr.hip, CorrFold) -----------------------
+// Per layer: QKV (FOLD of the previous layer's output LayerNorm; layer 0 reads the materialised embedding rows), attention, attention
+// output dense (kind 3: y1 = ctx Wo^T + b + LN2_{l-1}(y2_{l-1}), written fp32 + split + row partials), intermediate dense (FOLD of
+// LN1_l, GELU, split), output dense (kind 3: y2 = ffn W2^T + b + LN1_l(y1)).  Five launches per layer instead of seven; no launch reads
+// or writes a normalised row.  layers_pre[l] = y2 of layer l (PRE-LayerNorm), ln_stats[l][row] = (mu, rstd) of that row: the layer's
+// output is (y2 - mu) rstd gamma2_l + beta2_l, which ruart_bert_pool_mix_ln applies on the fly.
+static size_t fold_extra_bytes(size_t R, size_t H, int n_layers) {
+  (void)H;
+  return align_up(R * 32, 256) * ((size_t)n_layers + 2);      // partA, the gathered partials of the last layer's residual, partB per layer
+}
+extern "C" size_t ruart_bert_workspace_bytes_folded(const ruart_bert_model* m, int n_rows) {
+  return corr_workspace_bytes((size_t)n_rows, (size_t)m->hidden, (size_t)m->intermediate) + fold_extra_bytes((size_t)n_rows, (size_t)m->hidden, m->n_layers);
+}
+
+
+extern "C" int ruart_bert_forward_folded(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_pre, float* ln_stats, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  RUART_ENTRY();
+  const int H = m->hidden, I = m->intermediate, R = b->n_rows, NL = m->n_layers;
+  if (!m->corr8 || !m->ln_fold || m->dtype != RUART_DT_F16 || !m->fold_c_qkv || !m->fold_c_ff1 || !m->fold_s_qkv || !m->fold_s_ff1)
+    return (int)hipErrorInvalidValue;
+  if (R <= 0 || R % 256 || H % 256 || I % 256 || b->n_long_blocks != 0 || b->n_blocks <= 0 || b->n_tokens > R || b->n_tokens <= 0 ||
+      m->n_heads * 64 != H || !layers_pre || !ln_stats)
+    return (int)hipErrorInvalidValue;
+  if (!m->w8_qkv || !m->w8_ao || !m->w8_ff1 || !m->w8_ff2) return (int)hipErrorInvalidValue;
+  if (workspace_bytes < ruart_bert_workspace_bytes_folded(m, R)) return (int)hipErrorInvalidValue;
+  const int np = H / 256;
+  Carve c{(char*)workspace, 0};
+  float* x32 = (float*)c.take((size_t)R * H * 4);
+  void* x16 = c.take((size_t)R * H * 2);
+  void* x8 = c.take((size_t)R * H * 2);
+  float* qkv = (float*)c.take((size_t)R * 3 * H * 4);
+  void* ctx16 = c.take((size_t)R * H * 2);
+  void* ctx8 = c.take((size_t)R * H * 2);
+  float* pre = (float*)c.take((size_t)R * H * 4);
+  c.take((size_t)R * H * 4);                          // (the unfolded pass's mid32: the two forms share one carving of the common part)
+  void* mid16 = c.take((size_t)R * H * 2);
+  void* mid8 = c.take((size_t)R * H * 2);
+  void* ffn16 = c.take((size_t)R * I * 2);
+  void* ffn8 = c.take((size_t)R * I * 2);
+  float* partA = (float*)c.take((size_t)R * 32);       // row partials: four (sum, sumsq) slots per row, np of them used
+  float* partG = (float*)c.take((size_t)R * 32);
+  float* partB = (float*)c.take(0);                    // [n_layers][R][4][2] (R % 256 == 0: contiguous)
+  const size_t partB_stride = (size_t)R * 8;
+  hipStream_t s = (hipStream_t)stream;
+  const float eps = m->ln_eps;
+  int rc = ruart_bert_embed_ln_split(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, eps, x32, x16, x8, H, R,
+                                     H, stream);
+  if (rc) return rc;
+  ruart_prof_real_rows = b->n_tokens;
+  const int n_last = last_layer_rows(m, b);
+  const float* res = x32;                 // residual rows of the attention-output dense: materialised (layer 0) or y2 of the layer before
+  const float* res_part = nullptr;
+  for (int l = 0; l < NL; ++l) {
+    float* out = (float*)layers_pre + (size_t)l * R * H;
+    float* pB = partB + (size_t)l * partB_stride;
+    const float* pPrev = l ? partB + (size_t)(l - 1) * partB_stride : nullptr;
+    if ((rc = ruart_gemm_16c_nt_fold(x16, x8, H, m->w_qkv[l], m->w8_qkv[l], H, m->b_qkv[l], 0, pPrev, np, l ? m->fold_c_qkv[l] : nullptr,
+                                     l ? m->fold_s_qkv[l] : 1.f, nullptr, 0, nullptr, 0, nullptr, nullptr, qkv, 3 * H, nullptr, nullptr, nullptr, R,
+                                     3 * H, H, H, eps, stream)))
+      return rc;
+    if ((rc = ruart_bert_attention_split(qkv, 3 * H, ctx16, ctx8, H, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1,
+                                         b->tok_lo, b->tok_hi, b->key_bias, stream)))
+      return rc;
+    int Rl = R;
+    const void *a16 = ctx16, *a8 = ctx8;
+    if (n_last > 0 && l == NL - 1) {
+      // last layer on the pooled rows only (bert_forward_corr): context rows -> x16 / x8, residual rows (y2 of the layer before, raw) ->
+      // the QKV buffer, their partials -> partG; the pad rows of the compacted residual are zeroed (their stale partials stay finite)
+      Rl = (n_last + 255) / 256 * 256;
+      if ((rc = ruart_rows_gather(b->last_rows, n_last, ctx16, (long long)H * 2, x16, (long long)H * 2, H * 2, ctx8, (long long)H * 2, x8,
+                                  (long long)H * 2, H * 2, res, (long long)H * 4, qkv, (long long)H * 4, H * 4, stream)))
+        return rc;
+      if ((rc = ruart_rows_gather(b->last_rows, n_last, res_part, 32, partG, 32, 32, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, stream)))
+        return rc;
+      if (Rl > n_last && hipMemsetAsync(qkv + (size_t)n_last * H, 0, (size_t)(Rl - n_last) * H * 4, s) != hipSuccess) return (int)hipGetLastError();
+      a16 = x16;
+      a8 = x8;
+      res = qkv;
+      res_part = partG;
+      ruart_prof_real_rows = n_last;
+    }
+    // y1 -> pre (fp32), mid16 / mid8 (split), partA
+    if ((rc = ruart_gemm_16c_nt_fold(a16, a8, H, m->w_ao[l], m->w8_ao[l], H, m->b_ao[l], 3, nullptr, 0, nullptr, 1.f, res, H, res_part, np,
+                                     l ? m->ln2_g[l - 1] : nullptr, l ? m->ln2_b[l - 1] : nullptr, pre, H, mid16, mid8, partA, Rl, H, H, H, eps,
+                                     stream)))
+      return rc;
+    if ((rc = ruart_gemm_16c_nt_fold(mid16, mid8, H, m->w_ff1[l], m->w8_ff1[l], H, m->b_ff1[l], 2, partA, np, m->fold_c_ff1[l], m->fold_s_ff1[l],
+                                     nullptr, 0, nullptr, 0, nullptr, nullptr, ffn16, I, nullptr, ffn8, nullptr, Rl, I, H, H, eps, stream)))
+      return rc;
+    // y2 -> layers_pre[l] (fp32), the next layer's operand (split; the last layer's goes to the dead context buffers), partB[l]
+    if ((rc = ruart_gemm_16c_nt_fold(ffn16, ffn8, I, m->w_ff2[l], m->w8_ff2[l], I, m->b_ff2[l], 3, nullptr, 0, nullptr, 1.f, pre, H, partA, np,
+                                     m->ln1_g[l], m->ln1_b[l], out, H, Rl == R ? x16 : ctx16, Rl == R ? x8 : ctx8, pB, Rl, H, I, H, eps, stream)))
+      return rc;
+    res = out;
+    res_part = pB;
+  }
+  ruart_prof_real_rows = 0;
+  // (mu, rstd) of every layer's rows for the consumers of the layer outputs: one launch over [n_layers][R]
+  return ruart_rows_stats_finish(partB, np, NL * R, 1.0f / (float)H, eps, ln_stats, stream);
+}
+
 extern "C" int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   RUART_ENTRY();
+  if (m->ln_fold) return (int)hipErrorInvalidValue;       // this model's QKV / intermediate weights are the folded forms: ruart_bert_forward_folded
   const int H = m->hidden, I = m->intermediate, R = b->n_rows, dt = m->dtype;
   if (R % 128 || b->n_tokens > R || b->n_tokens <= 0 || H % 64 || m->n_heads * 64 != H) return (int)hipErrorInvalidValue;
   if (dt != RUART_DT_F32 && (H % 128 || I % 128)) return (int)hipErrorInvalidValue;

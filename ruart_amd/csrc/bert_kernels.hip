@@ -1433,6 +1433,186 @@ extern "C" int ruart_bert_attention(const void* qkv, int ld, void* ctx, int ldc,
   return 0;
 }
 
+// ---- pooling over PRE-LayerNorm layer rows (the folded encoder pass, ruart_bert_forward_folded): layer l's output row is
+//   (y - mu) rstd gamma_l + beta_l   with (mu, rstd) = stats[l][row], gamma / beta [NL][H]
+// and is formed on the fly - per loaded element one fma with the row's (rstd, -mu rstd) and one with the layer's gamma; beta enters once
+// per layer (the mean over a word's pieces of a constant).  fp32 rows, H % 256 == 0; otherwise the column-split kernels above.
+struct PoolLN {
+  const float2* stats;       // [NL][stats_stride] (mu, rstd)
+  size_t stats_stride;
+  const float* g;            // [NL][H]
+  const float* b;
+};
+__global__ __launch_bounds__(256) void pool_mix_cols_ln_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl, int NL,
+                                                               const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                               const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                               const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H,
+                                                               PoolLN ln) {
+  constexpr int LB = 6;
+  const int w = blockIdx.x;
+  const int st = span_start[w], n = span_len[w];
+  const int st_last = span_start_last ? span_start_last[w] : st;
+  const float inv = 1.0f / (float)n;
+  const int col = threadIdx.x * 4;                       // blockDim.x = H / 4
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  auto body = [&](auto two_tag) {
+    constexpr bool TWO = decltype(two_tag)::value;
+    for (int lb = 0; lb < NL; lb += LB) {
+      f32x4_t v[LB][TWO ? 2 : 1], g[LB], be[LB];
+      float2 sa[LB][TWO ? 2 : 1];
+      float wgt[LB];
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int l = min(lb + j, NL - 1);
+        wgt[j] = (lb + j < NL) ? wl[l] : 0.f;
+        const int r0 = (l == NL - 1 ? st_last : st);
+        const float* base = layers + (size_t)l * layer_stride + (size_t)r0 * ldl + col;
+        v[j][0] = load4_stream(base);
+        sa[j][0] = ln.stats[(size_t)l * ln.stats_stride + r0];
+        if (TWO) {
+          v[j][TWO ? 1 : 0] = load4_stream(base + (size_t)ldl);
+          sa[j][TWO ? 1 : 0] = ln.stats[(size_t)l * ln.stats_stride + r0 + 1];
+        }
+        g[j] = load4(ln.g + (size_t)l * H + col);
+        be[j] = load4(ln.b + (size_t)l * H + col);
+      }
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        f32x4_t x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[r] = (v[j][0][r] - sa[j][0].x) * sa[j][0].y;
+          if (TWO) x[r] += (v[j][TWO ? 1 : 0][r] - sa[j][TWO ? 1 : 0].x) * sa[j][TWO ? 1 : 0].y;
+        }
+        acc += (x * g[j]) * (wgt[j] * inv) + be[j] * wgt[j];
+      }
+      if (TWO && n > 2) {
+        for (int j = 0; j < LB && lb + j < NL; ++j) {
+          const int r0 = (lb + j == NL - 1 ? st_last : st);
+          const float* base = layers + (size_t)(lb + j) * layer_stride + (size_t)r0 * ldl + col;
+          for (int p = 2; p < n; ++p) {
+            const float2 s2 = ln.stats[(size_t)(lb + j) * ln.stats_stride + r0 + p];
+            const f32x4_t y = load4_stream(base + (size_t)p * ldl);
+            f32x4_t x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = (y[r] - s2.x) * s2.y;
+            acc += (x * g[j]) * (wgt[j] * inv);
+          }
+        }
+      }
+    }
+  };
+  if (n > 1) body(std::true_type{});
+  else body(std::false_type{});
+  store4(out + (size_t)dst_row[w] * ldo + col, acc);
+}
+
+// d(loss)/d(wl[l]) partial of one word over pre-LayerNorm rows: <grad_out[dst_row[w]], gamma_l (mean of the word's normalised rows) + beta_l>
+template <int NG>
+__global__ __launch_bounds__(256) void pool_mix_bwd_ln_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl, int NL,
+                                                              const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                              const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                              const float* __restrict__ gout, int ldg, float* __restrict__ partial, int W, int H,
+                                                              PoolLN ln) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x;
+  const int st = span_start[w], n = span_len[w];
+  const int st_last = span_start_last ? span_start_last[w] : st;
+  const float inv = 1.0f / (float)n;
+  const int per = (NL + 3) >> 2;
+  const int l0 = wv * per, l1 = min(NL, l0 + per);
+  f32x4_t gv[NG];
+  int col[NG];
+  const float* g = gout + (size_t)dst_row[w] * ldg;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    col[i] = (i * 64 + lane) * 4;                        // H % 256 == 0: every lane inside the row
+    gv[i] = load4(g + col[i]);
+  }
+  for (int l = l0; l < l1; ++l) {
+    const int r0 = (l == NL - 1 ? st_last : st);
+    const float* base = layers + (size_t)l * layer_stride + (size_t)r0 * ldl;
+    f32x4_t x[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) x[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < n; ++p) {
+      const float2 s2 = ln.stats[(size_t)l * ln.stats_stride + r0 + p];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const f32x4_t y = load4_stream(base + (size_t)p * ldl + col[i]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[i][r] += (y[r] - s2.x) * s2.y;
+      }
+    }
+    f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const f32x4_t gg = load4(ln.g + (size_t)l * H + col[i]), bb = load4(ln.b + (size_t)l * H + col[i]);
+      s4 += ((x[i] * gg) * inv + bb) * gv[i];
+    }
+    const float d = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+    if (lane == 0) partial[(size_t)w * NL + l] = d;
+  }
+}
+
+// (mu, rstd) of `rows` rows from their partial (sum, sumsq) slots (gemm_corr.hip: four slots of 8 bytes per row, the first np used)
+__global__ __launch_bounds__(256) void rows_stats_finish_kernel(const float* __restrict__ part, int np, int rows, float inv_h, float eps,
+                                                                float2* __restrict__ stats) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const f32x4_t a = load4(part + (size_t)r * 8), b = load4(part + (size_t)r * 8 + 4);
+  const float ps[4] = {a[0], a[2], b[0], b[2]}, pq[4] = {a[1], a[3], b[1], b[3]};
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < np) {
+      s += ps[k];
+      q += pq[k];
+    }
+  const float mu = s * inv_h;
+  const float var = fmaxf(q * inv_h - mu * mu, 0.f);
+  stats[r] = make_float2(mu, 1.0f / sqrtf(var + eps));
+}
+extern "C" int ruart_rows_stats_finish(const float* part, int np, int rows, float inv_h, float eps, float* stats, void* stream) {
+  RUART_ENTRY();
+  if (!part || !stats || np <= 0 || np > 4 || rows <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(rows_stats_finish_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, part, np, rows, inv_h, eps,
+                     (float2*)stats);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
+                                      long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
+                                      const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out,
+                                      int ldo, int n_words, int H, void* stream) {
+  RUART_ENTRY();
+  if (H % 256 || H <= 0 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0 || !ln_stats || !ln_gamma || !ln_beta)
+    return (int)hipErrorInvalidValue;
+  const PoolLN ln{(const float2*)ln_stats, (size_t)stats_stride, ln_gamma, ln_beta};
+  hipLaunchKernelGGL(pool_mix_cols_ln_kernel, dim3(n_words), dim3(H / 4), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, n_layers,
+                     span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ruart_bert_pool_mix_ln_bwd(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
+                                          long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
+                                          const int* span_start_last, const int* span_len, const int* dst_row, const float* grad_out, int ldg,
+                                          float* partial_ws, float* grad_layer_w, int n_words, int H, void* stream) {
+  RUART_ENTRY();
+  if (H % 256 || H <= 0 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0 || !ln_stats || !ln_gamma || !ln_beta)
+    return (int)hipErrorInvalidValue;
+  const PoolLN ln{(const float2*)ln_stats, (size_t)stats_stride, ln_gamma, ln_beta};
+#define POOL(NG) hipLaunchKernelGGL((pool_mix_bwd_ln_kernel<NG>), dim3(n_words), dim3(256), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, ln)
+  switch (H / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
+#undef POOL
+  RUART_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, partial_ws, n_words, n_layers, grad_layer_w);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
 static int g_pool_cols = 1;        // 1: column-split pooling kernel where H % 256 == 0 (default); 0: the layer-split form (A/B runs)
 extern "C" int ruart_bert_pool_set_variant(int cols) {
   g_pool_cols = cols ? 1 : 0;

@@ -72,10 +72,67 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
 #ifndef RUART_NT_EPI
 #define RUART_NT_EPI 0
 #endif
-template <int EPI>
+
+// ---- LayerNorm folded into the projections around it (ruart_bert_forward_folded, bert_forward.hip) --------------------------------
+// The encoder's LayerNorm pass (Models/Bert/modeling.py:164-168) reads a fp32 row and writes it back three times over (fp32 + f16 +
+// two e4m3 bytes): 12 bytes per element of pure traffic between two GEMMs.  In the folded form nobody materialises a normalised row:
+//   * the PRODUCER of the pre-LayerNorm row y (attention-output / output dense, EPI 3) writes y itself - fp32 and in the split operand
+//     form - plus, per row and per 256-column tile, the partial (sum, sum of squares) of the row: part[row][4][2] (slot = tile);
+//   * the CONSUMER projection (QKV / intermediate dense, FOLD) runs on y with weights W' = W diag(gamma) 2^-s prepared once, and its
+//     epilogue finishes the normalisation per output element:
+//         LN(y) W^T + b  =  rstd_r 2^s (y W'^T - mu_r c) + d,     c_j = sum_i W'_ji,   d_j = b_j + sum_i beta_i W_ji
+//     (mu_r, rstd_r from the row's partials; c and d are vectors prepared with the weights);
+//   * whoever needs the normalised row as a RESIDUAL (the next EPI 3 product) or as a layer output (the pooling kernel) applies
+//     (y - mu) rstd gamma + beta to the fp32 y it reads anyway.
+// Row statistics are one-pass sums in fp32 over 768-1024 elements (var = E[y^2] - mu^2, clamped at 0): |mu| << sigma on these rows.
+struct CorrFold {
+  const float* in_part;    // FOLD: partials of the A rows, [M][4][2], the first in_np slots used
+  const float* colc;       // FOLD: c [N]
+  int in_np;
+  float wscale;            // FOLD: 2^s
+  const float* rs_part;    // EPI 3: partials of the residual rows [M][4][2] (rs_np used); NULL = the residual rows are taken as they are
+  const float* rs_g;       // EPI 3: gamma, beta [N] of the residual's LayerNorm
+  const float* rs_b;
+  int rs_np;
+  float* out_part;         // EPI 3: [M][4][2] partials of the rows written (slot = column tile, N / 256 <= 4 of them)
+  void* C16;               // EPI 3: the written rows in the split operand form (C16 f16 [M][ldc], C8 e4m3 [M][2 ldc])
+  float inv_h;             // 1 / (row length the partials cover)
+  float eps;
+};
+constexpr int kFoldSlots = 4;                // partial slots per row (32 bytes: rows of partials can be gathered 16 bytes at a time); N <= 1024
+constexpr int kFoldStatsOff = 72 * 1024;    // LDS: (mu, rstd) of the tile's 256 rows, beyond the epilogue's staging image (68 KB)
+constexpr int kFoldPartOff = 76 * 1024;     // LDS: [4 column groups][256 rows] (sum, sumsq) of an EPI 3 tile
+
+// (mu, rstd) of the tile's rows m0 .. m0 + 255 from their partials -> LDS; every thread of the workgroup calls it
+__device__ __forceinline__ void fold_row_stats(char* smem, const float* __restrict__ part, int np, int m0, float inv_h, float eps) {
+  if (threadIdx.x < 256) {
+    const float* p = part + (size_t)(m0 + threadIdx.x) * (2 * kFoldSlots);
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < np; ++k) {
+      s += p[2 * k];
+      q += p[2 * k + 1];
+    }
+    const float mu = s * inv_h;
+    const float var = fmaxf(q * inv_h - mu * mu, 0.f);
+    reinterpret_cast<float2*>(smem + kFoldStatsOff)[threadIdx.x] = make_float2(mu, 1.0f / sqrtf(var + eps));
+  }
+  __syncthreads();
+}
+// sum over the 16 lanes of a DPP row (the lanes that share a tile row in the epilogue); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+  return v;
+}
+
+// EPI: 0 fp32 out; 1 fp32 out + fp32 residual; 2 GELU, split out; 3 fp32 out + (LayerNorm of the) residual, split out, row partials.
+// FOLD (EPI 0 / 2): the A rows are pre-LayerNorm rows, see CorrFold.
+template <int EPI, bool FOLD = false>
 __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, const float* __restrict__ bias,
                                               const float* __restrict__ R, int ldr, void* __restrict__ C, int ldc,
-                                              unsigned char* __restrict__ C8, int N, int hh0 = 0, int hh1 = 4) {
+                                              unsigned char* __restrict__ C8, int N, int hh0, int hh1, const CorrFold& f) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
@@ -85,6 +142,24 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
   f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
   const int ncol = n0 + wn * 64 + rcol;
   if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
+  f32x4_t cv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, ev = {0.f, 0.f, 0.f, 0.f};
+  bool res_ln = false;
+  float wsc = 1.f;
+  if constexpr (FOLD) {
+    fold_row_stats(smem, f.in_part, f.in_np, m0, f.inv_h, f.eps);
+    cv = *reinterpret_cast<const f32x4_t*>(f.colc + ncol);
+    wsc = f.wscale;
+  }
+  if constexpr (EPI == 3) {
+    res_ln = f.rs_part != nullptr;
+    if (res_ln) {
+      fold_row_stats(smem, f.rs_part, f.rs_np, m0, f.inv_h, f.eps);
+      gv = *reinterpret_cast<const f32x4_t*>(f.rs_g + ncol);
+      ev = *reinterpret_cast<const f32x4_t*>(f.rs_b + ncol);
+    }
+  }
+  const float2* rstat = reinterpret_cast<const float2*>(smem + kFoldStatsOff) + wm * 128 + rrow;
+  float2* rpart = reinterpret_cast<float2*>(smem + kFoldPartOff) + wn * 256 + wm * 128 + rrow;
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) {
     if (hh < hh0 || hh >= hh1) continue;           // (the fix-up kernel runs one 32-row pass per workgroup)
@@ -95,14 +170,47 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
         *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
     f32x4_t v[8], res[8];
     const int mrow = m0 + wm * 128 + hh * 32 + rrow;
-    if (EPI == 1) {
+    if (EPI == 1 || EPI == 3) {
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr)
         res[rr] = (RUART_NT_EPI & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(R + (size_t)(mrow + rr * 4) * ldr + ncol))
                                      : load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
     }
+    if constexpr (FOLD) {
+      // v = rstd 2^s (acc - mu c) + d   (d arrives as `bias`)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+      for (int rr = 0; rr < 8; ++rr) {
+        const float2 st = rstat[hh * 32 + rr * 4];
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4);
+        const float sc = st.y * wsc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rr][r] = fmaf(sc, fmaf(-st.x, cv[r], a[r]), bv[r]);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    }
+    if constexpr (EPI == 3) {
+      // y = acc + bias + residual (the residual rows normalised on the way in when they are pre-LayerNorm rows); out: y fp32, y split,
+      // the row's (sum, sumsq) over this wave's 64 columns -> LDS
+      f16_t* C16 = reinterpret_cast<f16_t*>(f.C16);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const size_t row = (size_t)(mrow + rr * 4);
+        if (res_ln) {
+          const float2 st = rstat[hh * 32 + rr * 4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[rr][r] = fmaf(gv[r], (res[rr][r] - st.x) * st.y, ev[r]);
+        }
+        v[rr] += res[rr];
+        store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+        store_split4(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+        const float s1 = row16_sum((v[rr][0] + v[rr][1]) + (v[rr][2] + v[rr][3]));
+        const float s2 = row16_sum(fmaf(v[rr][0], v[rr][0], v[rr][1] * v[rr][1]) + fmaf(v[rr][2], v[rr][2], v[rr][3] * v[rr][3]));
+        if ((lane & 15) == 0) rpart[hh * 32 + rr * 4] = make_float2(s1, s2);
+      }
+      continue;
+    }
 #ifndef RUART_ABL_NOGELU            // (diagnostic builds: the epilogue without its GELU / without its fp8 stores)
     if (EPI == 2) {
 #pragma unroll
@@ -123,6 +231,15 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
         __builtin_nontemporal_store(v[rr], reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(C) + row * ldc + ncol));
       else
         store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+    }
+  }
+  if constexpr (EPI == 3) {
+    // the four column groups of a row in a fixed order -> this tile's partial of the row
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const float2* pp = reinterpret_cast<const float2*>(smem + kFoldPartOff) + threadIdx.x;
+      const float2 a = pp[0], b = pp[256], c = pp[512], d = pp[768];
+      reinterpret_cast<float2*>(f.out_part)[(size_t)(m0 + threadIdx.x) * kFoldSlots + n0 / 256] = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
     }
   }
 }
@@ -151,13 +268,13 @@ __device__ __forceinline__ void corr_tile_of(int id, int ntm, int ntn, int order
 #define RUART_VGPR_ATTR
 #endif
 // EPI: 0 fp32 out; 1 fp32 out + fp32 residual; 2 GELU, split out (C = f16 rows, C8 = fp8 rows of 2N bytes)
-template <int EPI>
+template <int EPI, bool FOLD = false>
 __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(const char* __restrict__ A16, const char* __restrict__ A8, int pitch_a,
                                                             const char* __restrict__ W16, const char* __restrict__ W8, int pitch_w,
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             void* __restrict__ C, int ldc, unsigned char* __restrict__ C8, int M, int N,
                                                             int K, int order, int n8, int o8, int n_full, int S,
-                                                            float* __restrict__ slabs) {
+                                                            float* __restrict__ slabs, const CorrFold f) {
   constexpr int kHalf = 128 * CBKB;              // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -362,7 +479,7 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
       for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * 8 + j) * 512 + tid) * 4) = acc[i][j];
     return;
   }
-  corr_epilogue<EPI>(acc, smem, m0, n0, bias, R, ldr, C, ldc, C8, N);
+  corr_epilogue<EPI, FOLD>(acc, smem, m0, n0, bias, R, ldr, C, ldc, C8, N, 0, 4, f);
 }
 
 // Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices IN SLICE ORDER (deterministic), then the
@@ -408,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_fixup(const float* __restrict
         }
     }
   }
-  corr_epilogue<EPI>(acc, smem, tm * CBM, tn * CBN, bias, R, ldr, C, ldc, C8, N, hh, hh + 1);
+  corr_epilogue<EPI>(acc, smem, tm * CBM, tn * CBN, bias, R, ldr, C, ldc, C8, N, hh, hh + 1, CorrFold{});
 #undef TILE_OF
 }
 
@@ -453,10 +570,10 @@ extern "C" size_t ruart_gemm_16c_tail_ws_bytes(int M, int N, int K, int cus) {
   return (size_t)p.r * p.S * CBM * CBN * sizeof(float);
 }
 
-template <int EPI>
+template <int EPI, bool FOLD = false>
 static void launch_corr(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
                         const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int corr, void* tail_ws,
-                        size_t tail_ws_bytes, int cus, hipStream_t s) {
+                        size_t tail_ws_bytes, int cus, hipStream_t s, const CorrFold& fold = CorrFold{}) {
   constexpr int lds = 2 * 2 * CBM * CBKB;                // 128 KB
   const int nt = K / 64;
   const int n8 = corr == 3 ? nt : (corr ? nt / 2 : 0), o8 = corr == 2 ? nt / 2 : 0;
@@ -466,12 +583,12 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
     p = corr_tail_plan(tiles, 2 * nt, cus);
     if ((size_t)p.r * p.S * CBM * CBN * sizeof(float) > tail_ws_bytes) p = TailPlan{tiles, 0, 0};
   }
-  auto kern = gemm_16c_nt_256p8<EPI>;
+  auto kern = gemm_16c_nt_256p8<EPI, FOLD>;
   static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)done;
   hipLaunchKernelGGL(kern, dim3(p.n_full + p.r * p.S), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
                      (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, order, n8, o8, p.n_full, p.S,
-                     (float*)tail_ws);
+                     (float*)tail_ws, fold);
   if (p.r > 0) {
     constexpr int flds = 8 * 32 * 272;                    // the epilogue's staging image
     auto fix = gemm_16c_fixup<EPI>;
@@ -508,6 +625,47 @@ extern "C" int ruart_gemm_16c_nt_ws(const void* A16, const void* A8, int lda, co
     launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
   else
     launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
+  ruart_prof_end_(rec, s);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
+// The projections of the LayerNorm-folded encoder pass (CorrFold above; ruart_bert_forward_folded).  Single launch, both correction
+// products.  kind 0: C fp32 = rstd 2^s (A W'^T - mu c) + d (QKV; `bias` = d);  kind 2: the same, then GELU, split out (C f16, C8);
+// kind 3: y = A W^T + bias + residual - the residual rows normalised with (res_part, res_gamma, res_beta) when res_part != NULL -,
+// out: C fp32, C16 / C8 split, out_part[M][4][2] (N <= 1024).  Partials: four (sum, sumsq) slots per row.  `in_part` NULL with kind 0 / 2 = the plain product (rows already normalised).
+extern "C" int ruart_gemm_16c_nt_fold(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias,
+                                      int kind, const float* in_part, int in_np, const float* colc, float wscale, const float* residual,
+                                      int ldr, const float* res_part, int res_np, const float* res_gamma, const float* res_beta, void* C,
+                                      int ldc, void* C16, void* C8, float* out_part, int M, int N, int K, int stat_len, float eps,
+                                      void* stream) {
+  RUART_ENTRY();
+  if (M <= 0 || M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
+  if (!A16 || !A8 || !W16 || !W8 || !C || stat_len <= 0) return (int)hipErrorInvalidValue;
+  if (kind == 3) {
+    if (!residual || !C16 || !C8 || !out_part || ldc < N || N > 256 * kFoldSlots || res_np > kFoldSlots || (res_part && (!res_gamma || !res_beta || res_np <= 0))) return (int)hipErrorInvalidValue;
+  } else if (kind == 0 || kind == 2) {
+    if (in_part && (!colc || in_np <= 0 || in_np > kFoldSlots)) return (int)hipErrorInvalidValue;
+    if (kind == 2 ? (!C8 || ldc < N) : (C8 != nullptr)) return (int)hipErrorInvalidValue;
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  CorrFold f{};
+  f.in_part = in_part; f.colc = colc; f.in_np = in_np; f.wscale = wscale;
+  f.rs_part = res_part; f.rs_g = res_gamma; f.rs_b = res_beta; f.rs_np = res_np;
+  f.out_part = out_part; f.C16 = C16; f.inv_h = 1.0f / (float)stat_len; f.eps = eps;
+  void* rec = ruart_prof_begin_(s, M, N, K);
+  if (kind == 3)
+    launch_corr<3>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, C8, M, N, K, 3, nullptr, 0, 0, s, f);
+  else if (kind == 2 && in_part)
+    launch_corr<2, true>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, 3, nullptr, 0, 0, s, f);
+  else if (kind == 2)
+    launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, 3, nullptr, 0, 0, s);
+  else if (in_part)
+    launch_corr<0, true>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, 3, nullptr, 0, 0, s, f);
+  else
+    launch_corr<0>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, nullptr, M, N, K, 3, nullptr, 0, 0, s);
   ruart_prof_end_(rec, s);
   RUART_CHECK_LAUNCH();
   return 0;

@@ -33,7 +33,8 @@ class BertModelC(Structure):
                 ("w_ff2", POINTER(c_void_p)), ("b_ff2", POINTER(c_void_p)),
                 ("ln2_g", POINTER(c_void_p)), ("ln2_b", POINTER(c_void_p)), ("f32_gemm", c_int), ("corr8", c_int),
                 ("w8_qkv", POINTER(c_void_p)), ("w8_ao", POINTER(c_void_p)), ("w8_ff1", POINTER(c_void_p)), ("w8_ff2", POINTER(c_void_p)),
-                ("tail_cus", c_int)]
+                ("tail_cus", c_int), ("ln_fold", c_int), ("fold_c_qkv", POINTER(c_void_p)), ("fold_c_ff1", POINTER(c_void_p)),
+                ("fold_s_qkv", POINTER(c_float)), ("fold_s_ff1", POINTER(c_float))]
 
 
 class X3TnProblemC(Structure):
@@ -104,6 +105,12 @@ _SIGNATURES = {
     "ruart_cast_f32_to_16": (_I, [_P, _P, _I, _LL, _F, _P]),
     "ruart_bert_workspace_bytes": (c_size_t, [POINTER(BertModelC), _I]),
     "ruart_bert_forward": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, c_size_t, _P]),
+    "ruart_bert_workspace_bytes_folded": (c_size_t, [POINTER(BertModelC), _I]),
+    "ruart_bert_forward_folded": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, _P, c_size_t, _P]),
+    "ruart_gemm_16c_nt_fold": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ruart_rows_stats_finish": (_I, [_P, _I, _I, _F, _F, _P, _P]),
+    "ruart_bert_pool_mix_ln": (_I, [_P, _LL, _I, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_pool_mix_ln_bwd": (_I, [_P, _LL, _I, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_attn_set_prefetch": (_I, [_I]),

@@ -443,7 +443,8 @@ class SDNet(nn.Module):
             s_, l_, dst, rows, s_last = bi.spans[g]
             if trainable:
                 return bert_train.pool_words(mixed, s_, l_, dst, rows, n_pieces=bi.span_pieces[g])
-            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last)
+            ln = getattr(layers, "_ln", None) or (None, None, None)      # a LayerNorm-folded encoder pass: the kernel normalises what it reads
+            return _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last, *ln)
 
         def front(items, idx, mix):
             words, raw = self._embed_items(items, idx, mix)

@@ -344,18 +344,23 @@ def _bert_case(golden_dir, name):
 
 @pytest.mark.parametrize("name", ["bert_small", "bert_base"])
 @pytest.mark.parametrize("precision,pack,tol", [("fp32", True, 5e-5), ("fp32", False, 5e-5), ("bf16", True, 6e-2), ("fp16", True, 1.5e-2), ("fp16", False, 1.5e-2),
-                                                ("x3", True, 3e-4), ("fp16c", True, 6e-4), ("fp16c", False, 6e-4)])
+                                                ("x3", True, 3e-4), ("fp16c", True, 6e-4), ("fp16c", False, 6e-4),
+                                                ("fp16c-fold", True, 6e-4), ("fp16c-fold", False, 6e-4)])
 def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol):
-    """Whole encoder through ruart_bert_forward vs the reference's own layer outputs (gen_golden.py)."""
-    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode
+    """Whole encoder through ruart_bert_forward (fp16c-fold: ruart_bert_forward_folded, the LayerNorms folded into the projections;
+    its pre-LayerNorm rows are normalised by layer_outputs) vs the reference's own layer outputs (gen_golden.py)."""
+    from ruart_amd.bert import BertEncoderWeights, PackedTokens, bert_encode, layer_outputs
     z, cfg, w = _bert_case(golden_dir, name)
+    fold = precision.endswith("-fold")
+    precision = precision.replace("-fold", "")
     if precision == "fp16c" and cfg["hidden_size"] % 256:
         pytest.skip("the f16 + fp8-correction GEMM takes hidden sizes that are multiples of 256 (bert-base / bert-large)")
     d = dev()
-    W = BertEncoderWeights(w, cfg, d, precision)
+    W = BertEncoderWeights(w, cfg, d, precision, ln_fold=fold)
+    assert W.ln_fold == fold
     ids, mask = T(z["ids"]), T(z["mask"])
     packed = PackedTokens([(ids, mask)], d, pack=pack, mfma_long=precision in ("fp16", "bf16"))
-    layers = bert_encode(W, packed).float().cpu()
+    layers = layer_outputs(bert_encode(W, packed)).float().cpu()
     gi = packed.group_index[0]
     sel = T(z["mask"]).bool()
     for k in z.files:
@@ -1022,3 +1027,167 @@ def test_rows_scale_equals_gather_and_multiply(W, N, D):
     gy = wide[:, 4:4 + D]                                   # strided rows, 16-byte aligned start
     y.backward(gy)
     assert torch.equal(x.grad.view(torch.int32), (gy * mask[row_of]).view(torch.int32))
+
+
+def _row_partials(y):
+    """[M][4][2] (sum, sumsq) over 256-column tiles of y (fp64 sums), the layout of ruart_gemm_16c_nt_fold"""
+    M, H = y.shape
+    p = torch.zeros(M, 4, 2, dtype=torch.float64)
+    for t in range(H // 256):
+        blk = y[:, t * 256:(t + 1) * 256].double()
+        p[:, t, 0] = blk.sum(1)
+        p[:, t, 1] = (blk * blk).sum(1)
+    return p.float()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (512, 1024, 1024), (256, 768, 3072)])
+@pytest.mark.parametrize("res_ln", [False, True])
+def test_gemm_16c_fold_producer(M, N, K, res_ln):
+    """kind 3 of ruart_gemm_16c_nt_fold: y = A W^T + b + residual (the residual rows normalised from their partials when res_ln),
+    written fp32, in the split operand form and as row partials - against fp64."""
+    from ruart_amd.bert import split_f16c
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + int(res_ln))
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    R = torch.randn(M, N, generator=g) * 1.5 + 0.2
+    gam, bet = 1.0 + 0.3 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    if res_ln:
+        mu = R.double().mean(1, keepdim=True)
+        var = ((R.double() - mu) ** 2).mean(1, keepdim=True)
+        ref = ref + (R.double() - mu) / torch.sqrt(var + 1e-12) * gam.double() + bet.double()
+    else:
+        ref = ref + R.double()
+    A16, A8 = split_f16c(A)
+    W16, W8 = _w8(W)
+    dv = lambda t: t.to(d)
+    A16d, A8d, W16d, W8d, bd, Rd, gd, bed = map(dv, (A16, A8, W16, W8, bias, R, gam, bet))
+    rp = dv(_row_partials(R)) if res_ln else None
+    C = torch.zeros(M, N, dtype=torch.float32, device=d)
+    C16 = torch.zeros(M, N, dtype=torch.float16, device=d)
+    C8 = torch.zeros(M, 2 * N, dtype=torch.uint8, device=d)
+    part = torch.full((M, 4, 2), -7.0, dtype=torch.float32, device=d)
+    rc = lib.ruart_gemm_16c_nt_fold(hip.ptr(A16d), hip.ptr(A8d), K, hip.ptr(W16d), hip.ptr(W8d), K, hip.ptr(bd), 3, None, 0, None, 1.0,
+                                    hip.ptr(Rd), N, hip.ptr(rp), N // 256, hip.ptr(gd), hip.ptr(bed), hip.ptr(C), N, hip.ptr(C16), hip.ptr(C8),
+                                    hip.ptr(part), M, N, K, N, 1e-12, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    scale = float(ref.abs().mean())
+    assert maxerr(C, ref) < 6e-5 * scale * max(1.0, (K / 768) ** 0.5) * 4
+    h16, h8 = split_f16c(C.cpu())
+    assert torch.equal(h16, C16.cpu()) and torch.equal(h8, C8.cpu())            # the split rows are the split of the fp32 rows written
+    want = _row_partials(C.cpu())
+    got = part.cpu()
+    nt = N // 256
+    assert maxerr(got[:, :nt, 0], want[:, :nt, 0]) < 2e-4 * max(1.0, float(want[:, :nt, 0].abs().max()))
+    assert maxerr(got[:, :nt, 1], want[:, :nt, 1]) < 2e-5 * float(want[:, :nt, 1].abs().max())
+    if nt < 4:
+        assert float((got[:, nt:] + 7.0).abs().max()) == 0.0                   # unused slots untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 2304, 768), (512, 3072, 768), (256, 4096, 1024)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_16c_fold_consumer(M, N, K, gelu):
+    """kind 0 / 2 of ruart_gemm_16c_nt_fold on pre-LayerNorm rows y with folded weights: rstd 2^s (y W'^T - mu c) + d against
+    LayerNorm(y) W^T + b in fp64 (gamma with a few large gains, so that the fold needs s > 0), and against the unfolded fp16c product
+    of the materialised LayerNorm rows: the folded form must be about as accurate."""
+    from ruart_amd.bert import split_f16c
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + int(gelu))
+    y = torch.randn(M, K, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + 0.3 * torch.randn(M, 1, generator=g)
+    y[:, 5] += 20.0                                                               # an outlier dimension, as a pretrained encoder has
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    gam, bet = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    gam[7] = 40.0                                                                 # |W'| reaches ~4: s = 1
+    mu = y.double().mean(1, keepdim=True)
+    var = ((y.double() - mu) ** 2).mean(1, keepdim=True)
+    x = (y.double() - mu) / torch.sqrt(var + 1e-12) * gam.double() + bet.double()
+    ref = x @ W.double().t() + bias.double()
+    if gelu:
+        ref = O.gelu_erf(ref)
+    wf = W * gam[None, :]
+    sh = 0
+    while float(wf.abs().max()) * 2.0 ** -sh >= 3.4:
+        sh += 1
+    assert sh >= 1
+    wf = wf * 2.0 ** -sh
+    dvec = (bias.double() + W.double() @ bet.double()).float()
+    cvec = wf.double().sum(1).float()
+    A16, A8 = split_f16c(y)
+    W16, W8 = _w8(wf)
+    dv = lambda t: t.to(d)
+    A16d, A8d, W16d, W8d, dd, cd, pd = map(dv, (A16, A8, W16, W8, dvec, cvec, _row_partials(y)))
+    if gelu:
+        C = torch.zeros(M, N, dtype=torch.float16, device=d)
+        C8 = torch.zeros(M, 2 * N, dtype=torch.uint8, device=d)
+    else:
+        C = torch.zeros(M, N, dtype=torch.float32, device=d)
+        C8 = None
+    rc = lib.ruart_gemm_16c_nt_fold(hip.ptr(A16d), hip.ptr(A8d), K, hip.ptr(W16d), hip.ptr(W8d), K, hip.ptr(dd), 2 if gelu else 0, hip.ptr(pd),
+                                    K // 256, hip.ptr(cd), float(2.0 ** sh), None, 0, None, 0, None, None, hip.ptr(C), N, None, hip.ptr(C8), None,
+                                    M, N, K, K, 1e-12, hip.stream_ptr())
+    assert rc == 0
+    # the unfolded product of the materialised rows
+    X16, X8 = split_f16c(x.float())
+    V16, V8 = _w8(W)
+    U = torch.zeros(M, N, dtype=torch.float32, device=d)
+    rc = lib.ruart_gemm_16c_nt(hip.ptr(X16.to(d)), hip.ptr(X8.to(d)), K, hip.ptr(V16.to(d)), hip.ptr(V8.to(d)), K, hip.ptr(bias.to(d)), None, 0,
+                               hip.ptr(U), N, None, M, N, K, hip.ACT_NONE, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    if gelu:
+        sa_lo, _, _, _ = hip.f16c_shifts()
+        got = C.float().cpu() + C8[:, :N].view(torch.float8_e4m3fn).float().cpu() / 2.0 ** sa_lo
+        ref_u = O.gelu_erf(U.double().cpu())
+    else:
+        got, ref_u = C.cpu(), U.double().cpu()
+    e_f = float((got.double() - ref).pow(2).mean().sqrt())
+    e_u = float((ref_u - ref).pow(2).mean().sqrt())
+    print("fold rms err %.2e (max %.2e) | unfolded fp16c rms %.2e | mean |ref| %.2e" % (e_f, maxerr(got, ref), e_u, float(ref.abs().mean())))
+    assert e_f < 4 * e_u + 1e-6 and maxerr(got, ref) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+def test_pool_mix_over_prelayernorm_rows():
+    """ruart_bert_pool_mix_ln / _bwd (the folded pass's pooling: rows normalised on the fly) == ruart_bert_pool_mix / _bwd over the
+    materialised LayerNorm rows, last layer compacted."""
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    NL, Tp, H, W = 5, 512, 768, 300
+    y = (torch.randn(NL, Tp, H, generator=g) * 1.3 + 0.2).to(d)
+    gam, bet = (1.0 + 0.2 * torch.randn(NL, H, generator=g)).to(d), (0.1 * torch.randn(NL, H, generator=g)).to(d)
+    mu = y.mean(2, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((y - mu) ** 2).mean(2, keepdim=True) + 1e-12)
+    stats = torch.cat([mu, rstd], 2).contiguous()
+    x = ((y - mu) * rstd * gam[:, None, :] + bet[:, None, :]).contiguous()
+    n = torch.randint(1, 4, (W,), generator=g).int()
+    n[:7] = torch.tensor([1, 2, 3, 4, 1, 2, 5]).int()
+    st = torch.randint(0, Tp - 8, (W,), generator=g).int()
+    st_last = torch.randint(0, 200, (W,), generator=g).int()
+    dst = torch.randperm(W + 20, generator=g)[:W].int()
+    lw = torch.randn(NL, generator=g)
+    gy = torch.randn(W + 20, H, generator=g)
+    std, nd, stl, dstd, lwd, gyd = st.to(d), n.to(d), st_last.to(d), dst.to(d), lw.to(d), gy.to(d)
+    o1 = torch.zeros(W + 20, H, device=d)
+    o2 = torch.zeros(W + 20, H, device=d)
+    assert lib.ruart_bert_pool_mix(hip.ptr(x), Tp * H, H, hip.DT_F32, NL, hip.ptr(std), hip.ptr(stl), hip.ptr(nd), hip.ptr(dstd), hip.ptr(lwd),
+                                   hip.ptr(o1), H, W, H, hip.stream_ptr()) == 0
+    assert lib.ruart_bert_pool_mix_ln(hip.ptr(y), Tp * H, H, NL, hip.ptr(stats), Tp, hip.ptr(gam), hip.ptr(bet), hip.ptr(std), hip.ptr(stl),
+                                      hip.ptr(nd), hip.ptr(dstd), hip.ptr(lwd), hip.ptr(o2), H, W, H, hip.stream_ptr()) == 0
+    p1, p2 = torch.empty(W * NL, device=d), torch.empty(W * NL, device=d)
+    g1, g2 = torch.zeros(NL, device=d), torch.zeros(NL, device=d)
+    assert lib.ruart_bert_pool_mix_bwd(hip.ptr(x), Tp * H, H, hip.DT_F32, NL, hip.ptr(std), hip.ptr(stl), hip.ptr(nd), hip.ptr(dstd), hip.ptr(gyd),
+                                       H, hip.ptr(p1), hip.ptr(g1), W, H, hip.stream_ptr()) == 0
+    assert lib.ruart_bert_pool_mix_ln_bwd(hip.ptr(y), Tp * H, H, NL, hip.ptr(stats), Tp, hip.ptr(gam), hip.ptr(bet), hip.ptr(std), hip.ptr(stl),
+                                          hip.ptr(nd), hip.ptr(dstd), hip.ptr(gyd), H, hip.ptr(p2), hip.ptr(g2), W, H, hip.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert maxerr(o2, o1) < 2e-5 * max(1.0, float(o1.abs().max()))
+    assert maxerr(g2, g1) < 1e-4 * max(1.0, float(g1.abs().max()))

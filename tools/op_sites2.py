@@ -61,6 +61,6 @@ with Spy():
 torch.cuda.synchronize()
 print("%5s  %-28s %-28s %s" % ("calls", "site", "op", "most common shapes"))
 for (fr, name), n in sites.most_common(a.top):
-    sh = "; ".join("%s x%d" % (k, v) for k, v in shapes[(fr, name)].most_common(2))
-    print("%5d  %-28s %-28s %s" % (n, fr, name, sh[:150]))
+    sh = "; ".join("%s x%d" % (k, v) for k, v in shapes[(fr, name)].most_common(40 if n >= 20 else 2))
+    print("%5d  %-28s %-28s %s" % (n, fr, name, sh if n >= 20 else sh[:150]))
 print("total non-view aten calls:", sum(sites.values()))
