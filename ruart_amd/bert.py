@@ -593,7 +593,8 @@ class Bert(nn.Module):
         # CUs the run-ahead encoder pass may occupy.  In the fp16c mode the pass (19 ms) outlasts the trunk's step (15 ms), and a trunk
         # kernel otherwise waits for a GEMM workgroup (which owns a whole CU's registers and LDS for ~45 us) to retire: keeping 16
         # CUs out of the encoder's reach took the step from 26.7 to 25.8 ms.  The plain 16-bit modes gain nothing (round 1).
-        self._opt_prefetch_cus = int(opt.get("bert_prefetch_cus", 240 if precision == "fp16c" else 0))
+        # Round 5: 'auto' (fp16c default) picks the mask per batch from the GEMMs' tile rounds (plan_prefetch_cus below).
+        self._opt_prefetch_cus = opt.get("bert_prefetch_cus", "auto" if precision == "fp16c" else 0)
         self._init_pipeline()
         # Tail split of the encoder GEMMs (csrc/gemm_corr.hip, gemm.hip; opt['bert_tail_cus'] = the CU count the split is planned for, one
         # value per model so that every pass computes the same bits).  OFF by default: measured on the bench batch (round 4, DESIGN.md
@@ -659,15 +660,35 @@ class Bert(nn.Module):
         self._pending = None                 # PackedTokens whose prefetched pass has not been consumed yet
         self._in_use = 1                     # set whose layer outputs the current step's forward/backward reads
         # CUs the prefetch pass may occupy; the rest stay free for the trunk (0 = all, the default).
-        self._pf_cus = int(os.environ.get("RUART_PREFETCH_CUS", self._opt_prefetch_cus))
+        cus = os.environ.get("RUART_PREFETCH_CUS", self._opt_prefetch_cus)
+        self._pf_cus = cus if cus == "auto" else int(cus)
         self._pf_streams = {}                # CU count (0 = all) -> stream
 
-    def prefetch_cus(self):
-        """CUs the run-ahead pass may use NOW: the configured mask (240 in the fp16c schedule) in training - the trunk is on the
-        device for 85 % of a training step and needs CUs no GEMM workgroup can take - and all of them in evaluation, where the trunk's
-        forward is gone after a quarter of the step and the mask only costs (forward-only steps: 24.0 ms masked, 20.5 unmasked).
-        RUART_PREFETCH_CUS_EVAL overrides the evaluation value (experiments)."""
+    def plan_prefetch_cus(self, n_rows):
+        """CU mask of the run-ahead pass for a batch of ``n_rows`` packed rows.  A GEMM workgroup (one 256 x 256 tile) owns a CU, so a
+        product of t tiles takes ceil(t / cus) rounds whatever is left of the last one: among 208 .. 248 CUs the SMALLEST mask with
+        the fewest rounds over the layer's four products (weighted by their K) runs the encoder as fast as the largest one and leaves
+        the most CUs to the trunk.  Bench batch (167 row tiles): 224, 232, 240 and 248 all take 31 rounds per layer, 216 takes 32 -
+        measured 22.94 / 23.22 / 23.47 / 23.59 ms per step for 224 / 232 / 240 / 248 and 23.78 for 216 (profiles/r05_knob_sweep.log)."""
+        cfg = self.weights.cfg
+        H, I = cfg["hidden_size"], cfg["intermediate_size"]
+        rt = -(-int(n_rows) // 256)
+        prods = ((3 * H // 256, 1.0), (H // 256, 1.0), (I // 256, 1.0), (H // 256, I / float(H)))      # (column tiles, relative K)
+        best = None
+        for c in range(208, 249, 8):
+            cost = sum(w * -(-rt * nt // c) for nt, w in prods)
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, c)
+        return best[1]
+
+    def prefetch_cus(self, packed=None):
+        """CUs the run-ahead pass may use NOW: the configured mask ('auto': plan_prefetch_cus of the batch; a number: that many) in
+        training - the trunk is on the device for 85 % of a training step and needs CUs no GEMM workgroup can take - and all of them
+        in evaluation, where the trunk's forward is gone after a quarter of the step and the mask only costs (forward-only steps:
+        24.0 ms masked, 20.5 unmasked).  RUART_PREFETCH_CUS_EVAL overrides the evaluation value (experiments)."""
         if self.training:
+            if self._pf_cus == "auto":
+                return self.plan_prefetch_cus(packed.Tp) if packed is not None else 240
             return self._pf_cus
         return int(os.environ.get("RUART_PREFETCH_CUS_EVAL", 0))
 
@@ -678,7 +699,7 @@ class Bert(nn.Module):
         if getattr(packed, "_layers", None) is not None or getattr(self, "bert_model", None) is not None or self._frozen_dropout_active():
             return                           # (a trainable encoder changes every step, a dropout pass is drawn per step: nothing to run ahead)
         dev = self._device
-        cus = self.prefetch_cus()
+        cus = self.prefetch_cus(packed)
         st = self._pf_streams.get(cus)
         if st is None or st.device != dev:
             epr = int(os.environ.get("RUART_ENCODER_PRIORITY", 0))            # experiments: -1 = a HIGH-priority (unmasked) encoder stream

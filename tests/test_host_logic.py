@@ -524,9 +524,11 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
 
     class FakeBert:
         prefetch_cus = Bert.prefetch_cus
+        plan_prefetch_cus = Bert.plan_prefetch_cus
 
         def __init__(self, cus, training):
             self._pf_cus, self.training = cus, training
+            self.weights = type("W", (), {"cfg": {"hidden_size": 768, "intermediate_size": 3072}})()
 
     class FakeNet:
         trunk_stream_priority = SDNet.trunk_stream_priority
@@ -535,6 +537,12 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
             self.Bert = bert
 
     assert FakeBert(240, True).prefetch_cus() == 240 and FakeBert(240, False).prefetch_cus() == 0
+    # 'auto': the smallest mask with the fewest GEMM tile rounds for the batch's rows (167 / 168 row tiles of the bench batches: 224)
+    auto = FakeBert("auto", True)
+    pk = lambda rows: type("P", (), {"Tp": rows})()
+    assert auto.prefetch_cus(pk(42752)) == 224 and auto.prefetch_cus(pk(43008)) == 224 and auto.prefetch_cus() == 240
+    assert all(208 <= auto.plan_prefetch_cus(r) <= 248 for r in range(256, 60000, 256))
+    assert FakeBert("auto", False).prefetch_cus(pk(42752)) == 0 and FakeNet(auto).trunk_stream_priority() == 1
     assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 1          # fp16c schedule, training: LOW beside the masked pass
     assert FakeNet(FakeBert(240, False)).trunk_stream_priority() == -1        # evaluation: unmasked pass, trunk first
     assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
