@@ -218,6 +218,11 @@ int ruart_colsum_f32(const float* x, int ld, int rows, int cols, float* out, int
 /* out[j] (+)= sum over `rows` rows of part[r * ld + j], rows in a fixed order (the reduction behind per-strip partial sums such as
  * ruart_gemm_16_nt_gelu_bwd's colpart) */
 int ruart_colsum_f32_rows(const float* part, int rows, int ld, int cols, float* out, int accumulate, void* stream);
+/* Backward through the GELU of the intermediate dense (Models/Bert/modeling.py:287-288 under autograd) as an elementwise pass, in place:
+ * d (M x N bf16, row stride ld) holds dY . W2 and becomes that times gelu'(h); g = gelu(h) (bf16, same stride; h: the saved f16
+ * pre-activation); colpart[(M / 128) x N] = column sums of the unrounded d per 128-row strip.  M % 128 == 0, N % 256 == 0.  Same results
+ * contract as ruart_gemm_16_nt_gelu_bwd except that the product was rounded to bf16 once before the multiplication. */
+int ruart_gelu_bwd_rows(void* d_bf16, const void* h16, int ld, void* g_bf16, float* colpart, int M, int N, void* stream);
 /* f16 -> bf16 copy (n elements, n % 4 == 0): saved activations as the bf16 operand of a weight-gradient product */
 int ruart_f16_to_bf16(const void* in16, void* out_bf16, long long n, void* stream);
 /* bias gradient: out[j] (+)= sum_r x[r][j] of a bf16 matrix; ws: ceil(rows / 256) * cols floats */

@@ -438,6 +438,58 @@ extern "C" int ruart_ln_train_bwd(const float* dy, int ldy, const float* add, co
   return 0;
 }
 
+// Backward through the GELU of the intermediate dense as a pass of its own (round 5: the fused form, ruart_gemm_16_nt_gelu_bwd, spends
+// 300 us of a 476-us launch in its epilogue - 8 waves per CU doing two transcendentals per element and 384 KB of traffic per tile after the
+// matrix work, nothing overlapped; the plain product + this pass are 160 + ~190 us).  In place: d (M x N bf16) holds acc = dY . W2 and
+// becomes acc * gelu'(H); G = gelu(H) (bf16: the X operand of the output dense's weight gradient); colpart[(M / 128) x N] = column sums
+// of the unrounded d per 128-row strip (the intermediate bias gradient after ruart_colsum_f32_rows).  One workgroup = one strip x 256
+// columns, a wave takes every fourth row, eight rows of loads in flight per lane.
+#include "gemm_shared.h"
+__global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(bf16_t* __restrict__ d, const f16_t* __restrict__ Hh, int ld, bf16_t* __restrict__ G,
+                                                            float* __restrict__ colpart, int M, int N) {
+  __shared__ __attribute__((aligned(16))) float red[3][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * 128;
+  f32x4_t cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    f32x4_t a[8], h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t o = (size_t)(r0 + (it * 8 + k) * 4 + wv) * ld + col;
+      a[k] = load4_stream(d + o);
+      h[k] = load4_stream(Hh + o);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t o = (size_t)(r0 + (it * 8 + k) * 4 + wv) * ld + col;
+      f32x2_t g0, d0, g1, d1;
+      gelu_fwd_bwd_pk((f32x2_t){h[k][0], h[k][1]}, g0, d0);
+      gelu_fwd_bwd_pk((f32x2_t){h[k][2], h[k][3]}, g1, d1);
+      const f32x4_t v = a[k] * (f32x4_t){d0.x, d0.y, d1.x, d1.y};
+      cs += v;
+      store4(G + o, (f32x4_t){g0.x, g0.y, g1.x, g1.y});
+      store4(d + o, v);
+    }
+  }
+  if (wv > 0) *reinterpret_cast<f32x4_t*>(&red[wv - 1][lane * 4]) = cs;
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cs += *reinterpret_cast<const f32x4_t*>(&red[k][lane * 4]);
+    store4(colpart + (size_t)blockIdx.y * N + col, cs);
+  }
+}
+extern "C" int ruart_gelu_bwd_rows(void* d_bf16, const void* h16, int ld, void* g_bf16, float* colpart, int M, int N, void* stream) {
+  RUART_ENTRY();
+  if (M <= 0 || M % 128 || N <= 0 || N % 256 || (ld & 3) || ld < N || !d_bf16 || !h16 || !g_bf16 || !colpart) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gelu_bwd_rows_kernel, dim3(N / 256, M / 128), dim3(256), 0, (hipStream_t)stream, (bf16_t*)d_bf16, (const f16_t*)h16, ld,
+                     (bf16_t*)g_bf16, colpart, M, N);
+  RUART_CHECK_LAUNCH();
+  return 0;
+}
+
 __global__ void f16_to_bf16_kernel(const f16_t* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) store4(out + i * 4, load4(in + i * 4));
 }

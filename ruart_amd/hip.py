@@ -82,6 +82,7 @@ _SIGNATURES = {
     "ruart_ln_train_fwd": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, ctypes.c_uint, _I, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_ln_train_bwd_ws_floats": (c_size_t, [_I]),
     "ruart_ln_train_bwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _F, ctypes.c_uint, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "ruart_gelu_bwd_rows": (_I, [_P, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_f16_to_bf16": (_I, [_P, _P, _LL, _P]),
     "ruart_weight_prep": (_I, [_P, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "ruart_weight_prep_batch": (_I, [POINTER(WPrepItemC), _I, _P]),

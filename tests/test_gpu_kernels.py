@@ -1191,3 +1191,28 @@ def test_pool_mix_over_prelayernorm_rows():
     torch.cuda.synchronize()
     assert maxerr(o2, o1) < 2e-5 * max(1.0, float(o1.abs().max()))
     assert maxerr(g2, g1) < 1e-4 * max(1.0, float(g1.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(256, 3072), (128, 256), (43008, 3072)])
+def test_gelu_bwd_rows(M, N):
+    """ruart_gelu_bwd_rows (the trainable encoder's GELU backward as an elementwise pass): d *= gelu'(h) in place, g = gelu(h), 128-row
+    strip column sums of the unrounded d - against torch in fp64 (erf GELU; the kernel's logistic-polynomial form is 3.4e-6 off)."""
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N)
+    h = (torch.randn(M, N, generator=g) * 1.5).to(torch.float16)
+    acc = (torch.randn(M, N, generator=g) * 0.01).to(torch.bfloat16)
+    hd, dd = h.to(d), acc.to(d).clone()
+    gb = torch.zeros(M, N, dtype=torch.bfloat16, device=d)
+    part = torch.zeros(M // 128, N, dtype=torch.float32, device=d)
+    assert lib.ruart_gelu_bwd_rows(hip.ptr(dd), hip.ptr(hd), N, hip.ptr(gb), hip.ptr(part), M, N, hip.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    x = h.double()
+    cdf = 0.5 * (1.0 + torch.erf(x / 2.0 ** 0.5))
+    gref = x * cdf
+    dref = acc.double() * (cdf + x * torch.exp(-0.5 * x * x) / (2.0 * np.pi) ** 0.5)
+    assert maxerr(gb.float(), gref) < 2.0 ** -8 * float(gref.abs().max())                 # bf16 rounding of the output
+    assert maxerr(dd.float(), dref) < 2.0 ** -8 * float(dref.abs().max()) + 1e-6
+    pref = dref.view(M // 128, 128, N).sum(1)
+    assert maxerr(part, pref) < 2e-5 * 128 ** 0.5 + 1e-4 * float(pref.abs().max())
