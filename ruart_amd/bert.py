@@ -593,8 +593,12 @@ class Bert(nn.Module):
         # CUs the run-ahead encoder pass may occupy.  In the fp16c mode the pass (19 ms) outlasts the trunk's step (15 ms), and a trunk
         # kernel otherwise waits for a GEMM workgroup (which owns a whole CU's registers and LDS for ~45 us) to retire: keeping 16
         # CUs out of the encoder's reach took the step from 26.7 to 25.8 ms.  The plain 16-bit modes gain nothing (round 1).
-        # Round 5: 'auto' (fp16c default) picks the mask per batch from the GEMMs' tile rounds (plan_prefetch_cus below).
-        self._opt_prefetch_cus = opt.get("bert_prefetch_cus", "auto" if precision == "fp16c" else 0)
+        # Round 5: 224 - on the bench batch the smallest mask with as few GEMM tile rounds as 240 (plan_prefetch_cus below; 22.9 ms
+        # against 23.5), and the better one on a 10 % smaller batch too (21.4 against 22.3 at that batch's own plan, 232).  'auto' plans
+        # ONCE, from the first training batch, and keeps that stream: a second CU-masked stream in the same process lands on a hardware
+        # queue pipe one of the step's four streams already uses and the two run one after the other (27-29 ms steps,
+        # tools/r05_mask_switch.py).
+        self._opt_prefetch_cus = opt.get("bert_prefetch_cus", 224 if precision == "fp16c" else 0)
         self._init_pipeline()
         # Tail split of the encoder GEMMs (csrc/gemm_corr.hip, gemm.hip; opt['bert_tail_cus'] = the CU count the split is planned for, one
         # value per model so that every pass computes the same bits).  OFF by default: measured on the bench batch (round 4, DESIGN.md
@@ -669,7 +673,10 @@ class Bert(nn.Module):
         product of t tiles takes ceil(t / cus) rounds whatever is left of the last one: among 208 .. 248 CUs the SMALLEST mask with
         the fewest rounds over the layer's four products (weighted by their K) runs the encoder as fast as the largest one and leaves
         the most CUs to the trunk.  Bench batch (167 row tiles): 224, 232, 240 and 248 all take 31 rounds per layer, 216 takes 32 -
-        measured 22.94 / 23.22 / 23.47 / 23.59 ms per step for 224 / 232 / 240 / 248 and 23.78 for 216 (profiles/r05_knob_sweep.log)."""
+        measured 22.94 / 23.22 / 23.47 / 23.59 ms per step for 224 / 232 / 240 / 248 and 23.78 for 216 (profiles/r05_knob_sweep.log).
+        The model counts whole rounds only: a product that fits its rounds with no slack (153 row tiles at 232 CUs: 5.94 / 1.98 / 7.91
+        rounds) spills as soon as the trunk holds a few CUs, and that batch ran better at 224 - which is why 224 is the default and
+        this plan an option ('auto')."""
         cfg = self.weights.cfg
         H, I = cfg["hidden_size"], cfg["intermediate_size"]
         rt = -(-int(n_rows) // 256)
@@ -682,13 +689,16 @@ class Bert(nn.Module):
         return best[1]
 
     def prefetch_cus(self, packed=None):
-        """CUs the run-ahead pass may use NOW: the configured mask ('auto': plan_prefetch_cus of the batch; a number: that many) in
+        """CUs the run-ahead pass may use NOW: the configured mask (a number - 224 by default in the fp16c schedule -, or 'auto':
+        plan_prefetch_cus of the FIRST training batch, kept from then on) in
         training - the trunk is on the device for 85 % of a training step and needs CUs no GEMM workgroup can take - and all of them
         in evaluation, where the trunk's forward is gone after a quarter of the step and the mask only costs (forward-only steps:
         24.0 ms masked, 20.5 unmasked).  RUART_PREFETCH_CUS_EVAL overrides the evaluation value (experiments)."""
         if self.training:
             if self._pf_cus == "auto":
-                return self.plan_prefetch_cus(packed.Tp) if packed is not None else 240
+                if packed is None:
+                    return 240
+                self._pf_cus = self.plan_prefetch_cus(packed.Tp)      # planned once: the process keeps the stream it starts with
             return self._pf_cus
         return int(os.environ.get("RUART_PREFETCH_CUS_EVAL", 0))
 

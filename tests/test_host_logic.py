@@ -540,9 +540,11 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
     # 'auto': the smallest mask with the fewest GEMM tile rounds for the batch's rows (167 / 168 row tiles of the bench batches: 224)
     auto = FakeBert("auto", True)
     pk = lambda rows: type("P", (), {"Tp": rows})()
-    assert auto.prefetch_cus(pk(42752)) == 224 and auto.prefetch_cus(pk(43008)) == 224 and auto.prefetch_cus() == 240
+    assert auto.prefetch_cus() == 240 and FakeNet(auto).trunk_stream_priority() == 1            # (before the first batch is known)
+    assert auto.prefetch_cus(pk(42752)) == 224 and auto.prefetch_cus(pk(39168)) == 224        # planned once, then kept (39168 alone: 232)
+    assert auto.plan_prefetch_cus(43008) == 224 and auto.plan_prefetch_cus(39168) == 232
     assert all(208 <= auto.plan_prefetch_cus(r) <= 248 for r in range(256, 60000, 256))
-    assert FakeBert("auto", False).prefetch_cus(pk(42752)) == 0 and FakeNet(auto).trunk_stream_priority() == 1
+    assert FakeBert("auto", False).prefetch_cus(pk(42752)) == 0
     assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 1          # fp16c schedule, training: LOW beside the masked pass
     assert FakeNet(FakeBert(240, False)).trunk_stream_priority() == -1        # evaluation: unmasked pass, trunk first
     assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
