@@ -181,6 +181,16 @@ __device__ __forceinline__ void store_split4(f16_t* p16, unsigned char* p8, int 
   *reinterpret_cast<unsigned*>(p8) = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
   *reinterpret_cast<unsigned*>(p8 + hi_off) = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
 }
+// Timing diagnostic (-DRUART_ABL_SPLIT8 in gemm_corr.hip; WRONG operand layout): both companions in one 8-byte store at p8x2 = the
+// row's byte 2 * column - what a [lo4 | hi4]-interleaved companion layout would allow.
+__device__ __forceinline__ void store_split8_diag(f16_t* p16, unsigned char* p8x2, f32x4_t v) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const f16x4_t h = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+  *reinterpret_cast<f16x4_t*>(p16) = h;
+  const f32x4_t lo = {v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]};
+  const u32x2_t w = {pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO)), pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI))};
+  *reinterpret_cast<u32x2_t*>(p8x2) = w;
+}
 
 // ---- dropout without stored masks: a counter-based hash of (stream seed, element index) decides every element, so the backward
 // pass regenerates the forward's mask (training kernels of the encoder, bert_train_*.hip)

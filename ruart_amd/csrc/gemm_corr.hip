@@ -204,7 +204,11 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
         }
         v[rr] += res[rr];
         store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+#ifdef RUART_ABL_SPLIT8
+        store_split8_diag(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + 2 * ncol, v[rr]);
+#else
         store_split4(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+#endif
         const float s1 = row16_sum((v[rr][0] + v[rr][1]) + (v[rr][2] + v[rr][3]));
         const float s2 = row16_sum(fmaf(v[rr][0], v[rr][0], v[rr][1] * v[rr][1]) + fmaf(v[rr][2], v[rr][2], v[rr][3] * v[rr][3]));
         if ((lane & 15) == 0) rpart[hh * 32 + rr * 4] = make_float2(s1, s2);
@@ -224,6 +228,8 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
       if (EPI == 2)
 #ifdef RUART_ABL_NOFP8
         *reinterpret_cast<f16x4_t*>(reinterpret_cast<f16_t*>(C) + row * ldc + ncol) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
+#elif defined(RUART_ABL_SPLIT8)
+        store_split8_diag(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + 2 * ncol, v[rr]);
 #else
         store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
 #endif
