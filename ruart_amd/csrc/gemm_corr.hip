@@ -206,12 +206,14 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
         store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
 #ifdef RUART_ABL_SPLIT8
         store_split8_diag(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + 2 * ncol, v[rr]);
-#else
+#elif !defined(RUART_ABL_FOLD_NOSPLIT)     // (timing diagnostic: kind 3 without its split copy)
         store_split4(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
 #endif
+#ifndef RUART_ABL_FOLD_NOSTATS        // (timing diagnostic: the epilogue without the rows' partial sums - wrong results downstream)
         const float s1 = row16_sum((v[rr][0] + v[rr][1]) + (v[rr][2] + v[rr][3]));
         const float s2 = row16_sum(fmaf(v[rr][0], v[rr][0], v[rr][1] * v[rr][1]) + fmaf(v[rr][2], v[rr][2], v[rr][3] * v[rr][3]));
         if ((lane & 15) == 0) rpart[hh * 32 + rr * 4] = make_float2(s1, s2);
+#endif
       }
       continue;
     }
