@@ -349,7 +349,10 @@ def _gemm_split(b, e, f):
         rows.append((1e3 * float(np.mean(beside)) if beside else float("nan"), 1e3 * float(np.mean(after)) if after else float("nan"), len(after), s1 - s0))
     if not rows:
         return {}
-    return {"beside_trunk": round(float(np.nanmedian([r[0] for r in rows])), 1), "after_trunk": round(float(np.nanmedian([r[1] for r in rows])), 1),
+    def med(col):                                   # (a column may be all-NaN: no GEMM launch after the trunk in any step)
+        v = [r[col] for r in rows if r[col] == r[col]]
+        return round(float(np.median(v)), 1) if v else None
+    return {"beside_trunk": med(0), "after_trunk": med(1),
             "launches_after_trunk": int(np.median([r[2] for r in rows])), "step_ms_of_this_pass": round(float(np.median([r[3] for r in rows])), 3),
             "note": "the ~100 events per step of this pass stretch the step; timeline_ms is the unperturbed schedule"}
 
@@ -367,10 +370,17 @@ def main():
     if a.launch_check:
         raise SystemExit(launch_check(a, out_stream, world, rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback of the product path"
+    # RUART_BENCH_REHEARSE_ONE_GPU=1: every rank on device 0, gradients over gloo - the N-rank control flow of this file (rank 0's
+    # parity trainer while the others wait, the barriers, the all-reduced fields) rehearsed on a one-GPU box; its numbers mean nothing
+    rehearse = os.environ.get("RUART_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1 or a.force_dp:
+    if rehearse and world > 1:
+        dist.init_process_group("gloo")
+    elif world > 1 or a.force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.force_dp and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -645,7 +655,7 @@ def main():
     if want_parity:
         note("parity check on a second trainer built from the same seeds ...")
         torch.cuda.synchronize()
-        tr2, _ = build_trainer(opt, cfg, device)
+        tr2, _ = build_trainer(dict(opt, ruart_dp=False), cfg, device)      # rank 0 alone: a plain replica, no collective in its set-up
         try:
             b0 = tr2.ToCUDA(synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank, n_q=30, n_ocr=n_ocr, n_od=n_od))
             parity = live_parity(tr2, opt, b0, golden)

@@ -55,3 +55,23 @@ def test_bench_timeline_and_distribution_helpers():
     assert abs(t["encoder_pass_start"] - 0.3) < 1e-6 and abs(t["encoder_pass_end"] - 23.8) < 1e-6
     g = bench._gemm_split(b, e, f)
     assert abs(g["beside_trunk"] - 440.0) < 0.5 and abs(g["after_trunk"] - 300.0) < 0.5 and g["launches_after_trunk"] == 8
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The N-rank control flow of bench.py on a one-GPU box (RUART_BENCH_REHEARSE_ONE_GPU=1: both ranks on device 0, gradients over
+    gloo): the self-launch, the timed region's barriers, rank 0's parity check on a second trainer - built as a plain replica, no
+    collective in its set-up - while rank 1 waits, one JSON line from rank 0.  The numbers mean nothing; the run must end."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["RUART_BENCH_REHEARSE_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-bert512"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 128
+    assert out["parity"]["holds"] and out["parity"]["max_abs_err_vs_reference"] < 1e-3
