@@ -315,13 +315,19 @@ def _timeline(b, e, f):
     every time in ms from the step's own start (mark 1: the step stream reaches the forward, i.e. the previous encoder pass has
     ended).  The encoder pass launched inside step t serves batch t+1: its end ends step t's device work."""
     marks, starts = _steps_of(b, f)
+    ends6 = sorted(t for t, tag in marks if tag == 6)
     rows = []
     for k in range(1, len(starts) - 1):                  # (the first step of the pass refills the pipeline after a sync)
         s0, s1 = starts[k], starts[k + 1]
-        m = {tag: t - s0 for t, tag in marks if s0 <= t < s1}
-        if not all(t in m for t in (2, 3, 4, 5, 6)):
+        m = {tag: t - s0 for t, tag in marks if s0 <= t < s1 and tag != 6}
+        if not all(t in m for t in (2, 3, 4, 5)):
             continue
-        rows.append((s1 - s0, m[2], m[3], m[4], m[5], m[6]))
+        # the pass launched in this step starts (mark 5, on the in-order encoder stream) when the pass before it has ended, and may
+        # end inside the NEXT step's window (round 5: the next step's trunk no longer waits for it)
+        after = [t for t in ends6 if t > s0 + m[5]]
+        if not after:
+            continue
+        rows.append((s1 - s0, m[2], m[3], m[4], m[5], after[0] - s0))
     if not rows:
         return {}
     med = [float(np.median([r[i] for r in rows])) for i in range(6)]
@@ -330,7 +336,9 @@ def _timeline(b, e, f):
             "encoder_pass_start": round(med[4], 3), "encoder_pass_end": round(med[5], 3),
             "what": "medians over the steps of a separate pass of the timed schedule with six hipEvents per step (step stream: forward "
                     "start / forward end / backward end / optimizer end; encoder stream: before / after the pass launched in the step, "
-                    "which encodes batch t+1); ms from the step's forward start"}
+                    "which encodes batch t+1); ms from the step's forward start.  The encoder stream runs its passes back to back: "
+                    "encoder_pass_start is where the previous pass ended, and a pass may end after the next step has started "
+                    "(encoder_pass_end > step)"}
 
 
 def _gemm_split(b, e, f):
@@ -521,18 +529,30 @@ def main():
     if os.environ.get("RUART_BENCH_GC_FREEZE", "1") != "0":
         gc.collect()
         gc.freeze()
-    for i in range(a.warmup):
-        step(i)
-        torch.cuda.synchronize()
-        note("warmup step %d done" % i)
+    import contextlib
+
+    def caller_stream():
+        """The loop that drives update() runs where SDNetTrainer.train() runs its own: with the training step stream current
+        (trainer.step_stream; from torch's default stream every step is joined with the LEGACY stream on both sides, and those markers
+        hold the next step's trunk back until the encoder pass beside it has ended: 22.75 -> 22.00 ms).
+        RUART_BENCH_CALLER_DEFAULT_STREAM=1: the caller on torch's default stream, as in rounds 1-4."""
+        if a.mode != "train" or os.environ.get("RUART_BENCH_CALLER_DEFAULT_STREAM") == "1":
+            return contextlib.nullcontext()
+        return tr.step_stream()
+    with caller_stream():
+        for i in range(a.warmup):
+            step(i)
+            torch.cuda.synchronize()
+            note("warmup step %d done" % i)
     sync()
     t0 = time.perf_counter()
     marks, enq = [], []
-    for i in range(a.steps):
-        ts = time.perf_counter()
-        step(i)
-        marks.append(time.perf_counter())     # (host time at which step i's call returned: update() ends with the step's loss readback)
-        enq.append((getattr(tr, "host_enqueued_at", ts) - ts) * 1e3)      # host time until the whole step was enqueued (train mode)
+    with caller_stream():
+        for i in range(a.steps):
+            ts = time.perf_counter()
+            step(i)
+            marks.append(time.perf_counter())     # (host time at which step i's call returned: update() ends with the step's loss readback)
+            enq.append((getattr(tr, "host_enqueued_at", ts) - ts) * 1e3)      # host time until the whole step was enqueued (train mode)
     sync()
     dt = time.perf_counter() - t0
     # the spread of the timed steps, always on the line: a uniform slow run, a transient and a slow first step look different here
@@ -600,12 +620,13 @@ def main():
                 net.forward, optim.clip_and_step = fwd, cs
                 bert_mod.bert_encode = enc
             try:
-                step(0)                                                   # settle the pipeline state of this schedule
-                torch.cuda.synchronize()
-                hip.check(lib.ruart_prof_enable(mode), "prof_enable")
-                for i in range(a.steps):
-                    step(i + 1)
-                torch.cuda.synchronize()
+                with caller_stream():                                     # (the timed region's schedule: see caller_stream)
+                    step(0)                                               # settle the pipeline state of this schedule
+                    torch.cuda.synchronize()
+                    hip.check(lib.ruart_prof_enable(mode), "prof_enable")
+                    for i in range(a.steps):
+                        step(i + 1)
+                    torch.cuda.synchronize()
                 M = 8192
                 b_, e_, f_, n_ = (ctypes.c_float * M)(), (ctypes.c_float * M)(), (ctypes.c_double * M)(), ctypes.c_int(0)
                 hip.check(lib.ruart_prof_timeline(b_, e_, f_, M, ctypes.byref(n_)), "prof_timeline")

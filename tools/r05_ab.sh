@@ -16,7 +16,7 @@ import json, glob, sys, statistics as st
 for cfg in sys.argv[1:]:
     name = cfg.split(':')[0]
     med, mean = [], []
-    for f in sorted(glob.glob('gpurun_out/r05/ab/%s_*.json' % name)):
+    for f in sorted(glob.glob('gpurun_out/r05/ab/%s_[0-9].json' % name)):
         try:
             d = json.loads(open(f).read().strip().splitlines()[-1])
         except Exception:
