@@ -410,8 +410,9 @@ def main():
         opt["dp_pinned_scalar"] = True
     if os.environ.get("RUART_STREAMS"):                   # experiments: 0 = the trunk's three branches on ONE stream
         opt["ruart_streams"] = os.environ["RUART_STREAMS"] != "0"
-    if os.environ.get("RUART_DEFER_READBACK"):            # experiments: loss / NaN readback one step late (default: trained encoder only)
-        opt["ruart_defer_readback"] = os.environ["RUART_DEFER_READBACK"] != "0"
+    # the loss / NaN readback of a step one step late, as SDNetTrainer.train() does inside its loop (trainer._defer_readback): this file
+    # drives update() itself, so it asks for the same explicitly; RUART_DEFER_READBACK=0 = the per-step sync of a bare update() call
+    opt["ruart_defer_readback"] = os.environ.get("RUART_DEFER_READBACK", "1") != "0"
     if os.environ.get("RUART_TILE_ORDER_TRAIN"):          # experiments: one GROUP_M for every encoder GEMM of the training step
         from ruart_amd import hip as _hip
         _hip.check(_hip.load().ruart_gemm_set_tile_order(int(os.environ["RUART_TILE_ORDER_TRAIN"])), "set_tile_order")
@@ -710,7 +711,10 @@ def main():
                                       % (a.batch, n_ocr, n_od, "bert-large 24x1024" if a.stress else "bert-base 12x768",
                                          "TRAINED (no LOCK_BERT)" if a.unlock_bert else "frozen"),
                           "global_batch": world * a.batch, "real_wordpieces_per_batch": int(real_tokens),
-                          "parallelism": "dp%d" % world, "mode": a.mode},
+                          "parallelism": "dp%d" % world, "mode": a.mode,
+                          "loop": ("update() driven as SDNetTrainer.train() drives it: on the trainer's step stream, the loss of a step "
+                                   "read back one step late" if opt.get("ruart_defer_readback") else
+                                   "update() with its per-step loss readback") if a.mode == "train" else None},
                "step_ms": step_ms, "timeline_ms": timeline if roof is not None else None,
                "roofline": roof, "parity": parity, "bert512": b512,
                "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}

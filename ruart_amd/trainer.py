@@ -407,10 +407,15 @@ class SDNetTrainer(BaseTrainer):
     # still in the encoder backward of step t.  The reference's contract is kept one step late: the same asserts fire, before
     # any checkpoint or evaluation can see the weights (``flush_readback`` runs first there), and ``train_loss`` sees every
     # step's value in order.  The frozen-encoder pipeline keeps its per-step sync: there it was measured FASTER.
+    # Round 5: since the training loop runs on the step stream (step_stream) the frozen pipeline's trunk chain is as long as its encoder
+    # chain, and the host sits on it once per step (loss.item(): 22.28 ms per step against 22.03 deferred, and every host hiccup is a
+    # slow step).  ``train()`` therefore defers inside its own loop - it only logs the loss, and flush_readback keeps the asserts ahead
+    # of every evaluation and checkpoint; a direct ``update()`` call keeps the reference's contract (a float, asserts in the same
+    # step) unless opt['ruart_defer_readback'] says otherwise.
     def _defer_readback(self):
         d = self.opt.get("ruart_defer_readback")
         if d is None:
-            d = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
+            d = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None or getattr(self, "_in_train_loop", False)
         return bool(d) and self.device.type == "cuda"
 
     def _readback_later(self, loss, stage_next=None):
@@ -430,6 +435,7 @@ class SDNetTrainer(BaseTrainer):
         lazy = _PendingLoss(self, self._rb_pending)
         if stage_next is not None:
             self.staged = stage_next()
+        self.host_enqueued_at = time.perf_counter()      # (bench.py: how long the host took to enqueue the step)
         if prev is not None:
             self._resolve(prev)
         return lazy
@@ -566,6 +572,7 @@ class SDNetTrainer(BaseTrainer):
             self._train(train_loader, val_loader, eval_every, log_every)
         finally:
             self._in_train = False
+            self._in_train_loop = False
             self.close()
 
     def _train(self, train_loader, val_loader, eval_every, log_every):
@@ -606,6 +613,7 @@ class SDNetTrainer(BaseTrainer):
         # joined with torch's (legacy) default stream, whose markers would hold the next step back until the encoder pass beside it
         # has ended (step_stream)
         with self.step_stream():
+            self._in_train_loop = True                                    # (the loss of a step is read back one step late: _defer_readback)
             batch, nxt = stage(), None
             if batch is not None:
                 nxt = stage()                                             # one batch of lookahead feeds the BERT prefetch
@@ -620,6 +628,8 @@ class SDNetTrainer(BaseTrainer):
                 if batch_i % log_every == 0:
                     log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
                 batch_i += 1
+            self._in_train_loop = False
+            self.flush_readback()                            # the last step's loss and asserts
             if train_data is not None:                       # :121-122
                 self.evaluate(val_loader, batch_i - 1)
                 self.evaluate(train_data, batch_i - 1, mode="train")
