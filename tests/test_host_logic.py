@@ -550,3 +550,30 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
     assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
     monkeypatch.setenv("RUART_TRUNK_PRIORITY", "-1")
     assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == -1
+
+
+def test_readback_is_deferred_inside_the_training_loop_only():
+    """SDNetTrainer._defer_readback: a bare update() keeps the reference's per-step float and asserts (Models/SDNetTrainer.py:376); inside
+    train()'s own loop, and always with a trained encoder, the loss is read back one step late; opt['ruart_defer_readback'] overrides;
+    never on the CPU.  step_stream() on the CPU is a null context.  Bare objects, no device needed."""
+    import contextlib
+    import torch
+    from ruart_amd.trainer import SDNetTrainer
+
+    class Fake:
+        _defer_readback = SDNetTrainer._defer_readback
+        step_stream = SDNetTrainer.step_stream
+        _step_stream = SDNetTrainer._step_stream
+
+        def __init__(self, opt, dev, trained=False, in_loop=False):
+            self.opt, self.device, self._in_train_loop = opt, torch.device(dev), in_loop
+            bert = type("B", (), {"bert_model": object() if trained else None})()
+            self.network = type("N", (), {"Bert": bert, "train": lambda self_: None, "trunk_stream_priority": lambda self_: 1})()
+
+    assert Fake({}, "cuda").__class__._defer_readback(Fake({}, "cuda")) is False
+    assert Fake({}, "cuda", in_loop=True)._defer_readback() is True
+    assert Fake({}, "cuda", trained=True)._defer_readback() is True
+    assert Fake({"ruart_defer_readback": False}, "cuda", trained=True, in_loop=True)._defer_readback() is False
+    assert Fake({"ruart_defer_readback": True}, "cuda")._defer_readback() is True
+    assert Fake({"ruart_defer_readback": True}, "cpu", in_loop=True)._defer_readback() is False
+    assert isinstance(Fake({}, "cpu").step_stream(), contextlib.nullcontext)
