@@ -25,7 +25,7 @@ def run(net, b):
         s, _ = net(q, ocr, od)
     torch.cuda.synchronize()
     return s.float().cpu()
-for prec in ("fp32", "fp16"):
+for prec in (os.environ.get("PRECISIONS", "fp32,fp16,fp16c").split(",")):
     for streams in (True, False):
         net, opt = make(prec, ruart_streams=streams)
         B = 64
