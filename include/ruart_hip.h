@@ -348,6 +348,10 @@ int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_stride, int 
                            long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
                            const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out, int ldo,
                            int n_words, int H, void* stream);
+/* Tuning knob: 1 (default) = twelve-layer encoders take the form of the FORWARD pooling kernel that keeps gamma / beta in registers
+ * over four words per workgroup; 0 = one word per workgroup, tables reloaded; 2 = the backward in its register-table form too
+ * (measured slower).  Results agree to the rounding of the fp32 sums. */
+int ruart_bert_pool_ln_set_variant(int reg_tables);
 int ruart_bert_pool_mix_ln_bwd(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
                                long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
                                const int* span_start_last, const int* span_len, const int* dst_row, const float* grad_out, int ldg,

@@ -1507,6 +1507,94 @@ __global__ __launch_bounds__(256) void pool_mix_cols_ln_kernel(const float* __re
   store4(out + (size_t)dst_row[w] * ldo + col, acc);
 }
 
+// The same pooling with the layers' gamma / beta columns held in REGISTERS for WPB words (NLT = the layer count, a compile-time
+// constant: bert-base's 12): the two table loads per layer and lane of the kernel above are as many L1 / L2 transactions as the rows
+// themselves (236 us over the three groups of the bench batch against 194 for the plain kernel); loaded once per workgroup and reused
+// over WPB words they cost a quarter of that.  192 threads (H = 768) x 24 f32x4 = 96 VGPRs of tables.
+#ifndef RUART_POOL_LN_WPB
+#define RUART_POOL_LN_WPB 4
+#endif
+template <int NLT>
+__global__ __launch_bounds__(256) void pool_mix_cols_ln_reg_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl,
+                                                                   const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                                   const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                                   const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H,
+                                                                   PoolLN ln) {
+  constexpr int LB = 6, WPB = RUART_POOL_LN_WPB;
+  static_assert(NLT % LB == 0 && 2 * NLT <= 64, "layers are loaded six at a time; one lane per (layer, piece) statistic");
+  const int col = threadIdx.x * 4;                       // blockDim.x = H / 4
+  f32x4_t g[NLT], be[NLT];
+  float wgt[NLT];
+  f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < NLT; ++l) {
+    g[l] = load4(ln.g + (size_t)l * H + col);
+    be[l] = load4(ln.b + (size_t)l * H + col);
+    wgt[l] = wl[l];
+    bsum += be[l] * wgt[l];                              // (the mean over a word's pieces of a constant: once per layer)
+  }
+  for (int wi = 0; wi < WPB; ++wi) {
+    const int w = blockIdx.x * WPB + wi;
+    if (w >= W) break;
+    const int st = span_start[w], n = span_len[w];
+    const int st_last = span_start_last ? span_start_last[w] : st;
+    const float inv = 1.0f / (float)n;
+    f32x4_t acc = bsum;
+    // the (mu, rstd) of the word's first two pieces in every layer: ONE load per lane - lane 2 l + p of each wave fetches layer l,
+    // piece p - and a readlane per use, instead of 2 NLT broadcast loads per lane
+    const int sl = min((threadIdx.x & 63) >> 1, NLT - 1), sp = min((int)(threadIdx.x & 1), n - 1);
+    const float2 smine = ln.stats[(size_t)sl * ln.stats_stride + (sl == NLT - 1 ? st_last : st) + sp];
+    auto stat_of = [&](int l, int p) {
+      return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.x), 2 * l + p)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.y), 2 * l + p)));
+    };
+    auto body = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+#pragma unroll
+      for (int lb = 0; lb < NLT; lb += LB) {
+        f32x4_t v[LB][TWO ? 2 : 1];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int l = lb + j;
+          const int r0 = (l == NLT - 1 ? st_last : st);
+          const float* base = layers + (size_t)l * layer_stride + (size_t)r0 * ldl + col;
+          v[j][0] = load4_stream(base);
+          if (TWO) v[j][TWO ? 1 : 0] = load4_stream(base + (size_t)ldl);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const float2 s0 = stat_of(lb + j, 0), s1 = stat_of(lb + j, TWO ? 1 : 0);
+          f32x4_t x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            x[r] = (v[j][0][r] - s0.x) * s0.y;
+            if (TWO) x[r] += (v[j][TWO ? 1 : 0][r] - s1.x) * s1.y;
+          }
+          acc += (x * g[lb + j]) * (wgt[lb + j] * inv);
+        }
+        if (TWO && n > 2) {
+#pragma unroll
+          for (int j = 0; j < LB; ++j) {
+            const int r0 = (lb + j == NLT - 1 ? st_last : st);
+            const float* base = layers + (size_t)(lb + j) * layer_stride + (size_t)r0 * ldl + col;
+            for (int p = 2; p < n; ++p) {
+              const float2 s2 = ln.stats[(size_t)(lb + j) * ln.stats_stride + r0 + p];
+              const f32x4_t y = load4_stream(base + (size_t)p * ldl);
+              f32x4_t x;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[r] = (y[r] - s2.x) * s2.y;
+              acc += (x * g[lb + j]) * (wgt[lb + j] * inv);
+            }
+          }
+        }
+      }
+    };
+    if (n > 1) body(std::true_type{});
+    else body(std::false_type{});
+    store4(out + (size_t)dst_row[w] * ldo + col, acc);
+  }
+}
+
 // d(loss)/d(wl[l]) partial of one word over pre-LayerNorm rows: <grad_out[dst_row[w]], gamma_l (mean of the word's normalised rows) + beta_l>
 template <int NG>
 __global__ __launch_bounds__(256) void pool_mix_bwd_ln_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl, int NL,
@@ -1555,6 +1643,65 @@ __global__ __launch_bounds__(256) void pool_mix_bwd_ln_kernel(const float* __res
   }
 }
 
+// The backward with the tables in registers as well: wave v owns layers v * NLT / 4 .. (NLT / 4 layers x NG column groups x gamma / beta
+// = 72 VGPRs at bert-base), WPB words per workgroup.
+template <int NG, int NLT>
+__global__ __launch_bounds__(256) void pool_mix_bwd_ln_reg_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl,
+                                                                  const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                                  const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                                  const float* __restrict__ gout, int ldg, float* __restrict__ partial, int W, int H,
+                                                                  PoolLN ln) {
+  constexpr int PER = NLT / 4, WPB = RUART_POOL_LN_WPB;
+  static_assert(NLT % 4 == 0, "the four waves share the layers evenly");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l0 = wv * PER;
+  f32x4_t gg[PER][NG], bb[PER][NG];
+  int col[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) col[i] = (i * 64 + lane) * 4;
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      gg[k][i] = load4(ln.g + (size_t)(l0 + k) * H + col[i]);
+      bb[k][i] = load4(ln.b + (size_t)(l0 + k) * H + col[i]);
+    }
+  for (int wi = 0; wi < WPB; ++wi) {
+    const int w = blockIdx.x * WPB + wi;
+    if (w >= W) break;
+    const int st = span_start[w], n = span_len[w];
+    const int st_last = span_start_last ? span_start_last[w] : st;
+    const float inv = 1.0f / (float)n;
+    f32x4_t gv[NG];
+    const float* g = gout + (size_t)dst_row[w] * ldg;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) gv[i] = load4(g + col[i]);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int l = l0 + k;
+      const int r0 = (l == NLT - 1 ? st_last : st);
+      const float* base = layers + (size_t)l * layer_stride + (size_t)r0 * ldl;
+      f32x4_t x[NG];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) x[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < n; ++p) {
+        const float2 s2 = ln.stats[(size_t)l * ln.stats_stride + r0 + p];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+          const f32x4_t y = load4_stream(base + (size_t)p * ldl + col[i]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[i][r] += (y[r] - s2.x) * s2.y;
+        }
+      }
+      f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NG; ++i) s4 += ((x[i] * gg[k][i]) * inv + bb[k][i]) * gv[i];
+      const float d = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+      if (lane == 0) partial[(size_t)w * NLT + l] = d;
+    }
+  }
+}
+
 // (mu, rstd) of `rows` rows from their partial (sum, sumsq) slots (gemm_corr.hip: four slots of 8 bytes per row, the first np used)
 __global__ __launch_bounds__(256) void rows_stats_finish_kernel(const float* __restrict__ part, int np, int rows, float inv_h, float eps,
                                                                 float2* __restrict__ stats) {
@@ -1582,6 +1729,11 @@ extern "C" int ruart_rows_stats_finish(const float* part, int np, int rows, floa
   return 0;
 }
 
+static int g_pool_ln_reg = 1;      // 1: twelve-layer encoders take the register-table form of the pooling kernel (0: A/B runs)
+extern "C" int ruart_bert_pool_ln_set_variant(int reg_tables) {
+  g_pool_ln_reg = reg_tables < 0 ? 0 : (reg_tables > 2 ? 2 : reg_tables);      // 2: the backward's register-table form too (slower, A/B runs)
+  return 0;
+}
 extern "C" int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_stride, int ldl, int n_layers, const float* ln_stats,
                                       long long stats_stride, const float* ln_gamma, const float* ln_beta, const int* span_start,
                                       const int* span_start_last, const int* span_len, const int* dst_row, const float* layer_w, float* out,
@@ -1590,8 +1742,12 @@ extern "C" int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_s
   if (H % 256 || H <= 0 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0 || !ln_stats || !ln_gamma || !ln_beta)
     return (int)hipErrorInvalidValue;
   const PoolLN ln{(const float2*)ln_stats, (size_t)stats_stride, ln_gamma, ln_beta};
-  hipLaunchKernelGGL(pool_mix_cols_ln_kernel, dim3(n_words), dim3(H / 4), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, n_layers,
-                     span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln);
+  if (n_layers == 12 && g_pool_ln_reg)
+    hipLaunchKernelGGL(pool_mix_cols_ln_reg_kernel<12>, dim3(ceil_div(n_words, RUART_POOL_LN_WPB)), dim3(H / 4), 0, (hipStream_t)stream, layers_pre,
+                       (size_t)layer_stride, ldl, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln);
+  else
+    hipLaunchKernelGGL(pool_mix_cols_ln_kernel, dim3(n_words), dim3(H / 4), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, n_layers,
+                       span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln);
   RUART_CHECK_LAUNCH();
   return 0;
 }
@@ -1604,9 +1760,14 @@ extern "C" int ruart_bert_pool_mix_ln_bwd(const float* layers_pre, long long lay
   if (H % 256 || H <= 0 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0 || !ln_stats || !ln_gamma || !ln_beta)
     return (int)hipErrorInvalidValue;
   const PoolLN ln{(const float2*)ln_stats, (size_t)stats_stride, ln_gamma, ln_beta};
+  if (n_layers == 12 && H == 768 && g_pool_ln_reg == 2) {        // (measured slower than the one-word form: 288 against 279 us; kept for A/B runs, variant 2)
+    hipLaunchKernelGGL((pool_mix_bwd_ln_reg_kernel<3, 12>), dim3(ceil_div(n_words, RUART_POOL_LN_WPB)), dim3(256), 0, (hipStream_t)stream, layers_pre,
+                       (size_t)layer_stride, ldl, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, ln);
+  } else {
 #define POOL(NG) hipLaunchKernelGGL((pool_mix_bwd_ln_kernel<NG>), dim3(n_words), dim3(256), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, n_layers, span_start, span_start_last, span_len, dst_row, grad_out, ldg, partial_ws, n_words, H, ln)
-  switch (H / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
+    switch (H / 256) { case 1: POOL(1); break; case 2: POOL(2); break; case 3: POOL(3); break; default: POOL(4); }
 #undef POOL
+  }
   RUART_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, partial_ws, n_words, n_layers, grad_layer_w);
   RUART_CHECK_LAUNCH();

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "ruart_gemm_16c_nt_fold": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ruart_rows_stats_finish": (_I, [_P, _I, _I, _F, _F, _P, _P]),
     "ruart_bert_pool_mix_ln": (_I, [_P, _LL, _I, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ruart_bert_pool_ln_set_variant": (_I, [_I]),
     "ruart_bert_pool_mix_ln_bwd": (_I, [_P, _LL, _I, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "ruart_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ruart_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sub-word pooling + layer mix (ruart_bert_pool_mix / _bwd) on the bench batch's three word groups over fp32 layer outputs: device time
+"""Sub-word pooling + layer mix (ruart_bert_pool_mix / _bwd - or their _ln forms over the pre-LayerNorm rows of a folded encoder pass, the
+fp16c default; RUART_LN_FOLD=0 for the plain forms) on the bench batch's three word groups over fp32 layer outputs: device time
 per call set, Infinity Cache flushed between calls, GB/s of the algorithmic bytes (12 layers x pieces x 3 KB read + 3 KB per word written)."""
 import os, sys
 import torch
@@ -27,7 +28,8 @@ for g in range(3):
         flush.fill_(1.0)
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
-        out = _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last)
+        ln = getattr(layers, "_ln", None) or (None, None, None)       # a LayerNorm-folded pass (the fp16c default): the kernels normalise the rows they read
+        out = _PoolMix.apply(lw, layers, s_, l_, dst, rows, hip.dtype_code(layers), s_last, *ln)
         e1.record()
         go = torch.ones_like(out)
         flush.fill_(2.0)
