@@ -55,6 +55,22 @@ def test_bench_timeline_and_distribution_helpers():
     assert abs(t["encoder_pass_start"] - 0.3) < 1e-6 and abs(t["encoder_pass_end"] - 23.8) < 1e-6
     g = bench._gemm_split(b, e, f)
     assert abs(g["beside_trunk"] - 440.0) < 0.5 and abs(g["after_trunk"] - 300.0) < 0.5 and g["launches_after_trunk"] == 8
+    # the schedule since round 5: passes back to back on the encoder stream - the pass launched in a step starts 2.4 ms into it (where the
+    # one before ended) and ends 2.4 ms into the NEXT step; no GEMM starts after the trunk's optimizer step any more
+    b, e, f = [], [], []
+    for k in range(5):
+        t0 = 22.0 * k
+        for tag, t in ((1, 0.0), (6, 2.4), (5, 2.4), (2, 8.0), (3, 21.5), (4, 21.7)):
+            b.append(t0 + t); e.append(t0 + t); f.append(-float(tag))
+        for j in range(48):
+            st = t0 + 2.5 + j * 0.45
+            b.append(st); e.append(st + 0.42); f.append(1e11)
+    b, e, f = np.array(b), np.array(e), np.array(f)
+    t = bench._timeline(b, e, f)
+    assert t["steps"] == 3 and abs(t["step"] - 22.0) < 1e-6 and abs(t["optimizer_end"] - 21.7) < 1e-6
+    assert abs(t["encoder_pass_start"] - 2.4) < 1e-6 and abs(t["encoder_pass_end"] - 24.4) < 1e-6      # ends inside the next step's window
+    g = bench._gemm_split(b, e, f)
+    assert abs(g["beside_trunk"] - 420.0) < 0.5 and g["launches_after_trunk"] in (0, 1)
 
 
 import pytest
