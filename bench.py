@@ -683,7 +683,7 @@ def main():
             parity = live_parity(tr2, opt, b0, golden)
         finally:
             torch.cuda.synchronize()
-            tr2.network.Bert.close()
+            tr2.network.Bert.close(destroy=True)
             del tr2
         note("parity vs the reference's golden scores: %s" % parity)
 
@@ -727,7 +727,7 @@ def main():
         dist.destroy_process_group()
     torch.cuda.synchronize()
     if getattr(tr.network, "Bert", None) is not None:
-        tr.network.Bert.close()                 # the CU-masked run-ahead stream must not outlive the interpreter (hip.destroy_stream)
+        tr.network.Bert.close(destroy=True)     # the CU-masked run-ahead stream must not outlive the interpreter (hip.destroy_stream)
 
 
 if __name__ == "__main__":

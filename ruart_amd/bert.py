@@ -735,14 +735,27 @@ class Bert(nn.Module):
             packed._layers = bert_encode(self.weights, packed, self._bufsets[packed._set])
             packed._event = self._last_pf_event = st.record_event()
 
-    def close(self):
-        """Release the CU-masked run-ahead stream (see hip.destroy_stream); a later prefetch creates a new one."""
+    def close(self, destroy=None):
+        """End of a training / evaluation session: the pass that is still running ahead is dropped.  ``destroy``: also destroy the
+        CU-masked run-ahead stream (hip.destroy_stream; a later prefetch creates a new one).  True at the end of a process (bench.py,
+        the tools) - a masked stream alive at static destruction takes a process profiled under rocprofv3 down in __cxa_finalize -
+        and by default (None) exactly when a profiler is attached or RUART_DESTROY_STREAMS=1.  Otherwise the stream is KEPT for the
+        next session: a new masked stream lands on another hardware queue slot, and with an evaluation's streams created in between
+        it shared a slot with one of the trunk's streams - every later training step took 27.3 ms instead of 22.1
+        (tools/r05_two_sessions.py)."""
+        if destroy is None:
+            destroy = os.environ.get("RUART_DESTROY_STREAMS") == "1" or any(
+                "rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+        if self._pending is not None:
+            self._pending._layers = None
+            self._pending = None
+        if not destroy:
+            for st in getattr(self, "_pf_streams", {}).values():
+                st.synchronize()                 # (the dropped pass has finished: its buffers may be reused at once)
+            return
         streams, self._pf_streams = getattr(self, "_pf_streams", {}), {}
         self._last_pf_event = None
         for st in streams.values():
-            if self._pending is not None:
-                self._pending._layers = None
-                self._pending = None
             hip.destroy_stream(st)
 
     def layers_for(self, packed):

@@ -252,10 +252,12 @@ class SDNetTrainer(BaseTrainer):
             self._rank_seeded = True
 
     def close(self):
-        """Release what must not outlive the process's own teardown: the encoder's run-ahead stream.  A CU-masked stream
+        """End of a session: the deferred loss check, the encoder pass still running ahead (``Bert.close``).  A CU-masked stream
         (hipExtStreamCreateWithCUMask, the default in the fp16c mode) that is still alive at static destruction makes a process
-        profiled under rocprofv3 die in __cxa_finalize.  ``train()``, a stand-alone ``evaluate()`` and
-        ``predict_for_test()`` call this on every exit path; a later step simply creates a new stream."""
+        profiled under rocprofv3 die in __cxa_finalize: with a profiler attached (or RUART_DESTROY_STREAMS=1) the
+        stream is destroyed here, otherwise it is kept for the next session (a re-created one can land on a trunk stream's hardware
+        queue slot: ``Bert.close``).  ``train()``, a stand-alone ``evaluate()`` and ``predict_for_test()`` call this on every exit
+        path."""
         import sys
         unwinding = sys.exc_info()[0] is not None      # called from a ``finally`` while another exception propagates
         try:
