@@ -26,6 +26,10 @@ def session(name, n=40):
     print("%-40s median %.2f ms (p90 %.2f)" % (name, statistics.median(ts[5:]), sorted(ts[5:])[int(0.9 * (n - 5))]), flush=True)
 
 
+if os.environ.get("EVAL_FIRST"):            # an evaluation before the first training step: its streams are created first
+    tr.predict(A[0], next_batch=A[1])
+    tr.predict(A[1])
+    tr.close()
 session("session 1")
 for k in range(int(os.environ.get("SESSIONS", 3))):
     tr.close()
