@@ -554,6 +554,8 @@ def main():
             step(i)
             marks.append(time.perf_counter())     # (host time at which step i's call returned: update() ends with the step's loss readback)
             enq.append((getattr(tr, "host_enqueued_at", ts) - ts) * 1e3)      # host time until the whole step was enqueued (train mode)
+        if a.mode == "train":
+            tr.flush_readback()               # the last step's loss and NaN flag are read (and asserted) inside the bracket too
     sync()
     dt = time.perf_counter() - t0
     # the spread of the timed steps, always on the line: a uniform slow run, a transient and a slow first step look different here
