@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256) void pool_mix_cols_ln_reg_kernel(const float* 
                                                                    const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H,
                                                                    PoolLN ln) {
   constexpr int LB = 6, WPB = RUART_POOL_LN_WPB;
-  static_assert(NLT % LB == 0 && 2 * NLT <= 64, "layers are loaded six at a time; one lane per (layer, piece) statistic");
+  static_assert(NLT % LB == 0, "layers are loaded six at a time");
   const int col = threadIdx.x * 4;                       // blockDim.x = H / 4
   f32x4_t g[NLT], be[NLT];
   float wgt[NLT];
@@ -1540,14 +1540,12 @@ __global__ __launch_bounds__(256) void pool_mix_cols_ln_reg_kernel(const float* 
     const int st_last = span_start_last ? span_start_last[w] : st;
     const float inv = 1.0f / (float)n;
     f32x4_t acc = bsum;
-    // the (mu, rstd) of the word's first two pieces in every layer: ONE load per lane - lane 2 l + p of each wave fetches layer l,
-    // piece p - and a readlane per use, instead of 2 NLT broadcast loads per lane
-    const int sl = min((threadIdx.x & 63) >> 1, NLT - 1), sp = min((int)(threadIdx.x & 1), n - 1);
-    const float2 smine = ln.stats[(size_t)sl * ln.stats_stride + (sl == NLT - 1 ? st_last : st) + sp];
-    auto stat_of = [&](int l, int p) {
-      return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.x), 2 * l + p)),
-                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.y), 2 * l + p)));
-    };
+    // The (mu, rstd) pairs are wave-uniform (word, layer, piece): the compiler turns these into SCALAR loads (s_load_dwordx2 / x4
+    // through the scalar cache) - no vector-memory slot, no broadcast.  (A form that fetched the word's 24 pairs with ONE vector load
+    // per lane and read them back with v_readlane was 6 % faster and WRONG under load: the scores of a three-stream forward differed
+    // from the one-stream forward's by up to 1e-3 from run to run, tools/r05_race_probe.py - the readlanes saw the register before
+    // the load had landed.  Removed.)
+    auto stat_of = [&](int l, int p) { return ln.stats[(size_t)l * ln.stats_stride + (l == NLT - 1 ? st_last : st) + min(p, n - 1)]; };
     auto body = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
 #pragma unroll
