@@ -53,6 +53,8 @@ def fwd(streams):
     net.train()
     net.drop_emb = False
     def f():
+        if streams and os.environ.get("PREFETCH"):          # the encoder pass on the CU-masked run-ahead stream instead of inline
+            net.Bert.prefetch(net.prepare(b[0], b[1], b[2]).packed)
         with torch.no_grad():
             return net(b[0], b[1], b[2])[0]
     s = tr.on_step_stream(f)
