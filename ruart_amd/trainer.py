@@ -504,8 +504,9 @@ class SDNetTrainer(BaseTrainer):
                 self.close()
             elif self.device.type == "cuda" and self.opt.get("ruart_empty_cache_after_eval", True):
                 # an evaluation inside train(): its no-grad forwards leave the caching allocator with a block layout the training steps
-                # would go on reusing - measured 0.7-1.0 ms per training step (bench.py's parity check); handing
-                # the cached blocks back costs a few re-allocations in the next step
+                # would go on reusing - measured 0.7-1.0 ms per training step under the schedule of the time (bench.py's parity check,
+                # DESIGN.md section 5 (11); under the final schedule of (12) the effect was no longer measurable); handing the cached
+                # blocks back costs a few re-allocations in the next step
                 torch.cuda.synchronize(self.device)
                 torch.cuda.empty_cache()
 
