@@ -1593,6 +1593,110 @@ __global__ __launch_bounds__(256) void pool_mix_cols_ln_reg_kernel(const float* 
   }
 }
 
+#ifdef RUART_POOL_RL_DIAG
+// DIAGNOSTIC BUILDS ONLY (tools/build_variant_all.sh rl -DRUART_POOL_RL_DIAG; tools/r06_readlane_diag.sh): the form of the kernel above that
+// commit 728930f removed - a word's 24 (mu, rstd) pairs fetched by ONE vector load per lane and read back with v_readlane - so that
+// the nondeterminism it was removed for can be examined instead of narrated.  MODE 0: as removed.  MODE 1: a full
+// `s_waitcnt vmcnt(0)` behind the statistics load (if the counted wait the compiler emits were the problem, this form is clean).
+// MODE 2: the row loads with the default cache policy (no mixing of policies in the wave's load queue).  MODE 3: the pairs go through
+// `__shfl` (ds_bpermute) instead of v_readlane (the cross-lane read itself).  MODE 4: v_readlane, its scalar results copied into
+// VGPRs at once.  MODE 5: sixteen wait states behind every pair of v_readlane.  MODE 6: v_readlane, the long-lived copies made by s_mov_b32.
+// Selected with ruart_bert_pool_ln_set_variant(10 + MODE).
+template <int NLT, int MODE>
+__global__ __launch_bounds__(256) void pool_mix_cols_ln_rl_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl,
+                                                                  const int* __restrict__ span_start, const int* __restrict__ span_start_last,
+                                                                  const int* __restrict__ span_len, const int* __restrict__ dst_row,
+                                                                  const float* __restrict__ wl, float* __restrict__ out, int ldo, int W, int H,
+                                                                  PoolLN ln) {
+  constexpr int LB = 6, WPB = RUART_POOL_LN_WPB;
+  static_assert(NLT % LB == 0 && 2 * NLT <= 64, "layers are loaded six at a time; one lane per (layer, piece) statistic");
+  const int col = threadIdx.x * 4;
+  f32x4_t g[NLT], be[NLT];
+  float wgt[NLT];
+  f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < NLT; ++l) {
+    g[l] = load4(ln.g + (size_t)l * H + col);
+    be[l] = load4(ln.b + (size_t)l * H + col);
+    wgt[l] = wl[l];
+    bsum += be[l] * wgt[l];
+  }
+  auto ldrow = [&](const float* p) { return MODE == 2 ? load4(p) : load4_stream(p); };
+  for (int wi = 0; wi < WPB; ++wi) {
+    const int w = blockIdx.x * WPB + wi;
+    if (w >= W) break;
+    const int st = span_start[w], n = span_len[w];
+    const int st_last = span_start_last ? span_start_last[w] : st;
+    const float inv = 1.0f / (float)n;
+    f32x4_t acc = bsum;
+    const int sl = min((threadIdx.x & 63) >> 1, NLT - 1), sp = min((int)(threadIdx.x & 1), n - 1);
+    const float2 smine = ln.stats[(size_t)sl * ln.stats_stride + (sl == NLT - 1 ? st_last : st) + sp];
+    if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto stat_of = [&](int l, int p) {
+      if (MODE == 3) return make_float2(__shfl(smine.x, 2 * l + p, 64), __shfl(smine.y, 2 * l + p, 64));
+      int rx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.x), 2 * l + p);
+      int ry = __builtin_amdgcn_readlane(__builtin_bit_cast(int, smine.y), 2 * l + p);
+      if (MODE == 4) {                  // the scalar results copied into VGPRs at once: no SGPR holds a statistic beyond two instructions
+        int vx, vy;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vx), "=v"(vy) : "s"(rx), "s"(ry));
+        return make_float2(__builtin_bit_cast(float, vx), __builtin_bit_cast(float, vy));
+      }
+      if (MODE == 5) asm volatile("s_nop 7\n\ts_nop 7" : "+s"(rx), "+s"(ry));      // sixteen wait states between v_readlane and any reader of its SGPRs
+      if (MODE == 6) {                  // the long-lived copies are written by the SCALAR unit (s_mov_b32), the v_readlane results die at once
+        int cx, cy;
+        asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(cx), "=s"(cy) : "s"(rx), "s"(ry));
+        return make_float2(__builtin_bit_cast(float, cx), __builtin_bit_cast(float, cy));
+      }
+      return make_float2(__builtin_bit_cast(float, rx), __builtin_bit_cast(float, ry));
+    };
+    auto body = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+#pragma unroll
+      for (int lb = 0; lb < NLT; lb += LB) {
+        f32x4_t v[LB][TWO ? 2 : 1];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const int l = lb + j;
+          const int r0 = (l == NLT - 1 ? st_last : st);
+          const float* base = layers + (size_t)l * layer_stride + (size_t)r0 * ldl + col;
+          v[j][0] = ldrow(base);
+          if (TWO) v[j][TWO ? 1 : 0] = ldrow(base + (size_t)ldl);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+          const float2 s0 = stat_of(lb + j, 0), s1 = stat_of(lb + j, TWO ? 1 : 0);
+          f32x4_t x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            x[r] = (v[j][0][r] - s0.x) * s0.y;
+            if (TWO) x[r] += (v[j][TWO ? 1 : 0][r] - s1.x) * s1.y;
+          }
+          acc += (x * g[lb + j]) * (wgt[lb + j] * inv);
+        }
+        if (TWO && n > 2) {
+#pragma unroll
+          for (int j = 0; j < LB; ++j) {
+            const int r0 = (lb + j == NLT - 1 ? st_last : st);
+            const float* base = layers + (size_t)(lb + j) * layer_stride + (size_t)r0 * ldl + col;
+            for (int p = 2; p < n; ++p) {
+              const float2 s2 = ln.stats[(size_t)(lb + j) * ln.stats_stride + r0 + p];
+              const f32x4_t y = ldrow(base + (size_t)p * ldl);
+              f32x4_t x;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[r] = (y[r] - s2.x) * s2.y;
+              acc += (x * g[lb + j]) * (wgt[lb + j] * inv);
+            }
+          }
+        }
+      }
+    };
+    if (n > 1) body(std::true_type{});
+    else body(std::false_type{});
+    store4(out + (size_t)dst_row[w] * ldo + col, acc);
+  }
+}
+#endif
+
 // d(loss)/d(wl[l]) partial of one word over pre-LayerNorm rows: <grad_out[dst_row[w]], gamma_l (mean of the word's normalised rows) + beta_l>
 template <int NG>
 __global__ __launch_bounds__(256) void pool_mix_bwd_ln_kernel(const float* __restrict__ layers, size_t layer_stride, int ldl, int NL,
@@ -1729,6 +1833,9 @@ extern "C" int ruart_rows_stats_finish(const float* part, int np, int rows, floa
 
 static int g_pool_ln_reg = 1;      // 1: twelve-layer encoders take the register-table form of the pooling kernel (0: A/B runs)
 extern "C" int ruart_bert_pool_ln_set_variant(int reg_tables) {
+#ifdef RUART_POOL_RL_DIAG
+  if (reg_tables >= 10 && reg_tables <= 16) { g_pool_ln_reg = reg_tables; return 0; }      // diagnostic builds: the removed readlane forms
+#endif
   g_pool_ln_reg = reg_tables < 0 ? 0 : (reg_tables > 2 ? 2 : reg_tables);      // 2: the backward's register-table form too (slower, A/B runs)
   return 0;
 }
@@ -1740,6 +1847,16 @@ extern "C" int ruart_bert_pool_mix_ln(const float* layers_pre, long long layer_s
   if (H % 256 || H <= 0 || H > 1024 || n_words <= 0 || n_layers > POOL_MAX_LAYERS || n_layers <= 0 || !ln_stats || !ln_gamma || !ln_beta)
     return (int)hipErrorInvalidValue;
   const PoolLN ln{(const float2*)ln_stats, (size_t)stats_stride, ln_gamma, ln_beta};
+#ifdef RUART_POOL_RL_DIAG
+#define RL_LAUNCH(MODE) hipLaunchKernelGGL((pool_mix_cols_ln_rl_kernel<12, MODE>), dim3(ceil_div(n_words, RUART_POOL_LN_WPB)), dim3(H / 4), 0, (hipStream_t)stream, layers_pre, (size_t)layer_stride, ldl, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln)
+  if (n_layers == 12 && g_pool_ln_reg >= 10) {
+    switch (g_pool_ln_reg) { case 10: RL_LAUNCH(0); break; case 11: RL_LAUNCH(1); break; case 12: RL_LAUNCH(2); break; case 13: RL_LAUNCH(3); break;
+                             case 14: RL_LAUNCH(4); break; case 15: RL_LAUNCH(5); break; default: RL_LAUNCH(6); }
+    RUART_CHECK_LAUNCH();
+    return 0;
+  }
+#undef RL_LAUNCH
+#endif
   if (n_layers == 12 && g_pool_ln_reg)
     hipLaunchKernelGGL(pool_mix_cols_ln_reg_kernel<12>, dim3(ceil_div(n_words, RUART_POOL_LN_WPB)), dim3(H / 4), 0, (hipStream_t)stream, layers_pre,
                        (size_t)layer_stride, ldl, span_start, span_start_last, span_len, dst_row, layer_w, out, ldo, n_words, H, ln);

@@ -154,6 +154,12 @@ __global__ __launch_bounds__(256) void gemm_16_nt_128(const T16* __restrict__ A,
 // ------------------------------------------------------------------------------------------------
 #define BM4 256
 #define BN4 256
+// Counted waits of the four-phase loop (gemm_16_nt_256p8): 1 = three waits per K-tile, each in front of the phase that precedes the
+// first read of what it covers, five half-tiles in flight; 0 = one wait per K-tile for the whole next tile (the product).  Round 6: equal
+// times (gemm_corr.hip has the numbers); diagnostic build only.
+#ifndef RUART_P8_WAITS
+#define RUART_P8_WAITS 0
+#endif
 template <typename T16, bool OUT_F32, int RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
@@ -585,6 +591,10 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     __builtin_amdgcn_sched_barrier(0);
     if (rd) read_a(D, 0);
     if (S1 && !(ab & 16)) stage_a(D ^ 1, 1, t + 1);
+#if RUART_P8_WAITS
+    // (this tile's W-h1, read one phase on, has landed; five younger half-tiles may be in flight)
+    if (N1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W-h0 reads (issued first) are back: its slot may be restaged
     RUART_BAR();
     if (RUART_P8_FULLWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -593,6 +603,10 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     // phase 1: (rows h0, cols h1); prefetch (t+2, W-h0)
     if (rd) read_w(D, 1, wf1);
     if (S2 && !(ab & 16)) stage_w(D, 0, t + 2);
+#if RUART_P8_WAITS
+    // (this tile's A-h1 has landed)
+    if (N2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (N1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     RUART_BAR();
     if (RUART_P8_FULLWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (S2) quad(1, 0, wf1, [&] { stage_w(D, 0, t + 2); }); else quad(1, 0, wf1, nothing);
@@ -605,6 +619,15 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     if (S2) quad(1, 1, wf1, [&] { stage_a(D, 0, t + 2); }); else quad(1, 1, wf1, nothing);
     RUART_BAR();
     // phase 3: (rows h1, cols h0) - operands already in registers; prefetch (t+2, W-h1)
+#if RUART_P8_WAITS
+    // (K-tile t+1's W-h0 and A-h0 have landed)
+    if (N2) {
+      if (S2) stage_w(D, 1, t + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (N1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+#else
     if (N2) {
       if (!(ab & 16)) {
         if (S2) stage_w(D, 1, t + 2);
@@ -615,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
     } else if (N1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // last prefetch: (t+1, A-h1) from phase 0
     }
+#endif
     RUART_BAR();
     if (S2) quad(0, 1, wf0, [&] { stage_w(D, 1, t + 2); }); else quad(0, 1, wf0, nothing);
     RUART_BAR();
@@ -639,7 +663,11 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
   stage_w(1, 0, kb + 1);
   stage_a(1, 0, kb + 1);
   stage_w(1, 1, kb + 1);
+#if RUART_P8_WAITS
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // K-tile kb's W-h0 and A-h0 landed (this wave's share)
+#else
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile kb landed (this wave's share)
+#endif
   RUART_BAR();
   P8_STAMP(1);
 #if RUART_P8_BALANCED

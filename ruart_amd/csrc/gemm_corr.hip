@@ -33,6 +33,13 @@ typedef int i32x8_t __attribute__((ext_vector_type(8)));
 #define RUART_C8_FMT 0
 #endif
 
+// Counted waits of the K loop: 0 = one wait per K-tile for the whole next tile (three half-tiles in flight; the product since round 1),
+// 1 = three waits per K-tile, each one phase ahead of the first read of what it covers (five half-tiles in flight, every DMA piece has
+// >= 5 phases to land instead of >= 3).  Round 6 measured 1 against 0: race screen clean, time equal (layer 1 246 vs 1 258 us, step 21.98
+// vs 21.98 ms, profiles/r06_waits_ab.log) - the loop does not wait for its prefetch; kept as a diagnostic build.
+#ifndef RUART_P8_WAITS
+#define RUART_P8_WAITS 0
+#endif
 #define CBM 256
 #define CBN 256
 #define CBKB 128   // bytes of one row of one K-tile (64 f16 or 128 fp8)
@@ -282,7 +289,24 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             void* __restrict__ C, int ldc, unsigned char* __restrict__ C8, int M, int N,
                                                             int K, int order, int n8, int o8, int n_full, int S,
-                                                            float* __restrict__ slabs, const CorrFold f) {
+                                                            float* __restrict__ slabs, const CorrFold f
+#ifdef RUART_P8_STAMPS
+                                                            , unsigned long long* __restrict__ stamps
+#endif
+) {
+  // diagnostic builds (tools/build_variant.sh stamps -DRUART_P8_STAMPS; tools/r06_corr_stamps.py): s_memrealtime (100 MHz) per workgroup at
+  // start / pipeline filled / f16 run done / fp8 run done / epilogue's stores drained, and where the workgroup ran (XCC_ID, HW_ID)
+#ifdef RUART_P8_STAMPS
+  // (per WAVE: [workgroup][wave][8])
+#define C8_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0) stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  if (stamps && (threadIdx.x & 63) == 0) {
+    stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 6] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+  }
+#else
+#define C8_STAMP(i)
+#endif
+  C8_STAMP(0);
   constexpr int kHalf = 128 * CBKB;              // 16 KB half-tile
   constexpr int kOper = 2 * kHalf;               // 32 KB per operand K-tile
   constexpr int kBuf = 2 * kOper;                // 64 KB per K-tile
@@ -396,6 +420,10 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
     __builtin_amdgcn_sched_barrier(0);
     read_a(D, 0);
     if (N1) stage_a(D ^ 1, 1, t + 1);
+#if RUART_P8_WAITS
+    // (this tile's W-h1, read one phase on, has landed; five younger half-tiles may be in flight - P8_VMCNT below)
+    if (N1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 4 W-h0 reads (issued first) are back: its slot may be restaged
     RUART_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -403,6 +431,10 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
     RUART_BAR();
     read_w(D, 1, wf1);
     if (N2) stage_w(D, 0, t + 2);
+#if RUART_P8_WAITS
+    // (this tile's A-h1 has landed)
+    if (N2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (N1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     RUART_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     quad(f8tag, 1, 0, wf1);
@@ -413,12 +445,22 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     quad(f8tag, 1, 1, wf1);
     RUART_BAR();
+#if RUART_P8_WAITS
+    // (K-tile t+1's W-h0 and A-h0 have landed)
+    if (N2) {
+      stage_w(D, 1, t + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (N1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+#else
     if (N2) {
       stage_w(D, 1, t + 2);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile t+1 complete; the 3 youngest half-tiles stay in flight
     } else if (N1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#endif
     RUART_BAR();
     quad(f8tag, 0, 1, wf0);
     RUART_BAR();
@@ -442,8 +484,16 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   stage_w(1, 0, kb + 1);
   stage_a(1, 0, kb + 1);
   stage_w(1, 1, kb + 1);
+#if RUART_P8_WAITS
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // K-tile kb's W-h0 and A-h0 landed (this wave's share)
+#else
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // K-tile kb landed (this wave's share)
+#endif
   RUART_BAR();
+  C8_STAMP(1);
+#ifdef RUART_P8_STAMPS
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();      // shader clock over the K loop (slot 5): cycles per K-tile, in-loop clock
+#endif
   if (wave >= 4) RUART_BAR();                                 // stagger: waves 4-7 run one barrier behind
   // The K loop as two optional runs - K-tiles [a0, a1) of the f16 phase, then [b0, b1) of the fp8 phase (each empty or an even count
   // >= 2): the whole product is (0, nt, nt, NT), a slice lives in one of the two, the no-correction ablation is (0, nt) alone.  The
@@ -466,6 +516,7 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
       tile(Ff{}, I1{}, Ff{}, Ff{}, t + 1);
     }
   }
+  C8_STAMP(2);
   if (b0 < b1) {
     int t = b0;
     for (; t + 2 < b1; t += 2) {
@@ -477,6 +528,10 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   }
   if (wave < 4) RUART_BAR();                                  // waves 0-3 pair the lagging group's last barrier
   RUART_BAR();                                                // every wave is done reading operand tiles
+  C8_STAMP(3);
+#ifdef RUART_P8_STAMPS
+  if (stamps && (threadIdx.x & 63) == 0) stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 5] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
 
   if (slice >= 0) {
     // partial sums of this slice, thread-major ([i][j][tid] x 4 floats: 16-byte coalesced stores, read back the same way)
@@ -488,6 +543,10 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
     return;
   }
   corr_epilogue<EPI, FOLD>(acc, smem, m0, n0, bias, R, ldr, C, ldc, C8, N, 0, 4, f);
+#ifdef RUART_P8_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  C8_STAMP(4);
 }
 
 // Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices IN SLICE ORDER (deterministic), then the
@@ -538,6 +597,9 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_fixup(const float* __restrict
 }
 
 extern int g_tile_order, g_tile_order_auto;
+#ifdef RUART_P8_STAMPS
+extern unsigned long long* g_p8_stamps;
+#endif
 // GROUP_M of the tile walk: ruart_tile_group_m (gemm_shared.h) unless ruart_gemm_set_tile_order pinned a value.  L2-miss traffic moves the
 // OTHER way (smallest at GROUP_M 2-3, profiles/r03_gemm_order_sweep_fetch.log): it is not what bounds this kernel.
 static inline int corr_tile_order(int M, int N, int K) {
@@ -596,7 +658,11 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
   (void)done;
   hipLaunchKernelGGL(kern, dim3(p.n_full + p.r * p.S), dim3(512), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
                      (const char*)W8, 2 * ldw, bias, residual, ldr, C, ldc, (unsigned char*)C8, M, N, K, order, n8, o8, p.n_full, p.S,
-                     (float*)tail_ws, fold);
+                     (float*)tail_ws, fold
+#ifdef RUART_P8_STAMPS
+                     , g_p8_stamps
+#endif
+                     );
   if (p.r > 0) {
     constexpr int flds = 8 * 32 * 272;                    // the epilogue's staging image
     auto fix = gemm_16c_fixup<EPI>;

@@ -1138,7 +1138,10 @@ def test_gemm_16c_fold_consumer(M, N, K, gelu):
     X16, X8 = split_f16c(x.float())
     V16, V8 = _w8(W)
     U = torch.zeros(M, N, dtype=torch.float32, device=d)
-    rc = lib.ruart_gemm_16c_nt(hip.ptr(X16.to(d)), hip.ptr(X8.to(d)), K, hip.ptr(V16.to(d)), hip.ptr(V8.to(d)), K, hip.ptr(bias.to(d)), None, 0,
+    # (named device copies: a temporary inside hip.ptr(...) is freed as soon as its address is taken, and the caching allocator may hand
+    # the block to the next temporary of the same call - the product then reads another operand's bytes)
+    X16d, X8d, V16d, V8d, biasd = map(dv, (X16, X8, V16, V8, bias))
+    rc = lib.ruart_gemm_16c_nt(hip.ptr(X16d), hip.ptr(X8d), K, hip.ptr(V16d), hip.ptr(V8d), K, hip.ptr(biasd), None, 0,
                                hip.ptr(U), N, None, M, N, K, hip.ACT_NONE, hip.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
