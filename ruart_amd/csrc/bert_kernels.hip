@@ -1543,8 +1543,12 @@ __global__ __launch_bounds__(256) void pool_mix_cols_ln_reg_kernel(const float* 
     // The (mu, rstd) pairs are wave-uniform (word, layer, piece): the compiler turns these into SCALAR loads (s_load_dwordx2 / x4
     // through the scalar cache) - no vector-memory slot, no broadcast.  (A form that fetched the word's 24 pairs with ONE vector load
     // per lane and read them back with v_readlane was 6 % faster and WRONG under load: the scores of a three-stream forward differed
-    // from the one-stream forward's by up to 1e-3 from run to run, tools/r05_race_probe.py - the readlanes saw the register before
-    // the load had landed.  Removed.)
+    // from the one-stream forward's by up to 1e-3 from run to run, tools/r05_race_probe.py.  Round 5 blamed an early read of the load;
+    // round 6 refuted that - its counted wait was right, loads of both cache policies return in issue order
+    // (tools/r06_load_order_probe.hip), a full vmcnt(0) changes nothing - and found that the fault follows the BUILD of that
+    // kernel: clean with the values moved to VGPRs (ds_bpermute, or v_mov behind the v_readlane) and clean when the same source is
+    // compiled with -fno-slp-vectorize; DESIGN.md section 5, profiles/r06_readlane_diag.log.  The form stays out; its source is
+    // kept for diagnostic builds under RUART_POOL_RL_DIAG below.)
     auto stat_of = [&](int l, int p) { return ln.stats[(size_t)l * ln.stats_stride + (l == NLT - 1 ? st_last : st) + min(p, n - 1)]; };
     auto body = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
