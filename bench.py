@@ -468,8 +468,28 @@ def main():
     # profiles/r05_knob_sweep.log; emptying the cache afterwards recovered most runs, not all).  RUART_BENCH_PARITY_FIRST=1: the old order.
     if want_parity and os.environ.get("RUART_BENCH_PARITY_FIRST") == "1":
         parity = live_parity(tr, opt, batches[0], golden)
+        if parity is not None:
+            parity["checked_on"] = "the timed trainer, before its warm-up (RUART_BENCH_PARITY_FIRST=1)"
         note("parity vs the reference's golden scores: %s" % parity)
         want_parity = False
+    # Round 6 (advisor): the TIMED trainer is checked too - one forward of batch 0 in the timed schedule (the encoder pass on the
+    # run-ahead stream, three-stream trunk, on the step stream) while its weights are still the seeded ones; the scores stay on the
+    # device and are compared with the reference's after the timed region (no host sync here).  RUART_BENCH_TIMED_PARITY=0 skips it.
+    timed_scores = None
+    if want_parity and a.mode == "train" and os.environ.get("RUART_BENCH_TIMED_PARITY", "1") != "0":
+        import ruart_amd.layers as _L
+        _L.set_dropout_prob(0.0)
+        tr.network.train()
+        tr.network.drop_emb = False
+        b0_ = batches[0]
+
+        def _fwd0():
+            if not a.no_prefetch:
+                tr.network.prefetch_bert(b0_[0], b0_[1], b0_[2])        # the pass runs where the timed steps' passes run
+            with torch.no_grad():
+                return tr.network(b0_[0], b0_[1], b0_[2])[0].float().clone()
+        timed_scores = tr.on_step_stream(_fwd0)
+        _L.set_dropout_prob(0.0 if "DROPOUT" not in opt else float(opt["DROPOUT"]))
 
     def fresh(i):
         """The batch of step i: pre-staged on the device (default) or shipped from its host copy now (--include-h2d)."""
@@ -688,6 +708,15 @@ def main():
         try:
             b0 = tr2.ToCUDA(synth.synthetic_batch(opt, a.batch, seed=7 + 1000 * rank, n_q=30, n_ocr=n_ocr, n_od=n_od))
             parity = live_parity(tr2, opt, b0, golden)
+            if parity is not None:
+                parity["checked_on"] = "a replica: a second trainer built from the same seeds after the timed region (inline encoder pass)"
+                if timed_scores is not None:
+                    zz = np.load(golden)
+                    if tuple(zz["scores"].shape) == tuple(timed_scores.shape):
+                        dd = np.abs(timed_scores.cpu().numpy() - zz["scores"])
+                        parity["timed_trainer"] = {"max_abs_err_vs_reference": float("%.3g" % dd.max()), "holds": bool(dd.max() < 1e-3),
+                                                   "what": "the timed trainer's own forward of batch 0 before its first update, in the timed "
+                                                           "schedule (run-ahead encoder stream, three-stream trunk)"}
         finally:
             torch.cuda.synchronize()
             tr2.network.Bert.close(destroy=True)

@@ -586,6 +586,8 @@ class Bert(nn.Module):
         precision = precision_of(opt, cfg["hidden_size"] if cfg["intermediate_size"] % 256 == 0 else 1)
         # LayerNorms folded into the projections (fp16c; csrc/gemm_corr.hip, CorrFold): on unless opt['bert_ln_fold'] / RUART_LN_FOLD say 0
         fold = bool(int(opt.get("bert_ln_fold", os.environ.get("RUART_LN_FOLD", 1))))
+        if int(opt.get("bert_tail_cus", os.environ.get("RUART_TAIL_CUS", 0)) or 0) > 0:
+            fold = False                     # the tail split exists in the unfolded pass only (ruart_bert_forward_folded refuses it)
         self.weights = BertEncoderWeights(state, cfg, self._device, precision, ln_fold=fold)
         self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
         self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path
@@ -737,15 +739,14 @@ class Bert(nn.Module):
 
     def close(self, destroy=None):
         """End of a training / evaluation session: the pass that is still running ahead is dropped.  ``destroy``: also destroy the
-        CU-masked run-ahead stream (hip.destroy_stream; a later prefetch creates a new one).  True at the end of a process (bench.py,
-        the tools) - a masked stream alive at static destruction takes a process profiled under rocprofv3 down in __cxa_finalize -
-        and by default (None) exactly when a profiler is attached or RUART_DESTROY_STREAMS=1.  Otherwise the stream is KEPT for the
+        CU-masked run-ahead stream (hip.destroy_stream; a later prefetch creates a new one).  True at the end of a process
+        (``SDNetTrainer.close(final=True)``: bench.py, the tools, __graft_entry__) - a masked stream alive at static destruction takes a
+        process with an HSA tool library loaded (rocprofv3 ...) down in __cxa_finalize.  Otherwise (None) the stream is KEPT for the
         next session: a new masked stream lands on another hardware queue slot, and with an evaluation's streams created in between
         it shared a slot with one of the trunk's streams - every later training step took 27.3 ms instead of 22.1
         (tools/r05_two_sessions.py)."""
         if destroy is None:
-            destroy = os.environ.get("RUART_DESTROY_STREAMS") == "1" or any(
-                "rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+            destroy = os.environ.get("RUART_DESTROY_STREAMS") == "1"        # (experiments; the product decides through SDNetTrainer.close(final=))
         if self._pending is not None:
             self._pending._layers = None
             self._pending = None

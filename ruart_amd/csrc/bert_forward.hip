@@ -178,6 +178,10 @@ extern "C" int ruart_bert_forward_folded(const ruart_bert_model* m, const ruart_
     return (int)hipErrorInvalidValue;
   if (!m->w8_qkv || !m->w8_ao || !m->w8_ff1 || !m->w8_ff2) return (int)hipErrorInvalidValue;
   if (workspace_bytes < ruart_bert_workspace_bytes_folded(m, R)) return (int)hipErrorInvalidValue;
+  // The folded pass always runs both correction products in every layer and never splits a tail: the ablation knobs of the unfolded
+  // pass (ruart_bert_set_correction, ruart_bert_model.tail_cus) are refused here instead of being silently ignored (advisor, round 5)
+  if (m->tail_cus > 0 || g_corr_layers != ~0ull || g_corr_site[0] != 3 || g_corr_site[1] != 3 || g_corr_site[2] != 3 || g_corr_site[3] != 3)
+    return (int)hipErrorNotSupported;
   const int np = H / 256;
   Carve c{(char*)workspace, 0};
   float* x32 = (float*)c.take((size_t)R * H * 4);

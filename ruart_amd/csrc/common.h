@@ -173,13 +173,66 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4_t v, float scale) {
   w = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], w, true);
   return (unsigned)w;
 }
+// The same bytes with the scale folded into the conversion (round 6): e4m3(clamp(x 2^s, -448, 448)) == v_cvt_scalef32_pk_fp8_f32 of
+// clamp(x, -448 / 2^s, 448 / 2^s) with the scale operand 2^-s - bit for bit on every non-NaN f32 (tools/r06_cvt_probe.hip swept 10^8
+// patterns on the device; the scaled conversion by itself does NOT saturate, an overflow gives the NaN code, so the clamp stays).
+// One v_mul_f32 per element less than pack_fp8x4.  `s` = log2 of the scale, a compile-time constant >= 1.
+template <int S>
+__device__ __forceinline__ unsigned pack_fp8x4_shift(f32x4_t v) {
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  constexpr float lim = 448.0f / (float)(1 << S), inv = 1.0f / (float)(1 << S);
+  f32x4_t c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = __builtin_amdgcn_fmed3f(v[r], -lim, lim);
+  s16x2_t w = {0, 0};
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c[0], c[1], inv, false);
+  w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, c[2], c[3], inv, true);
+  return (unsigned)__builtin_bit_cast(int, w);
+}
+// x - (float)h for the low / high half of a packed f16 pair: one v_fma_mix_f32 (x * 1.0 - h with the f16 operand read straight from the
+// packed register; exact in fp32, so the same bits as the C++ form, which hipcc compiles to v_cvt_f32_f16 + v_sub_f32)
+__device__ __forceinline__ float sub_f16_lo(float x, unsigned h2) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(h2));
+  return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float x, unsigned h2) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(h2));
+  return r;
+}
+// RUART_SPLIT_FAST=0 (a -D flag): the round-2 instruction sequence of the split stores (A/B builds); the bytes are the same
+#ifndef RUART_SPLIT_FAST
+#define RUART_SPLIT_FAST 1
+#endif
+// the three parts of 4 consecutive values in the split form: f16 x 4 (two packed words), the lo8 word, the hi8 word
+__device__ __forceinline__ void split4_words(f32x4_t v, unsigned& h01, unsigned& h23, unsigned& lo8, unsigned& hi8) {
+  typedef f16_t f16x2v __attribute__((ext_vector_type(2)));
+  const f16x2v a = {(f16_t)v[0], (f16_t)v[1]}, b = {(f16_t)v[2], (f16_t)v[3]};
+  h01 = __builtin_bit_cast(unsigned, a);
+  h23 = __builtin_bit_cast(unsigned, b);
+#if RUART_SPLIT_FAST
+  const f32x4_t lo = {sub_f16_lo(v[0], h01), sub_f16_hi(v[1], h01), sub_f16_lo(v[2], h23), sub_f16_hi(v[3], h23)};
+  lo8 = pack_fp8x4_shift<RUART_C8_SA_LO>(lo);
+#else
+  const f32x4_t lo = {v[0] - (float)a[0], v[1] - (float)a[1], v[2] - (float)b[0], v[3] - (float)b[1]};
+  lo8 = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
+#endif
+#if RUART_C8_SA_HI == 0
+  hi8 = pack_fp8x4(v, 1.0f);
+#else
+  hi8 = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
+#endif
+}
 // store 4 consecutive values in the split form: p16 -> f16 row, p8 -> the row's lo8 bytes, p8 + hi_off -> its hi8 bytes
 __device__ __forceinline__ void store_split4(f16_t* p16, unsigned char* p8, int hi_off, f32x4_t v) {
-  const f16x4_t h = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
-  *reinterpret_cast<f16x4_t*>(p16) = h;
-  const f32x4_t lo = {v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]};
-  *reinterpret_cast<unsigned*>(p8) = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
-  *reinterpret_cast<unsigned*>(p8 + hi_off) = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  unsigned h01, h23, lo8, hi8;
+  split4_words(v, h01, h23, lo8, hi8);
+  const u32x2_t h = {h01, h23};
+  *reinterpret_cast<u32x2_t*>(p16) = h;
+  *reinterpret_cast<unsigned*>(p8) = lo8;
+  *reinterpret_cast<unsigned*>(p8 + hi_off) = hi8;
 }
 // Timing diagnostic (-DRUART_ABL_SPLIT8 in gemm_corr.hip; WRONG operand layout): both companions in one 8-byte store at p8x2 = the
 // row's byte 2 * column - what a [lo4 | hi4]-interleaved companion layout would allow.

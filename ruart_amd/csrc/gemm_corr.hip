@@ -62,7 +62,8 @@ __device__ __forceinline__ float gelu_erfc7(float x) {
   p = fmaf(p, a, -1.151110943e+00f);
   p = fmaf(p, a, -9.999998964e-01f);
   const float r = __builtin_amdgcn_exp2f(p);
-  return x * (x < 0.f ? r : 1.0f - r);
+  // x Phi(x) = max(x, 0) - |x| r  (x >= 0: x - x r; x < 0: x r): two instructions instead of compare + select + subtract + multiply
+  return fmaf(-fabsf(x), r, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
   f32x4_t r;
@@ -177,11 +178,17 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
         *reinterpret_cast<f32x4_t*>(my + (j * 16 + fr) * ERS + (i * 16 + fq * 4) * 4) = acc[i][hh * 2 + j];
     f32x4_t v[8], res[8];
     const int mrow = m0 + wm * 128 + hh * 32 + rrow;
+    // Row addresses as uniform base + 32-bit byte offset (the launcher checks that every operand spans < 4 GB): the stores take the
+    // saddr form and a row costs one v_add_u32 instead of a 64-bit multiply-add chain (~2 VALU instructions per element of a VALU-bound epilogue)
+    const unsigned e_c = (unsigned)(mrow * ldc + ncol), e_r = (unsigned)(mrow * ldr + ncol);            // element offsets of row mrow
+    const unsigned st_c = 4u * (unsigned)ldc, st_r = 4u * (unsigned)ldr;                                   // ... and of four rows on
+    auto at = [](const void* base, unsigned byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
+    auto atw = [](void* base, unsigned byte_off) { return reinterpret_cast<char*>(base) + byte_off; };
     if (EPI == 1 || EPI == 3) {
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr)
-        res[rr] = (RUART_NT_EPI & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(R + (size_t)(mrow + rr * 4) * ldr + ncol))
-                                     : load4(R + (size_t)(mrow + rr * 4) * ldr + ncol);
+        res[rr] = (RUART_NT_EPI & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(at(R, (e_r + rr * st_r) * 4u)))
+                                     : *reinterpret_cast<const f32x4_t*>(at(R, (e_r + rr * st_r) * 4u));
     }
     if constexpr (FOLD) {
       // v = rstd 2^s (acc - mu c) + d   (d arrives as `bias`)
@@ -203,18 +210,19 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
       f16_t* C16 = reinterpret_cast<f16_t*>(f.C16);
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
-        const size_t row = (size_t)(mrow + rr * 4);
+        const unsigned ec = e_c + rr * st_c;                 // element offset of this row's four columns in C / C16
         if (res_ln) {
           const float2 st = rstat[hh * 32 + rr * 4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) res[rr][r] = fmaf(gv[r], (res[rr][r] - st.x) * st.y, ev[r]);
         }
         v[rr] += res[rr];
-        store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+        *reinterpret_cast<f32x4_t*>(atw(C, ec * 4u)) = v[rr];
 #ifdef RUART_ABL_SPLIT8
-        store_split8_diag(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + 2 * ncol, v[rr]);
+        store_split8_diag(C16 + (size_t)ec, C8 + 2 * (size_t)ec, v[rr]);
 #elif !defined(RUART_ABL_FOLD_NOSPLIT)     // (timing diagnostic: kind 3 without its split copy)
-        store_split4(C16 + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+        // (a C8 row is 2 ldc bytes: lo8 halves at [0, N), hi8 halves at [N, 2N))
+        store_split4(reinterpret_cast<f16_t*>(atw(C16, ec * 2u)), reinterpret_cast<unsigned char*>(atw(C8, ec * 2u - (unsigned)ncol)), N, v[rr]);
 #endif
 #ifndef RUART_ABL_FOLD_NOSTATS        // (timing diagnostic: the epilogue without the rows' partial sums - wrong results downstream)
         const float s1 = row16_sum((v[rr][0] + v[rr][1]) + (v[rr][2] + v[rr][3]));
@@ -232,20 +240,20 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
 #endif
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const size_t row = (size_t)(mrow + rr * 4);
+      const unsigned ec = e_c + rr * st_c;
       if (EPI == 1) v[rr] += res[rr];
       if (EPI == 2)
 #ifdef RUART_ABL_NOFP8
-        *reinterpret_cast<f16x4_t*>(reinterpret_cast<f16_t*>(C) + row * ldc + ncol) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
+        *reinterpret_cast<f16x4_t*>(atw(C, ec * 2u)) = (f16x4_t){(f16_t)v[rr][0], (f16_t)v[rr][1], (f16_t)v[rr][2], (f16_t)v[rr][3]};
 #elif defined(RUART_ABL_SPLIT8)
-        store_split8_diag(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + 2 * ncol, v[rr]);
+        store_split8_diag(reinterpret_cast<f16_t*>(C) + (size_t)ec, C8 + 2 * (size_t)ec, v[rr]);
 #else
-        store_split4(reinterpret_cast<f16_t*>(C) + row * ldc + ncol, C8 + row * (2 * (size_t)ldc) + ncol, N, v[rr]);
+        store_split4(reinterpret_cast<f16_t*>(atw(C, ec * 2u)), reinterpret_cast<unsigned char*>(atw(C8, ec * 2u - (unsigned)ncol)), N, v[rr]);
 #endif
       else if ((EPI == 0 && (RUART_NT_EPI & 1)) || (EPI == 1 && (RUART_NT_EPI & 2)))
-        __builtin_nontemporal_store(v[rr], reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(C) + row * ldc + ncol));
+        __builtin_nontemporal_store(v[rr], reinterpret_cast<f32x4_t*>(atw(C, ec * 4u)));
       else
-        store4(reinterpret_cast<float*>(C) + row * ldc + ncol, v[rr]);
+        *reinterpret_cast<f32x4_t*>(atw(C, ec * 4u)) = v[rr];
     }
   }
   if constexpr (EPI == 3) {
@@ -596,6 +604,11 @@ __global__ __launch_bounds__(512, 2) void gemm_16c_fixup(const float* __restrict
 #undef TILE_OF
 }
 
+// the epilogue's 32-bit byte offsets: the output (fp32 at most: 4 bytes per element; its split companions are smaller) and the residual
+// must span less than 4 GB each
+static inline bool corr_spans_ok(int M, int ldc, int ldr) {
+  return (size_t)M * (size_t)ldc * 4 < ((size_t)1 << 32) && (size_t)M * (size_t)ldr * 4 < ((size_t)1 << 32);
+}
 extern int g_tile_order, g_tile_order_auto;
 #ifdef RUART_P8_STAMPS
 extern unsigned long long* g_p8_stamps;
@@ -645,6 +658,7 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
                         const float* residual, int ldr, void* C, int ldc, void* C8, int M, int N, int K, int corr, void* tail_ws,
                         size_t tail_ws_bytes, int cus, hipStream_t s, const CorrFold& fold = CorrFold{}) {
   constexpr int lds = 2 * 2 * CBM * CBKB;                // 128 KB
+  // (the epilogue addresses C, C16 / C8 and the residual with 32-bit byte offsets; every caller checks spans_ok first)
   const int nt = K / 64;
   const int n8 = corr == 3 ? nt : (corr ? nt / 2 : 0), o8 = corr == 2 ? nt / 2 : 0;
   const int tiles = (M / CBM) * (N / CBN), order = corr_tile_order(M, N, K);
@@ -683,6 +697,7 @@ extern "C" int ruart_gemm_16c_nt_ws(const void* A16, const void* A8, int lda, co
   if (corr < 0 || corr > 3 || ((corr == 1 || corr == 2) && K % 256)) return (int)hipErrorInvalidValue;
   if (M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
   if (!A16 || !A8 || !W16 || !W8 || !C) return (int)hipErrorInvalidValue;
+  if (!corr_spans_ok(M, ldc, residual ? ldr : 0)) return (int)hipErrorInvalidValue;
   // every argument check sits in front of ruart_prof_begin_: an error return never leaves a profiling event open
   if (act == RUART_ACT_GELU) {
     if (residual || !C8 || ldc < N) return (int)hipErrorInvalidValue;
@@ -716,6 +731,7 @@ extern "C" int ruart_gemm_16c_nt_fold(const void* A16, const void* A8, int lda, 
   RUART_ENTRY();
   if (M <= 0 || M % CBM || N % CBN || K % 128 || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K) return (int)hipErrorInvalidValue;
   if (!A16 || !A8 || !W16 || !W8 || !C || stat_len <= 0) return (int)hipErrorInvalidValue;
+  if (!corr_spans_ok(M, ldc, residual ? ldr : 0)) return (int)hipErrorInvalidValue;
   if (kind == 3) {
     if (!residual || !C16 || !C8 || !out_part || ldc < N || N > 256 * kFoldSlots || res_np > kFoldSlots || (res_part && (!res_gamma || !res_beta || res_np <= 0))) return (int)hipErrorInvalidValue;
   } else if (kind == 0 || kind == 2) {

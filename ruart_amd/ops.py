@@ -258,10 +258,11 @@ def mm(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scal
         if _span(b) >= _X3_SPAN_LIMIT and b.numel() < _X3_SPAN_LIMIT:
             b = b.contiguous()
         if _span(a) >= _X3_SPAN_LIMIT and a_keep is None and c_scale is None and M > 1:
+            # (rows of the product are independent: a b-side mask applies to both halves unchanged - it masks b's K x N elements)
             out = torch.empty(M, N, dtype=torch.float32, device=a.device) if out is None else out
             h = M // 2
-            mm(a[:h], b, bias, mode, out[:h], residual=None if residual is None else residual[:h])
-            mm(a[h:], b, bias, mode, out[h:], residual=None if residual is None else residual[h:])
+            mm(a[:h], b, bias, mode, out[:h], residual=None if residual is None else residual[:h], b_keep=b_keep, keep_scale=keep_scale, rpm=rpm)
+            mm(a[h:], b, bias, mode, out[h:], residual=None if residual is None else residual[h:], b_keep=b_keep, keep_scale=keep_scale, rpm=rpm)
             return out
         if max(_span(a), _span(b)) >= _X3_SPAN_LIMIT:
             raise ValueError("ops.mm: an operand spans >= 2^30 elements in a layout the split-bf16 kernel cannot address; split the product")

@@ -251,13 +251,15 @@ class SDNetTrainer(BaseTrainer):
                 torch.manual_seed(self.seed + 7919 * rank)
             self._rank_seeded = True
 
-    def close(self):
-        """End of a session: the deferred loss check, the encoder pass still running ahead (``Bert.close``).  A CU-masked stream
-        (hipExtStreamCreateWithCUMask, the default in the fp16c mode) that is still alive at static destruction makes a process
-        profiled under rocprofv3 die in __cxa_finalize: with a profiler attached (or RUART_DESTROY_STREAMS=1) the
-        stream is destroyed here, otherwise it is kept for the next session (a re-created one can land on a trunk stream's hardware
-        queue slot: ``Bert.close``).  ``train()``, a stand-alone ``evaluate()`` and ``predict_for_test()`` call this on every exit
-        path."""
+    def close(self, final=False):
+        """End of a session: the deferred loss check, the encoder pass still running ahead (``Bert.close``).  ``final=True`` - the
+        END OF THE PROCESS's use of this trainer (bench.py, the tools, ``__graft_entry__``, a script's last call) - also destroys the
+        CU-masked run-ahead stream (hipExtStreamCreateWithCUMask, the default in the fp16c mode): alive at static destruction it takes a
+        process with a tool library loaded (rocprofv3, any other HSA tool) down in __cxa_finalize.  Between
+        sessions (``train()``, a stand-alone ``evaluate()``, ``predict_for_test()`` call this without ``final`` on every exit path) the
+        stream is KEPT: a re-created one can land on a trunk stream's hardware queue slot (``Bert.close``).  The decision is the
+        caller's, not a guess from the environment (round 5 looked for "rocprof" in environment variables; RUART_DESTROY_STREAMS=1
+        still forces the destruction for experiments)."""
         import sys
         unwinding = sys.exc_info()[0] is not None      # called from a ``finally`` while another exception propagates
         try:
@@ -269,7 +271,7 @@ class SDNetTrainer(BaseTrainer):
         finally:
             bert = getattr(getattr(self, "network", None), "Bert", None)
             if bert is not None:
-                bert.close()
+                bert.close(destroy=True if final else None)
 
     def ToCUDA(self, batch):
         """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host copies,
@@ -576,6 +578,9 @@ class SDNetTrainer(BaseTrainer):
         finally:
             self._in_train = False
             self._in_train_loop = False
+            if self.__dict__.pop("_gc_frozen", False):
+                import gc
+                gc.unfreeze()                # the permanent generation of _train is handed back: train() leaves the interpreter as it found it
             self.close()
 
     def _train(self, train_loader, val_loader, eval_every, log_every):
@@ -607,6 +612,7 @@ class SDNetTrainer(BaseTrainer):
             import gc
             gc.collect()
             gc.freeze()
+            self._gc_frozen = True           # (train()'s finally unfreezes)
 
         def stage():                                                  # the next batch of the loader, shipped to the device (or None)
             b = next(it, None)
@@ -629,7 +635,9 @@ class SDNetTrainer(BaseTrainer):
                 batch, nxt = nxt, (self.staged if nxt is not None else None)
                 self.staged = None
                 if batch_i % log_every == 0:
-                    log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, loss)
+                    # (a deferred loss is resolved by float(): the running average beside it then includes this step, as in the reference)
+                    cur = float(loss)
+                    log.info("updates[%6d] train loss[%8.5f / %8.5f]", self.updates, self.train_loss.avg, cur)
                 batch_i += 1
             self._in_train_loop = False
             self.flush_readback()                            # the last step's loss and asserts

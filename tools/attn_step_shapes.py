@@ -52,4 +52,4 @@ for (sa, sk, sv, hasd, relu), cnt in sorted(calls.items(), key=lambda kv: -kv[1]
 for f in FORMS:
     print("form %d: sum fwd+bwd over the step: %.2f ms (standalone, includes host launch gaps)" % (f, tot[f] / 1e3))
 hip.check(hip.load().ruart_attn_set_prefetch(1), "set_prefetch")
-tr.close()
+tr.close(final=True)

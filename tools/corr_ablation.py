@@ -37,7 +37,7 @@ def T(a):
 
 def build(z, cfg, **extra):
     from ruart_amd.sdnet import SDNet
-    opt = default_opt(vocab_size=int(z["vocab_size"]), cuda=True, device=DEV, bert_precision="fp16c", **extra)
+    opt = default_opt(vocab_size=int(z["vocab_size"]), cuda=True, device=DEV, bert_precision="fp16c", bert_ln_fold=0, **extra)      # (the per-site knobs exist in the unfolded pass only)
     opt["bert_state"], opt["bert_config"] = synth.make_bert_weights(cfg, seed=int(z["seed"]), w_std=float(z["w_std"])), cfg
     sw = synth.make_sdnet_weights(opt, seed=int(z["seed"]))
     net = SDNet(opt, {"glove_embedding": T(sw["glove_embed.weight"]), "fast_embedding": T(sw["fast_embed.weight"])})

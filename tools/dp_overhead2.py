@@ -151,5 +151,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N * 1e3
 print("%-9s %.2f ms per step; host time per step: _launch %.2f ms (all buckets), average_gradients %.2f ms (incl. late launches)"
       % (mode, dt, acc["launch"] / N * 1e3, acc["avg"] / N * 1e3), "events/step", acc.get("events", 0) / N, "buckets", len(gs.buckets))
-tr.close()
+tr.close(final=True)
 dist.destroy_process_group()

@@ -25,4 +25,4 @@ for _ in range(N):
     bert_encode(W, packed, bf)
 torch.cuda.synchronize()
 print("encoder pass alone (T=%d rows=%d): %.3f ms" % (packed.T, packed.Tp, (time.perf_counter() - t0) / N * 1e3))
-tr.close()
+tr.close(final=True)

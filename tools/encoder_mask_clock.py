@@ -55,4 +55,4 @@ for cus in [int(c) for c in a.cus.split(",")]:
           flush=True)
     if cus < 256:
         hip.destroy_stream(st)          # a CU-masked queue alive at exit takes rocprofv3's teardown down (hip.destroy_stream)
-tr.close()
+tr.close(final=True)

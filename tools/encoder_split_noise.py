@@ -93,4 +93,4 @@ for wgs in (16, 64, 200, 800, 3200, 6400):
 hip.destroy_stream(st)
 stop.set()
 th.join()
-tr.close()
+tr.close(final=True)

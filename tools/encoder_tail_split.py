@@ -46,4 +46,4 @@ for sname, st in streams.items():
             per[i % 4] += (et[i] - bt[i]) * 1e3
         k = max(1, cnt.value // 4)
         print("%-9s plan %3d CUs: pass %6.2f ms | per launch: QKV %5.0f  AO %5.0f  FF1 %5.0f  FF2 %5.0f us" % (sname, cus, dt, per[0] / k, per[1] / k, per[2] / k, per[3] / k), flush=True)
-tr.close()
+tr.close(final=True)

@@ -9,7 +9,7 @@ from ruart_amd import hip
 lib = hip.load(); d = torch.device("cuda:0")
 lib.ruart_gemm_set_stamps.argtypes = [ctypes.c_void_p]; lib.ruart_gemm_set_stamps.restype = ctypes.c_int
 dt = hip.DT_F16; td = torch.float16
-M = 43008
+M = int(os.environ.get("ROWS", 43008))
 for name, N, K, act, res in [("qkv", 2304, 768, 0, False), ("ao", 768, 768, 0, True), ("ff1", 3072, 768, 1, False), ("ff2", 768, 3072, 0, True)]:
     g = torch.Generator().manual_seed(0)
     A = torch.randn(M, K, generator=g).to(td).to(d); W = (torch.randn(N, K, generator=g) * 0.05).to(td).to(d)

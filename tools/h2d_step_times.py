@@ -54,4 +54,4 @@ for h2d in (False, True, False, True):
         pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(14)
     print("h2d=%s  %.2f ms per step: staging the lookahead batch %.2f ms, update() %.2f ms" %
           (h2d, (time.perf_counter() - t0) / 20 * 1e3, acc[0] / 20 * 1e3, acc[1] / 20 * 1e3))
-tr.close()
+tr.close(final=True)

@@ -35,4 +35,4 @@ for which in ("forward", "backward"):
     print("==== profile over %d steps (%s shown; divide by %d) ====" % (N, "all", N))
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
     break
-tr.close()
+tr.close(final=True)

@@ -70,4 +70,4 @@ for name, f in cases.items():
     for busy in (False, True):
         print("%-45s encoder beside it: %-5s %.1f us" % (name, busy, timeit(f, 60, busy)))
 hip.destroy_stream(enc)
-tr.close()
+tr.close(final=True)

@@ -48,4 +48,4 @@ for i in range(N):
 print("phase          host enqueue   until device done   (ms, mean of %d steps, phases separated by device syncs)" % N)
 for k, (h, d) in acc.items():
     print("%-12s %10.2f %16.2f" % (k, h / N * 1e3, d / N * 1e3))
-tr.close()
+tr.close(final=True)

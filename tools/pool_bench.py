@@ -42,4 +42,4 @@ for g in range(3):
     print("group %d: %5d words %6d pieces | forward %6.1f us = %.2f TB/s | backward (incl. zero-fill + partial sums) %6.1f us" % (g, W, pieces, tf[6], nb / tf[6] / 1e6, tb[6]))
     tot_f += tf[6]; tot_b += tb[6]; bytes_f += nb
 print("all groups: forward %.1f us = %.2f TB/s, backward %.1f us" % (tot_f, bytes_f / tot_f / 1e6, tot_b))
-tr.close()
+tr.close(final=True)

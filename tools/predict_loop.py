@@ -27,4 +27,4 @@ if "--trace" in sys.argv:
         tr.predict(batches[i % 2], next_batch=batches[(i + 1) % 2])
     torch.cuda.synchronize()
     pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(12)
-tr.close()
+tr.close(final=True)

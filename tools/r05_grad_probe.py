@@ -31,4 +31,4 @@ for k in range(3):
     print("run %d: scores equal %s; grads differing %d of %d, worst %.3e (%s)" % (k, torch.equal(s3, s1), nz, len(g1), worst[0], worst[1]), flush=True)
 s1b, g1b = run(False)
 print("one-stream repeat: grads differing", sum(1 for n in g1 if not torch.equal(g1b[n], g1[n])))
-tr.close()
+tr.close(final=True)

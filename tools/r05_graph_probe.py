@@ -193,4 +193,4 @@ with torch.cuda.stream(s2):
     print("eager on a torch pool stream : device %7.3f ms   host %7.3f ms" % (de2, he2), flush=True)
 torch.cuda.synchronize()
 print("max |raw - eager| = %.3g, max |torch graph - eager| = %.3g" % (float((out_raw - out_eager).abs().max()), float((out_torch - out_eager).abs().max())))
-tr.close()
+tr.close(final=True)

@@ -96,4 +96,4 @@ variant("1. eval forward, no autograd", False, False, False)
 variant("2. train-mode forward, no autograd", True, False, False)
 variant("3. train-mode forward under autograd", True, True, False)
 variant("4. train-mode forward + backward", True, True, True)
-tr.close()
+tr.close(final=True)

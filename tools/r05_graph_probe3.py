@@ -78,4 +78,4 @@ with torch.cuda.stream(s):
         out.backward(torch.ones_like(out))
         torch.cuda.synchronize()
     print(p.key_averages().table(sort_by="cuda_time_total", row_limit=25))
-tr.close()
+tr.close(final=True)

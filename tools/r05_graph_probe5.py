@@ -92,4 +92,4 @@ with torch.cuda.stream(s):
         print("%-46s eager fwd+bwd %7.3f ms | graphs %7.3f ms" % (name, measure(trunk, before), measure(graphed, before)), flush=True)
 torch.cuda.synchronize()
 hip.destroy_stream(masked)
-tr.close()
+tr.close(final=True)

@@ -48,4 +48,4 @@ if not os.environ.get("SHORT"):
     phase("alternating", [A[0], B[0], A[1], B[1]])
     phase("first batch only again", A)
     phase("second batch only again", B)
-tr.close()
+tr.close(final=True)

@@ -67,4 +67,4 @@ for k in range(int(os.environ.get("N", 8))):
     three = fwd(True)
     one2 = fwd(False)
     print("run %d: |three - one| = %.3e   |one - one| = %.3e" % (k, float((three - one).abs().max()), float((one2 - one).abs().max())), flush=True)
-tr.close()
+tr.close(final=True)

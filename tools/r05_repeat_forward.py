@@ -37,4 +37,4 @@ for k in range(int(os.environ.get("N", 12))):
         ref = fwd()
     s = fwd()
     print("run %2d: max |s - ref| = %.3e" % (k, float((s - ref).abs().max())), flush=True)
-tr.close()
+tr.close(final=True)

@@ -37,4 +37,4 @@ for k in range(int(os.environ.get("SESSIONS", 3))):
         tr.predict(A[0])
         tr.close()
     session("session %d (after close())" % (k + 2))
-tr.close()
+tr.close(final=True)

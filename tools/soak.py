@@ -37,7 +37,7 @@ for i in range(steps):
         torch.cuda.synchronize()
         mem.append(torch.cuda.memory_allocated() / 2**30)
         print("step %4d loss %.4f avg %.4f  mem %.2f GiB reserved %.2f GiB  %.1f s" % (i, float(losses[-1]), np.mean([float(v) for v in losses[-20:]]), mem[-1], torch.cuda.memory_reserved() / 2**30, time.time() - t0), flush=True)
-tr.close()          # the CU-masked run-ahead stream must not outlive the process teardown
+tr.close(final=True)          # the CU-masked run-ahead stream must not outlive the process teardown
 losses = [float(v) for v in losses]
 assert all(np.isfinite(losses))
 assert np.mean(losses[-20:]) < np.mean(losses[:20]), (np.mean(losses[:20]), np.mean(losses[-20:]))

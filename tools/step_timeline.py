@@ -100,4 +100,4 @@ for k in range(2, len(starts) - 1):
 print("GFLOP per launch: mean us while the trunk runs / after it (counts)")
 for fl, (a, c) in sorted(by.items()):
     print("  %6d: %6.0f / %6.0f   (%d / %d)" % (fl, np.mean(a) if a else 0, np.mean(c) if c else 0, len(a), len(c)))
-tr.close()
+tr.close(final=True)

@@ -40,4 +40,4 @@ for name, b in (("pageable", hb), ("pinned", pin(hb))):
         ts.append(((t1 - t) * 1e3, (time.perf_counter() - t) * 1e3))
     n = sum(1 for _ in bench.__dict__) and 0
     print("%-9s ToCUDA host %.2f ms, until copies are done %.2f ms" % (name, min(a for a, _ in ts), min(b_ for _, b_ in ts)))
-tr.close()
+tr.close(final=True)

@@ -32,4 +32,4 @@ if "--trace" in sys.argv:
     pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 print("host time per update():", " ".join("%.1f" % h for h in hs))
 print("8 steps: host done after %.1f ms, device after %.1f ms (%.2f ms per step)" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3, (t2 - t0) * 1e3 / 8))
-tr.close()
+tr.close(final=True)
