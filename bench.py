@@ -555,7 +555,7 @@ def main():
     def caller_stream():
         """The loop that drives update() runs where SDNetTrainer.train() runs its own: with the training step stream current
         (trainer.step_stream; from torch's default stream every step is joined with the LEGACY stream on both sides, and those markers
-        hold the next step's trunk back until the encoder pass beside it has ended: 22.75 -> 22.00 ms).
+        hold the next step's trunk back until the encoder pass beside it has ended: 22.75 -> 22.00 ms, profiles/HISTORY.md round 5 (12)).
         RUART_BENCH_CALLER_DEFAULT_STREAM=1: the caller on torch's default stream, as in rounds 1-4."""
         if a.mode != "train" or os.environ.get("RUART_BENCH_CALLER_DEFAULT_STREAM") == "1":
             return contextlib.nullcontext()

@@ -599,7 +599,7 @@ class Bert(nn.Module):
         # against 23.5), and the better one on a 10 % smaller batch too (21.4 against 22.3 at that batch's own plan, 232).  'auto' plans
         # ONCE, from the first training batch, and keeps that stream: a second CU-masked stream in the same process lands on a hardware
         # queue pipe one of the step's four streams already uses and the two run one after the other (27-29 ms steps,
-        # tools/r05_mask_switch.py).
+        # tools/r05_mask_switch.py, profiles/HISTORY.md round 5 (9)).
         self._opt_prefetch_cus = opt.get("bert_prefetch_cus", 224 if precision == "fp16c" else 0)
         self._init_pipeline()
         # Tail split of the encoder GEMMs (csrc/gemm_corr.hip, gemm.hip; opt['bert_tail_cus'] = the CU count the split is planned for, one
@@ -744,7 +744,7 @@ class Bert(nn.Module):
         process with an HSA tool library loaded (rocprofv3 ...) down in __cxa_finalize.  Otherwise (None) the stream is KEPT for the
         next session: a new masked stream lands on another hardware queue slot, and with an evaluation's streams created in between
         it shared a slot with one of the trunk's streams - every later training step took 27.3 ms instead of 22.1
-        (tools/r05_two_sessions.py)."""
+        (tools/r05_two_sessions.py, profiles/HISTORY.md round 5 (9))."""
         if destroy is None:
             destroy = os.environ.get("RUART_DESTROY_STREAMS") == "1"        # (experiments; the product decides through SDNetTrainer.close(final=))
         if self._pending is not None:

@@ -112,7 +112,7 @@ struct Stager {
   // split-K sum test m < M, n < N), and they are copies of real rows, so they are finite.  Only k >= K has to contribute zeros, and
   // that happens in the last K step alone: KFULL (the step lies inside K: no clamp of k, no validity bits, no select in store()) is
   // what every other step runs - the per-element bounds select was 110 of the 233 VALU instructions of a K step (round 4 counters:
-  // these kernels are bound by their issue slots).
+  // these kernels are bound by their issue slots, profiles/HISTORY.md round 5 (9)).
   template <bool KFULL>
   __device__ __forceinline__ void load(const float* __restrict__ P, long srow, long sk, int r0, int rows, int k0, int K, int tid,
                                        const unsigned char* __restrict__ S, int rpm, const int (&mo)[4]) {

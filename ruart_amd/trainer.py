@@ -324,7 +324,7 @@ class SDNetTrainer(BaseTrainer):
 
     def _step_stream(self):
         """The step stream of the network's CURRENT mode (created on first use; one per priority: the process keeps the streams it
-        starts with); None on the CPU and with a trainable encoder (nothing runs ahead there)."""
+        starts with, profiles/HISTORY.md round 5 (6b) / (9)); None on the CPU and with a trainable encoder (nothing runs ahead there)."""
         dev = self.device
         unlocked = getattr(getattr(self.network, "Bert", None), "bert_model", None) is not None
         if dev.type != "cuda" or unlocked:
@@ -352,7 +352,7 @@ class SDNetTrainer(BaseTrainer):
         stream: each of those two markers waits for - and holds back - the CU-masked encoder stream (a blocking stream), so the
         next step's trunk cannot start before the encoder pass that runs beside it has ended.  With the caller on the step stream
         the first kernels of step t+1 (embeddings, the question branch) run under the tail of that pass: 22.75 -> 22.00 ms per step
-        (interleaved, three rounds).  Everything the loop enqueues - ``ToCUDA`` copies included - is then
+        (interleaved, three rounds; profiles/HISTORY.md round 5 (12)).  Everything the loop enqueues - ``ToCUDA`` copies included - is then
         ordered on that one stream; results handed to another stream need the usual ``wait_stream``."""
         import contextlib
         self.network.train()
@@ -507,7 +507,7 @@ class SDNetTrainer(BaseTrainer):
             elif self.device.type == "cuda" and self.opt.get("ruart_empty_cache_after_eval", True):
                 # an evaluation inside train(): its no-grad forwards leave the caching allocator with a block layout the training steps
                 # would go on reusing - measured 0.7-1.0 ms per training step under the schedule of the time (bench.py's parity check,
-                # DESIGN.md section 5 (11); under the final schedule of (12) the effect was no longer measurable); handing the cached
+                # profiles/HISTORY.md round 5 (11); under the final schedule of (12) the effect was no longer measurable); handing the cached
                 # blocks back costs a few re-allocations in the next step
                 torch.cuda.synchronize(self.device)
                 torch.cuda.empty_cache()

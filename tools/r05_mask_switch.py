@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does a CU-masked encoder stream created MID-RUN overlap with the trunk like the one created at the first step?  (A trunk stream created
-after the masked stream does not: DESIGN.md section 5 (6b).)  Two batches whose row counts plan different masks; phases: A only, B only
+after the masked stream does not: profiles/HISTORY.md round 5 (6b).)  Two batches whose row counts plan different masks; phases: A only, B only
 (its stream is created here, mid-run), alternating A / B, A only again.  Prints the median step time of every phase."""
 import os, sys, time, statistics
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two training sessions in one process with SDNetTrainer.close() between them (what two train() calls, or train() -> predict_for_test()
 -> train(), do): close() destroys the CU-masked encoder stream, the second session creates a new one - does it still overlap with the
-trunk's streams?  (A stream's hardware queue slot follows its creation order: DESIGN.md section 5 (9).)  Median step time per session."""
+trunk's streams?  (A stream's hardware queue slot follows its creation order: profiles/HISTORY.md round 5 (9).)  Median step time per session."""
 import os, sys, time, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
