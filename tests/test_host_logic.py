@@ -577,3 +577,111 @@ def test_readback_is_deferred_inside_the_training_loop_only():
     assert Fake({"ruart_defer_readback": True}, "cuda")._defer_readback() is True
     assert Fake({"ruart_defer_readback": True}, "cpu", in_loop=True)._defer_readback() is False
     assert isinstance(Fake({}, "cpu").step_stream(), contextlib.nullcontext)
+
+
+def test_close_final_decides_the_masked_streams_destruction(monkeypatch):
+    """Round 6: SDNetTrainer.close(final=True) destroys the CU-masked run-ahead stream, close() keeps it for the next session - the
+    caller decides, no environment variable is inspected for a profiler's name (RUART_DESTROY_STREAMS=1 stays as an experiment knob).
+    Bare objects, no device needed."""
+    from ruart_amd.bert import Bert
+    from ruart_amd.trainer import SDNetTrainer
+    seen = []
+
+    class FakeBert:
+        def close(self, destroy=None):
+            seen.append(destroy)
+
+    class Fake:
+        close = SDNetTrainer.close
+        flush_readback = lambda self: None
+
+        def __init__(self):
+            self.network = type("N", (), {"Bert": FakeBert()})()
+
+    Fake().close()
+    Fake().close(final=True)
+    assert seen == [None, True]
+    # Bert.close(None) keeps the streams whatever tool library the environment names
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    monkeypatch.delenv("RUART_DESTROY_STREAMS", raising=False)
+    kept = []
+
+    class FakeStream:
+        def synchronize(self):
+            kept.append("sync")
+
+    b = type("B", (), {"close": Bert.close})()
+    b._pending, b._pf_streams = None, {224: FakeStream()}
+    b.close()
+    assert kept == ["sync"] and 224 in b._pf_streams
+
+
+def test_train_hands_the_frozen_generation_back():
+    """Round 6 (advisor): train() freezes the collector's permanent generation after its set-up and unfreezes it on every exit path."""
+    import gc
+    from ruart_amd.trainer import SDNetTrainer
+
+    class Fake:
+        train = SDNetTrainer.train
+        closed = 0
+
+        def __init__(self, fail):
+            self.fail = fail
+
+        def _train(self, *a):
+            gc.freeze()
+            self._gc_frozen = True
+            if self.fail:
+                raise RuntimeError("loader died")
+
+        def close(self, final=False):
+            self.closed += 1
+
+    gc.unfreeze()
+    for fail in (False, True):
+        t = Fake(fail)
+        try:
+            t.train()
+        except RuntimeError:
+            assert fail
+        assert gc.get_freeze_count() == 0 and t.closed == 1 and not t._in_train
+
+
+def test_mm_row_split_keeps_the_b_side_mask(monkeypatch):
+    """Round 6 (advisor): when an operand spans >= 2^30 elements ops.mm splits the product over its rows; the halves must carry the
+    b-side dropout mask, its scale and rpm.  The recursion is observed on a stub (no device, no 4 GB tensor)."""
+    import torch
+    from ruart_amd import ops
+    calls = []
+    real_mm = ops.mm
+    monkeypatch.setattr(ops, "_span", lambda t: (1 << 30) if t.shape[0] == 8 and t.shape[1] == 4 else 1)
+    monkeypatch.setattr(ops, "_one_unit_stride", lambda t: t)
+
+    def spy(a, b, bias=None, mode=None, out=None, a_keep=None, b_keep=None, keep_scale=1.0, c_scale=None, rpm=1, residual=None):
+        if a.shape[0] == 8:
+            return real_mm(a, b, bias, mode, out, a_keep, b_keep, keep_scale, c_scale, rpm, residual)
+        calls.append((a.shape[0], b_keep is not None, keep_scale, rpm))
+        return out
+
+    monkeypatch.setattr(ops, "mm", spy)
+
+    class T:                       # the few tensor attributes mm() touches before it recurses
+        is_cuda, dtype, device = True, torch.float32, "cuda:0"
+
+        def __init__(self, r, c):
+            self.shape = (r, c)
+
+        def __getitem__(self, s):
+            n = len(range(*s.indices(self.shape[0])))
+            return T(n, self.shape[1])
+
+        def numel(self):
+            return 1 << 31
+
+        def stride(self, i):
+            return (self.shape[1], 1)[i]
+
+    keep = object()
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: T(a[0], a[1]))
+    spy(T(8, 4), T(4, 6), mode="x3", b_keep=keep, keep_scale=2.0, rpm=2)
+    assert calls == [(4, True, 2.0, 2), (4, True, 2.0, 2)]
