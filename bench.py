@@ -185,7 +185,9 @@ def bert512_measure(a, device, lib, precision, batch=64, steps=None, warmup=None
     steps = steps or a.steps
     warmup = a.warmup if warmup is None else warmup
     cfg = synth.bert_config()
-    W = BertEncoderWeights(synth.make_bert_weights(cfg, seed=1033, w_std=0.02), cfg, device, precision)
+    # round 6: the plain 16-bit pass with its LayerNorms folded into the projections (ruart_gemm_16_nt_fold; RUART_LN_FOLD=0: the seven-launch layer)
+    W = BertEncoderWeights(synth.make_bert_weights(cfg, seed=1033, w_std=0.02), cfg, device, precision,
+                           ln_fold=os.environ.get("RUART_LN_FOLD", "1") != "0")
     W.c_model.tail_cus = int(os.environ.get("RUART_TAIL_CUS", 0))       # experiments: tail split of the GEMMs (off: DESIGN.md section 5, round 4)
     if os.environ.get("RUART_TILE_ORDER"):              # experiments: GROUP_M of the encoder GEMM's tile walk
         hip.check(lib.ruart_gemm_set_tile_order(int(os.environ["RUART_TILE_ORDER"])), "set_tile_order")

@@ -287,8 +287,8 @@ typedef struct {
   int tail_cus;   /* CU count the encoder GEMMs plan their TAIL SPLIT for (ruart_gemm_16c_nt_ws / ruart_gemm_16_nt_ws): the CUs of the stream's
                      mask, or of the device; 0 = single-launch products.  The plan depends on (rows, N, K, tail_cus) only, so passes on
                      different streams of one model agree bit for bit.  Enlarges ruart_bert_workspace_bytes by tail_cus x 256 KB. */
-  int ln_fold;    /* corr8 only: != 0 = the weights are prepared for ruart_bert_forward_folded (the only forward such a model may be given
-                     to): for every layer l >= 1, w_qkv[l] / w8_qkv[l] hold W' = Wqkv diag(ln2_g[l-1]) 2^-s and b_qkv[l] holds
+  int ln_fold;    /* corr8, or (round 6) plain F16 / BF16: != 0 = the weights are prepared for ruart_bert_forward_folded (the only forward such a
+                     model may be given to): for every layer l >= 1, w_qkv[l] / w8_qkv[l] hold W' = Wqkv diag(ln2_g[l-1]) 2^-s and b_qkv[l] holds
                      d = b + Wqkv ln2_b[l-1]; for every layer, w_ff1 / w8_ff1 / b_ff1 the same with ln1_g[l] / ln1_b[l] */
   const float* const* fold_c_qkv;   /* [3H] per layer: c_j = sum_i W'_ji (entry 0 unused: layer 0 reads the materialised embedding rows) */
   const float* const* fold_c_ff1;   /* [intermediate] per layer */
@@ -327,7 +327,9 @@ int ruart_bert_forward(const ruart_bert_model* m, const ruart_bert_batch* b, voi
  * CorrFold): five launches per layer, no normalised row is ever written.  m->ln_fold != 0 (weights prepared accordingly), H % 256 == 0.
  * layers_pre: [n_layers][n_rows][hidden] fp32 PRE-LayerNorm rows y; ln_stats: [n_layers][n_rows][2] floats (mu, rstd); the layer output
  * the reference keeps is (y - mu) rstd ln2_g[l] + ln2_b[l] - formed on the fly by ruart_bert_pool_mix_ln.  Last layer compacted as in
- * ruart_bert_forward when b->last_rows is set (its stats rows are compacted the same way). */
+ * ruart_bert_forward when b->last_rows is set (its stats rows are compacted the same way).
+ * Round 6: a plain 16-bit model (corr8 == 0, dtype F16 / BF16, ln_fold != 0) runs the same five-launch layer on ruart_gemm_16_nt_fold:
+ * layers_pre is then 16-bit, b->last_rows is refused (hipErrorNotSupported) - whole-sequence encoding, bench.py --mode bert512. */
 size_t ruart_bert_workspace_bytes_folded(const ruart_bert_model* m, int n_rows);
 int ruart_bert_forward_folded(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_pre, float* ln_stats, void* workspace,
                               size_t workspace_bytes, void* stream);
@@ -340,6 +342,13 @@ int ruart_gemm_16c_nt_fold(const void* A16, const void* A8, int lda, const void*
                            const float* in_part, int in_np, const float* colc, float wscale, const float* residual, int ldr,
                            const float* res_part, int res_np, const float* res_gamma, const float* res_beta, void* C, int ldc, void* C16,
                            void* C8, float* out_part, int M, int N, int K, int stat_len, float eps, void* stream);
+/* The same projections for the plain 16-bit pass (dtype = F16 or BF16; round 6; Models/Bert/modeling.py:164-168 folded into :225-227,
+ * 261, 287-288, 300): kind 0 / 2: C (16-bit) = [gelu] (rstd 2^s (A W'^T - mu c) + d), in_part required; kind 3: y = A W^T + bias + residual
+ * (16-bit rows, normalised on the way in when res_part != NULL), C = y in 16 bits, out_part = the partials of the unrounded y. */
+int ruart_gemm_16_nt_fold(const void* A, int lda, const void* W, int ldw, const float* bias, int kind, const float* in_part, int in_np,
+                          const float* colc, float wscale, const void* residual, int ldr, const float* res_part, int res_np,
+                          const float* res_gamma, const float* res_beta, void* C, int ldc, float* out_part, int M, int N, int K, int stat_len,
+                          float eps, int dtype, void* stream);
 /* (mu, rstd) [rows][2] from such partials */
 int ruart_rows_stats_finish(const float* part, int np, int rows, float inv_h, float eps, float* stats, void* stream);
 /* ruart_bert_pool_mix / _bwd (Models/Bert/Bert.py:149-165 + Models/SDNet.py:573-581) over the pre-LayerNorm rows of the folded pass:

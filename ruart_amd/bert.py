@@ -56,8 +56,10 @@ class BertEncoderWeights:
         become W' = Wqkv diag(ln2_g[l-1]) 2^-s (s >= 0: keeps |W'| inside the fp8 companion's range), their bias d = b + Wqkv ln2_b[l-1],
         the intermediate dense the same with the layer's attention-output LayerNorm; c = row sums of W' (csrc/gemm_corr.hip, CorrFold)."""
         self._check_range = check_range
-        self.ln_fold = bool(ln_fold) and dtype == "fp16c" and cfg["hidden_size"] % 256 == 0 and cfg["intermediate_size"] % 256 == 0 \
-            and cfg["hidden_size"] <= 1024
+        # (round 6: the plain 16-bit modes fold too - ruart_gemm_16_nt_fold; whole-sequence encoding only, the pooling kernels read
+        #  pre-LayerNorm rows in fp32)
+        self.ln_fold = bool(ln_fold) and dtype in ("fp16c", "fp16", "bf16") and cfg["hidden_size"] % 256 == 0 \
+            and cfg["intermediate_size"] % 256 == 0 and cfg["hidden_size"] <= 1024
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self.precision = dtype
@@ -108,11 +110,13 @@ class BertEncoderWeights:
             wf = w * g[None, :]
             amax = float(wf.abs().max())
             sh = 0
-            while amax * 2.0 ** -sh >= 3.4:     # e4m3(f16(w) 2^7) saturates at 3.5 (csrc/common.h)
+            while self.corr8 and amax * 2.0 ** -sh >= 3.4:     # e4m3(f16(w) 2^7) saturates at 3.5 (csrc/common.h); plain 16-bit: no companion, s = 0
                 sh += 1
             wf = wf * float(2.0 ** -sh)
             d = (b.double() + w.double() @ be.double()).float().contiguous()
-            c = wf.double().sum(1).float().contiguous()
+            # c = row sums of the W' the matrix cores multiply: the 16-bit rounding of W' in the plain modes (mu c then cancels the mean's
+            # share of the product exactly), W' itself in fp16c (its f16 + e4m3 representation carries ~16 bits)
+            c = (wf if self.corr8 else gemm_w(wf)).double().sum(1).float().contiguous()
             return wf, d, c, float(2.0 ** sh)
 
         prev_g = prev_b = None
@@ -588,6 +592,9 @@ class Bert(nn.Module):
         fold = bool(int(opt.get("bert_ln_fold", os.environ.get("RUART_LN_FOLD", 1))))
         if int(opt.get("bert_tail_cus", os.environ.get("RUART_TAIL_CUS", 0)) or 0) > 0:
             fold = False                     # the tail split exists in the unfolded pass only (ruart_bert_forward_folded refuses it)
+        if precision != "fp16c":
+            fold = False                     # the sub-word pooling kernels read pre-LayerNorm rows in fp32 only: the plain 16-bit folded pass
+                                             # (round 6) serves whole-sequence encoding (bert_encode, bench.py --mode bert512), not this class
         self.weights = BertEncoderWeights(state, cfg, self._device, precision, ln_fold=fold)
         self.bert_model = None               # trainable fp32 encoder (bert_train.BertModelTrainable) once ``unlock`` is called
         self._source = (state, cfg)          # kept until SDNet has decided between the frozen and the trainable path

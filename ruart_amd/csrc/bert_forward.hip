@@ -163,7 +163,71 @@ static size_t fold_extra_bytes(size_t R, size_t H, int n_layers) {
   return align_up(R * 32, 256) * ((size_t)n_layers + 2);      // partA, the gathered partials of the last layer's residual, partB per layer
 }
 extern "C" size_t ruart_bert_workspace_bytes_folded(const ruart_bert_model* m, int n_rows) {
+  if (!m->corr8)        // the plain 16-bit folded pass (bert_forward_folded16): the unfolded pass's carving + the row partials
+    return ruart_bert_workspace_bytes(m, n_rows) + fold_extra_bytes((size_t)n_rows, (size_t)m->hidden, m->n_layers);
   return corr_workspace_bytes((size_t)n_rows, (size_t)m->hidden, (size_t)m->intermediate) + fold_extra_bytes((size_t)n_rows, (size_t)m->hidden, m->n_layers);
+}
+
+// ---- the plain 16-bit encoder (f16 / bf16 storage) with its LayerNorms folded the same way (round 6; gemm.hip, ruart_gemm_16_nt_fold) ---
+// layers_pre[l] = y2 of layer l, PRE-LayerNorm, in the model's 16-bit type; ln_stats[l][row] = (mu, rstd) taken from the unrounded fp32 y2.
+// Five launches per layer instead of seven: the two rows_layernorm passes (fp32 in, 16-bit out: 6 bytes per element each) are gone, the
+// attention-output / output dense write 2 bytes per element instead of 4.  Layer 0 reads the materialised embedding rows.  The last
+// layer is not compacted to the pooled rows (ruart_bert_batch.last_rows is refused: the sub-word pooling kernels read pre-LayerNorm rows
+// in fp32 only, so the training step keeps the unfolded 16-bit pass; this one serves whole-sequence encoding, bench.py --mode bert512).
+static int bert_forward_folded16(const ruart_bert_model* m, const ruart_bert_batch* b, void* layers_pre, float* ln_stats, void* workspace,
+                                 void* stream) {
+  const int H = m->hidden, I = m->intermediate, R = b->n_rows, NL = m->n_layers, dt = m->dtype;
+  if (dt != RUART_DT_F16 && dt != RUART_DT_BF16) return (int)hipErrorInvalidValue;
+  if (R <= 0 || R % 256 || H % 256 || I % 256 || H > 1024 || b->n_tokens > R || b->n_tokens <= 0 || m->n_heads * 64 != H) return (int)hipErrorInvalidValue;
+  if (last_layer_rows(m, b) > 0 || m->tail_cus > 0) return (int)hipErrorNotSupported;
+  const int np = H / 256;
+  const size_t es = 2;
+  Carve c{(char*)workspace, 0};
+  void* x0 = c.take((size_t)R * H * es);
+  void* qkv = c.take((size_t)R * 3 * H * es);
+  void* ctx = c.take((size_t)R * H * es);
+  c.take((size_t)R * H * 4);                           // (the unfolded pass's fp32 pre-LayerNorm rows: the two forms share one carving)
+  void* mid = c.take((size_t)R * H * es);              // y1, pre-LayerNorm
+  void* ffn = c.take((size_t)R * I * es);
+  float* partA = (float*)c.take((size_t)R * 32);
+  c.take((size_t)R * 32);
+  float* partB = (float*)c.take(0);                    // [n_layers][R][4][2]
+  const size_t partB_stride = (size_t)R * 8;
+  const float eps = m->ln_eps;
+  int rc = ruart_bert_embed_ln(b->ids, b->pos_ids, m->word_emb, m->pos_emb, m->type_emb, m->emb_ln_g, m->emb_ln_b, eps, x0, H, dt, R, H, stream);
+  if (rc) return rc;
+  ruart_prof_real_rows = b->n_tokens;
+  const void* in = x0;                    // the layer's input rows: materialised (layer 0) or y2 of the layer before
+  const float* in_part = nullptr;
+  for (int l = 0; l < NL; ++l) {
+    void* out = (char*)layers_pre + (size_t)l * R * H * es;
+    float* pB = partB + (size_t)l * partB_stride;
+    if (l == 0)
+      rc = ruart_gemm_16_nt(in, H, m->w_qkv[l], H, m->b_qkv[l], nullptr, 0, dt, qkv, 3 * H, dt, R, 3 * H, H, RUART_ACT_NONE, dt, stream);
+    else
+      rc = ruart_gemm_16_nt_fold(in, H, m->w_qkv[l], H, m->b_qkv[l], 0, in_part, np, m->fold_c_qkv[l], m->fold_s_qkv[l], nullptr, 0, nullptr, 0,
+                                 nullptr, nullptr, qkv, 3 * H, nullptr, R, 3 * H, H, H, eps, dt, stream);
+    if (rc) return rc;
+    if ((rc = ruart_bert_attention(qkv, 3 * H, ctx, H, dt, H, m->n_heads, b->n_blocks, b->blk_q0, b->blk_q1, b->blk_k0, b->blk_k1, b->tok_lo,
+                                   b->tok_hi, b->key_bias, b->n_long_blocks, b->lblk_q0, b->lblk_q1, b->lblk_k0, b->lblk_k1, stream)))
+      return rc;
+    // y1 = ctx Wo^T + b + (layer 0: the embedding rows; else LN2_{l-1}(y2_{l-1})) -> mid, partA
+    if ((rc = ruart_gemm_16_nt_fold(ctx, H, m->w_ao[l], H, m->b_ao[l], 3, nullptr, 0, nullptr, 1.f, in, H, in_part, np, l ? m->ln2_g[l - 1] : nullptr,
+                                    l ? m->ln2_b[l - 1] : nullptr, mid, H, partA, R, H, H, H, eps, dt, stream)))
+      return rc;
+    // gelu(LN1_l(y1) W1^T + b1) -> ffn
+    if ((rc = ruart_gemm_16_nt_fold(mid, H, m->w_ff1[l], H, m->b_ff1[l], 2, partA, np, m->fold_c_ff1[l], m->fold_s_ff1[l], nullptr, 0, nullptr, 0,
+                                    nullptr, nullptr, ffn, I, nullptr, R, I, H, H, eps, dt, stream)))
+      return rc;
+    // y2 = ffn W2^T + b2 + LN1_l(y1) -> layers_pre[l], partB[l]
+    if ((rc = ruart_gemm_16_nt_fold(ffn, I, m->w_ff2[l], I, m->b_ff2[l], 3, nullptr, 0, nullptr, 1.f, mid, H, partA, np, m->ln1_g[l], m->ln1_b[l],
+                                    out, H, pB, R, H, I, H, eps, dt, stream)))
+      return rc;
+    in = out;
+    in_part = pB;
+  }
+  ruart_prof_real_rows = 0;
+  return ruart_rows_stats_finish(partB, np, NL * R, 1.0f / (float)H, eps, ln_stats, stream);
 }
 
 
@@ -171,8 +235,12 @@ extern "C" int ruart_bert_forward_folded(const ruart_bert_model* m, const ruart_
                                          size_t workspace_bytes, void* stream) {
   RUART_ENTRY();
   const int H = m->hidden, I = m->intermediate, R = b->n_rows, NL = m->n_layers;
-  if (!m->corr8 || !m->ln_fold || m->dtype != RUART_DT_F16 || !m->fold_c_qkv || !m->fold_c_ff1 || !m->fold_s_qkv || !m->fold_s_ff1)
-    return (int)hipErrorInvalidValue;
+  if (!m->ln_fold || !m->fold_c_qkv || !m->fold_c_ff1 || !m->fold_s_qkv || !m->fold_s_ff1 || !layers_pre || !ln_stats) return (int)hipErrorInvalidValue;
+  if (!m->corr8) {
+    if (workspace_bytes < ruart_bert_workspace_bytes_folded(m, R)) return (int)hipErrorInvalidValue;
+    return bert_forward_folded16(m, b, layers_pre, ln_stats, workspace, stream);
+  }
+  if (m->dtype != RUART_DT_F16) return (int)hipErrorInvalidValue;
   if (R <= 0 || R % 256 || H % 256 || I % 256 || b->n_long_blocks != 0 || b->n_blocks <= 0 || b->n_tokens > R || b->n_tokens <= 0 ||
       m->n_heads * 64 != H || !layers_pre || !ln_stats)
     return (int)hipErrorInvalidValue;

@@ -280,10 +280,15 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256sq(const T16* __restrict
 
 // Epilogue of one 256 x 256 tile of gemm_16_nt_256p8 through LDS, eight rows per pass; shared with the fix-up kernel of its split tail
 // tiles (gemm_16_fixup).  `smem`: >= 8 x 32 x 272 bytes no wave reads as operand tiles any more.
-template <typename T16, bool OUT_F32, int RES, int ACT>
+// FK (round 6: the LayerNorms of the plain 16-bit pass folded into the projections, as the fp16c pass has had them since round 5 -
+// CorrFold, gemm_shared.h): 0 none; 1 the A rows are pre-LayerNorm rows, v = rstd 2^s (acc - mu c) + d before the activation (`bias` = d);
+// 3 (RES = 1) y = acc + bias + residual with the residual rows normalised on the way in when f.rs_part is given, written as T16, and
+// the row's (sum, sumsq) of the fp32 y per 256-column tile -> f.out_part.
+template <typename T16, bool OUT_F32, int RES, int ACT, int FK = 0>
 __device__ __forceinline__ void p8_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, int tm, const float* __restrict__ bias,
                                             const void* __restrict__ R, int ldr, void* __restrict__ C, int ldc, int N,
-                                            void* __restrict__ C2, float* __restrict__ colpart, int hh0 = 0, int hh1 = 4) {
+                                            void* __restrict__ C2, float* __restrict__ colpart, int hh0 = 0, int hh1 = 4,
+                                            const CorrFold& f = CorrFold{}) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
@@ -294,6 +299,24 @@ __device__ __forceinline__ void p8_epilogue(f32x4_t (&acc)[4][8], char* smem, in
   const int ncol = n0 + wn * 64 + rcol;
   if (bias) bv = *reinterpret_cast<const f32x4_t*>(bias + ncol);
   f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t cv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, ev = {0.f, 0.f, 0.f, 0.f};
+  bool res_ln = false;
+  float wsc = 1.f;
+  if constexpr (FK == 1) {
+    fold_row_stats(smem, f.in_part, f.in_np, m0, f.inv_h, f.eps);
+    cv = *reinterpret_cast<const f32x4_t*>(f.colc + ncol);
+    wsc = f.wscale;
+  }
+  if constexpr (FK == 3) {
+    res_ln = f.rs_part != nullptr;
+    if (res_ln) {
+      fold_row_stats(smem, f.rs_part, f.rs_np, m0, f.inv_h, f.eps);
+      gv = *reinterpret_cast<const f32x4_t*>(f.rs_g + ncol);
+      ev = *reinterpret_cast<const f32x4_t*>(f.rs_b + ncol);
+    }
+  }
+  const float2* rstat = reinterpret_cast<const float2*>(smem + kFoldStatsOff) + wm * 128 + rrow;
+  float2* rpart = reinterpret_cast<float2*>(smem + kFoldPartOff) + wn * 256 + wm * 128 + rrow;
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) {
     if (hh < hh0 || hh >= hh1) continue;           // (the fix-up kernel runs one 32-row pass per workgroup)
@@ -313,8 +336,35 @@ __device__ __forceinline__ void p8_epilogue(f32x4_t (&acc)[4][8], char* smem, in
         if (RES == 2) res[rr] = load4(reinterpret_cast<const float*>(R) + (size_t)(mrow + rr * 4) * ldr + ncol);
       }
     }
+    if constexpr (FK == 1) {
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+      for (int rr = 0; rr < 8; ++rr) {
+        const float2 st = rstat[hh * 32 + rr * 4];
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4);
+        const float sc = st.y * wsc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rr][r] = fmaf(sc, fmaf(-st.x, cv[r], a[r]), bv[r]);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = *reinterpret_cast<const f32x4_t*>(my + (rr * 4 + rrow) * ERS + rcol * 4) + bv;
+    }
+    if constexpr (FK == 3) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        if (res_ln) {
+          const float2 st = rstat[hh * 32 + rr * 4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[rr][r] = fmaf(gv[r], (res[rr][r] - st.x) * st.y, ev[r]);
+        }
+        v[rr] += res[rr];
+        store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+        const float s1 = row16_sum((v[rr][0] + v[rr][1]) + (v[rr][2] + v[rr][3]));
+        const float s2 = row16_sum(fmaf(v[rr][0], v[rr][0], v[rr][1] * v[rr][1]) + fmaf(v[rr][2], v[rr][2], v[rr][3] * v[rr][3]));
+        if ((lane & 15) == 0) rpart[hh * 32 + rr * 4] = make_float2(s1, s2);
+      }
+      continue;
+    }
     if (ACT == 3) {
       // backward through the GELU (R = the f16 pre-activation H): C = acc * gelu'(H) - the gradient at the intermediate dense output -,
       // C2 = gelu(H) again (the X operand of the next weight gradient), colsum += this pass's rows of C before their rounding
@@ -346,6 +396,15 @@ __device__ __forceinline__ void p8_epilogue(f32x4_t (&acc)[4][8], char* smem, in
         store4(reinterpret_cast<float*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
       else
         store4(reinterpret_cast<T16*>(C) + (size_t)(mrow + rr * 4) * ldc + ncol, v[rr]);
+    }
+  }
+  if constexpr (FK == 3) {
+    // the four column groups of a row in a fixed order -> this tile's partial of the row (as gemm_corr.hip's kind 3)
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const float2* pp = reinterpret_cast<const float2*>(smem + kFoldPartOff) + threadIdx.x;
+      const float2 a = pp[0], b = pp[256], c = pp[512], d = pp[768];
+      reinterpret_cast<float2*>(f.out_part)[(size_t)(m0 + threadIdx.x) * kFoldSlots + n0 / 256] = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
     }
   }
   if (ACT == 3 && colpart) {
@@ -394,12 +453,12 @@ __device__ __forceinline__ void p8_tile_of(int id, int ntm, int ntn, int order, 
 //    prefetch issue, so each SIMD's matrix pipe alternates between its two resident waves instead of idling while both read.
 // Needs K % 128 == 0 (even number of K-tiles), M % 256 == 0, N % 256 == 0.
 // ------------------------------------------------------------------------------------------------
-template <typename T16, bool OUT_F32, int RES, int ACT>
+template <typename T16, bool OUT_F32, int RES, int ACT, int FK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict__ A, int lda, const T16* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, const void* __restrict__ R, int ldr,
                                                            void* __restrict__ C, int ldc, int M, int N, int K, int order, int kchunk,
                                                            void* __restrict__ C2, float* __restrict__ colpart, int n_full, int S,
-                                                           float* __restrict__ slabs
+                                                           float* __restrict__ slabs, const CorrFold fold
 #ifdef RUART_P8_STAMPS
                                                            , unsigned long long* __restrict__ stamps
 #endif
@@ -694,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_16_nt_256p8(const T16* __restrict
       for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4_t*>(slab + ((i * 8 + j) * 512 + tid) * 4) = acc[i][j];
     return;
   }
-  p8_epilogue<T16, OUT_F32, RES, ACT>(acc, smem, m0, n0, tm, bias, R, ldr, C, ldc, N, C2, colpart);
+  p8_epilogue<T16, OUT_F32, RES, ACT, FK>(acc, smem, m0, n0, tm, bias, R, ldr, C, ldc, N, C2, colpart, 0, 4, fold);
 #ifdef RUART_P8_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1182,7 +1241,7 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
     (void)done;
 #ifdef RUART_P8_STAMPS
     hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       g_tile_order, 0, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, g_p8_stamps);
+                       g_tile_order, 0, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{}, g_p8_stamps);
 #else
     // GROUP_M from the tile counts (ruart_tile_group_m, gemm_shared.h) until ruart_gemm_set_tile_order pins a value
     const int order = g_tile_order_auto ? ruart_tile_group_m(M / BM4, N / BN4, K, false) : g_tile_order;
@@ -1194,7 +1253,7 @@ static void launch_one(const T16* a, int lda, const T16* w, int ldw, const float
       if ((size_t)tp.r * tp.S * BM4 * BN4 * sizeof(float) > g_tail_ws_bytes) tp = P8TailPlan{tiles, 0, 0};
     }
     hipLaunchKernelGGL(kern, dim3(tp.n_full + tp.r * tp.S), dim3(512), lds, s, a, lda, w, ldw, bias, residual, ldr, C, ldc, M, N, K,
-                       order, 0, (void*)nullptr, (float*)nullptr, tp.n_full, tp.S, (float*)tail_ws);
+                       order, 0, (void*)nullptr, (float*)nullptr, tp.n_full, tp.S, (float*)tail_ws, CorrFold{});
     if (tp.r > 0) {
       constexpr int flds = 8 * 32 * 272;
       auto fix = gemm_16_fixup<T16, OF, RS, AC>;
@@ -1280,10 +1339,10 @@ static void launch_gelu2(const void* A, int lda, const void* W, int ldw, const f
   (void)done;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{}, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, bias, (const void*)nullptr, 0, G,
-                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr);
+                     ldc, M, N, K, g_tile_order, 0, Hout, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{});
 #endif
 }
 
@@ -1323,10 +1382,10 @@ extern "C" int ruart_gemm_16_nt_gelu_bwd(const void* dY_bf16, int lda, const voi
   void* rec = ruart_prof_begin_((hipStream_t)stream, M, N, K);
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
-                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{}, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4)), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY_bf16, lda, (const bf16_t*)Wt_bf16, ldw,
-                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr);
+                     (const float*)nullptr, H16, ldh, dH_bf16, ldc, M, N, K, g_tile_order, 0, G_bf16, colpart, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{});
 #endif
   ruart_prof_end_(rec, (hipStream_t)stream);
   RUART_CHECK_LAUNCH();
@@ -1345,11 +1404,73 @@ static void launch_splitk(const void* A, int lda, const void* W, int ldw, float*
   const int nz = (K + kchunk - 1) / kchunk;
 #ifdef RUART_P8_STAMPS
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, (unsigned long long*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{}, (unsigned long long*)nullptr);
 #else
   hipLaunchKernelGGL(kern, dim3((M / BM4) * (N / BN4), nz), dim3(512), lds, s, (const T16*)A, lda, (const T16*)W, ldw, (const float*)nullptr,
-                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr);
+                     (const void*)nullptr, 0, (void*)part, ldc, M, N, K, g_tile_order, kchunk, (void*)nullptr, (float*)nullptr, (M / BM4) * (N / BN4), 0, (float*)nullptr, CorrFold{});
 #endif
+}
+
+// The projections of the LayerNorm-folded plain 16-bit encoder pass (round 6; CorrFold, gemm_shared.h; the fp16c pass's counterpart is
+// ruart_gemm_16c_nt_fold).  kind 0: C (16-bit) = rstd 2^s (A W'^T - mu c) + d (`bias` = d); kind 2: the same, then GELU; kind 3: y = A W^T +
+// bias + residual (16-bit rows, normalised with (res_part, res_gamma, res_beta) when res_part != NULL), C = y in 16 bits, out_part[M][4][2]
+// = the (sum, sumsq) of the unrounded y per 256-column tile (N <= 1024).  `in_part` NULL with kind 0 / 2 is refused (use ruart_gemm_16_nt).
+extern "C" int ruart_gemm_16_nt_fold(const void* A, int lda, const void* W, int ldw, const float* bias, int kind, const float* in_part, int in_np,
+                                     const float* colc, float wscale, const void* residual, int ldr, const float* res_part, int res_np,
+                                     const float* res_gamma, const float* res_beta, void* C, int ldc, float* out_part, int M, int N, int K,
+                                     int stat_len, float eps, int dtype, void* stream) {
+  RUART_ENTRY();
+  if (M <= 0 || M % BM4 || N % BN4 || K % (2 * BK) || (lda & 7) || (ldw & 7) || (ldc & 3) || lda < K || ldw < K || ldc < N) return (int)hipErrorInvalidValue;
+  if (!A || !W || !C || stat_len <= 0 || (dtype != RUART_DT_F16 && dtype != RUART_DT_BF16)) return (int)hipErrorInvalidValue;
+  if (kind == 3) {
+    if (!residual || !out_part || N > 256 * kFoldSlots || res_np > kFoldSlots || (res_part && (!res_gamma || !res_beta || res_np <= 0)) || (ldr & 3))
+      return (int)hipErrorInvalidValue;
+  } else if (kind == 0 || kind == 2) {
+    if (!in_part || !colc || in_np <= 0 || in_np > kFoldSlots) return (int)hipErrorInvalidValue;
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  CorrFold f{};
+  f.in_part = in_part; f.colc = colc; f.in_np = in_np; f.wscale = wscale;
+  f.rs_part = res_part; f.rs_g = res_gamma; f.rs_b = res_beta; f.rs_np = res_np;
+  f.out_part = out_part; f.inv_h = 1.0f / (float)stat_len; f.eps = eps;
+  constexpr int lds = 2 * 2 * BM4 * BK * 2;
+  const int order = g_tile_order_auto ? ruart_tile_group_m(M / BM4, N / BN4, K, false) : g_tile_order;
+  const int tiles = (M / BM4) * (N / BN4);
+  void* rec = ruart_prof_begin_(s, M, N, K);
+#ifdef RUART_P8_STAMPS
+#define FOLD_LAUNCH(T, RS, AC, FKV)                                                                                                            \
+  do {                                                                                                                                       \
+    auto kern = gemm_16_nt_256p8<T, false, RS, AC, FKV>;                                                                                     \
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);                      \
+    (void)done;                                                                                                                              \
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, (const T*)A, lda, (const T*)W, ldw, bias, residual, ldr, C, ldc, M, N, K, order, 0, \
+                       (void*)nullptr, (float*)nullptr, tiles, 0, (float*)nullptr, f, g_p8_stamps);                                          \
+  } while (0)
+#else
+#define FOLD_LAUNCH(T, RS, AC, FKV)                                                                                                            \
+  do {                                                                                                                                       \
+    auto kern = gemm_16_nt_256p8<T, false, RS, AC, FKV>;                                                                                     \
+    static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);                      \
+    (void)done;                                                                                                                              \
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, s, (const T*)A, lda, (const T*)W, ldw, bias, residual, ldr, C, ldc, M, N, K, order, 0, \
+                       (void*)nullptr, (float*)nullptr, tiles, 0, (float*)nullptr, f);                                                       \
+  } while (0)
+#endif
+  if (dtype == RUART_DT_F16) {
+    if (kind == 3) FOLD_LAUNCH(f16_t, 1, 0, 3);
+    else if (kind == 2) FOLD_LAUNCH(f16_t, 0, 1, 1);
+    else FOLD_LAUNCH(f16_t, 0, 0, 1);
+  } else {
+    if (kind == 3) FOLD_LAUNCH(bf16_t, 1, 0, 3);
+    else if (kind == 2) FOLD_LAUNCH(bf16_t, 0, 1, 1);
+    else FOLD_LAUNCH(bf16_t, 0, 0, 1);
+  }
+#undef FOLD_LAUNCH
+  ruart_prof_end_(rec, s);
+  RUART_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int ruart_gemm_16_nt_splitk(const void* A, int lda, const void* W, int ldw, float* part, int ldc, int M, int N, int K, int kchunk,

@@ -81,60 +81,7 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
 #define RUART_NT_EPI 0
 #endif
 
-// ---- LayerNorm folded into the projections around it (ruart_bert_forward_folded, bert_forward.hip) --------------------------------
-// The encoder's LayerNorm pass (Models/Bert/modeling.py:164-168) reads a fp32 row and writes it back three times over (fp32 + f16 +
-// two e4m3 bytes): 12 bytes per element of pure traffic between two GEMMs.  In the folded form nobody materialises a normalised row:
-//   * the PRODUCER of the pre-LayerNorm row y (attention-output / output dense, EPI 3) writes y itself - fp32 and in the split operand
-//     form - plus, per row and per 256-column tile, the partial (sum, sum of squares) of the row: part[row][4][2] (slot = tile);
-//   * the CONSUMER projection (QKV / intermediate dense, FOLD) runs on y with weights W' = W diag(gamma) 2^-s prepared once, and its
-//     epilogue finishes the normalisation per output element:
-//         LN(y) W^T + b  =  rstd_r 2^s (y W'^T - mu_r c) + d,     c_j = sum_i W'_ji,   d_j = b_j + sum_i beta_i W_ji
-//     (mu_r, rstd_r from the row's partials; c and d are vectors prepared with the weights);
-//   * whoever needs the normalised row as a RESIDUAL (the next EPI 3 product) or as a layer output (the pooling kernel) applies
-//     (y - mu) rstd gamma + beta to the fp32 y it reads anyway.
-// Row statistics are one-pass sums in fp32 over 768-1024 elements (var = E[y^2] - mu^2, clamped at 0): |mu| << sigma on these rows.
-struct CorrFold {
-  const float* in_part;    // FOLD: partials of the A rows, [M][4][2], the first in_np slots used
-  const float* colc;       // FOLD: c [N]
-  int in_np;
-  float wscale;            // FOLD: 2^s
-  const float* rs_part;    // EPI 3: partials of the residual rows [M][4][2] (rs_np used); NULL = the residual rows are taken as they are
-  const float* rs_g;       // EPI 3: gamma, beta [N] of the residual's LayerNorm
-  const float* rs_b;
-  int rs_np;
-  float* out_part;         // EPI 3: [M][4][2] partials of the rows written (slot = column tile, N / 256 <= 4 of them)
-  void* C16;               // EPI 3: the written rows in the split operand form (C16 f16 [M][ldc], C8 e4m3 [M][2 ldc])
-  float inv_h;             // 1 / (row length the partials cover)
-  float eps;
-};
-constexpr int kFoldSlots = 4;                // partial slots per row (32 bytes: rows of partials can be gathered 16 bytes at a time); N <= 1024
-constexpr int kFoldStatsOff = 72 * 1024;    // LDS: (mu, rstd) of the tile's 256 rows, beyond the epilogue's staging image (68 KB)
-constexpr int kFoldPartOff = 76 * 1024;     // LDS: [4 column groups][256 rows] (sum, sumsq) of an EPI 3 tile
-
-// (mu, rstd) of the tile's rows m0 .. m0 + 255 from their partials -> LDS; every thread of the workgroup calls it
-__device__ __forceinline__ void fold_row_stats(char* smem, const float* __restrict__ part, int np, int m0, float inv_h, float eps) {
-  if (threadIdx.x < 256) {
-    const float* p = part + (size_t)(m0 + threadIdx.x) * (2 * kFoldSlots);
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < np; ++k) {
-      s += p[2 * k];
-      q += p[2 * k + 1];
-    }
-    const float mu = s * inv_h;
-    const float var = fmaxf(q * inv_h - mu * mu, 0.f);
-    reinterpret_cast<float2*>(smem + kFoldStatsOff)[threadIdx.x] = make_float2(mu, 1.0f / sqrtf(var + eps));
-  }
-  __syncthreads();
-}
-// sum over the 16 lanes of a DPP row (the lanes that share a tile row in the epilogue); every lane gets the total
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
-  return v;
-}
-
+// (CorrFold, fold_row_stats, row16_sum: gemm_shared.h - the plain 16-bit kernel folds its LayerNorms the same way since round 6)
 // EPI: 0 fp32 out; 1 fp32 out + fp32 residual; 2 GELU, split out; 3 fp32 out + (LayerNorm of the) residual, split out, row partials.
 // FOLD (EPI 0 / 2): the A rows are pre-LayerNorm rows, see CorrFold.
 template <int EPI, bool FOLD = false>

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "ruart_bert_workspace_bytes_folded": (c_size_t, [POINTER(BertModelC), _I]),
     "ruart_bert_forward_folded": (_I, [POINTER(BertModelC), POINTER(BertBatchC), _P, _P, _P, c_size_t, _P]),
     "ruart_gemm_16c_nt_fold": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ruart_gemm_16_nt_fold": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _P]),
     "ruart_rows_stats_finish": (_I, [_P, _I, _I, _F, _F, _P, _P]),
     "ruart_bert_pool_mix_ln": (_I, [_P, _LL, _I, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_pool_ln_set_variant": (_I, [_I]),

@@ -345,7 +345,8 @@ def _bert_case(golden_dir, name):
 @pytest.mark.parametrize("name", ["bert_small", "bert_base"])
 @pytest.mark.parametrize("precision,pack,tol", [("fp32", True, 5e-5), ("fp32", False, 5e-5), ("bf16", True, 6e-2), ("fp16", True, 1.5e-2), ("fp16", False, 1.5e-2),
                                                 ("x3", True, 3e-4), ("fp16c", True, 6e-4), ("fp16c", False, 6e-4),
-                                                ("fp16c-fold", True, 6e-4), ("fp16c-fold", False, 6e-4)])
+                                                ("fp16c-fold", True, 6e-4), ("fp16c-fold", False, 6e-4),
+                                                ("fp16-fold", True, 1.5e-2), ("fp16-fold", False, 1.5e-2), ("bf16-fold", True, 6e-2)])
 def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol):
     """Whole encoder through ruart_bert_forward (fp16c-fold: ruart_bert_forward_folded, the LayerNorms folded into the projections;
     its pre-LayerNorm rows are normalised by layer_outputs) vs the reference's own layer outputs (gen_golden.py)."""
@@ -353,8 +354,8 @@ def test_bert_encoder_vs_reference_golden(golden_dir, name, precision, pack, tol
     z, cfg, w = _bert_case(golden_dir, name)
     fold = precision.endswith("-fold")
     precision = precision.replace("-fold", "")
-    if precision == "fp16c" and cfg["hidden_size"] % 256:
-        pytest.skip("the f16 + fp8-correction GEMM takes hidden sizes that are multiples of 256 (bert-base / bert-large)")
+    if (precision == "fp16c" or fold) and cfg["hidden_size"] % 256:
+        pytest.skip("the f16 + fp8-correction GEMM and the folded passes take hidden sizes that are multiples of 256 (bert-base / bert-large)")
     d = dev()
     W = BertEncoderWeights(w, cfg, d, precision, ln_fold=fold)
     assert W.ln_fold == fold
@@ -1155,6 +1156,93 @@ def test_gemm_16c_fold_consumer(M, N, K, gelu):
     e_u = float((ref_u - ref).pow(2).mean().sqrt())
     print("fold rms err %.2e (max %.2e) | unfolded fp16c rms %.2e | mean |ref| %.2e" % (e_f, maxerr(got, ref), e_u, float(ref.abs().mean())))
     assert e_f < 4 * e_u + 1e-6 and maxerr(got, ref) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (512, 1024, 1024), (256, 768, 3072)])
+@pytest.mark.parametrize("res_ln", [False, True])
+def test_gemm_16_fold_producer(M, N, K, res_ln, dt):
+    """kind 3 of ruart_gemm_16_nt_fold (round 6: the plain 16-bit pass's attention-output / output dense with the LayerNorm behind it
+    folded away): y = A W^T + b + residual (16-bit rows, normalised from their partials when res_ln) written in 16 bits, and the row
+    partials of the UNROUNDED y - against fp64 on the operands as the kernel reads them."""
+    lib = hip.load()
+    d = dev()
+    code, td = (hip.DT_F16, torch.float16) if dt == "fp16" else (hip.DT_BF16, torch.bfloat16)
+    g = torch.Generator().manual_seed(M + N + K + int(res_ln))
+    A = torch.randn(M, K, generator=g).to(td)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(td)
+    bias = torch.randn(N, generator=g) * 0.1
+    R = (torch.randn(M, N, generator=g) * 1.5 + 0.2).to(td)
+    gam, bet = 1.0 + 0.3 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    if res_ln:
+        mu = R.double().mean(1, keepdim=True)
+        var = ((R.double() - mu) ** 2).mean(1, keepdim=True)
+        ref = ref + (R.double() - mu) / torch.sqrt(var + 1e-12) * gam.double() + bet.double()
+    else:
+        ref = ref + R.double()
+    dv = lambda t: t.to(d)
+    Ad, Wd, bd, Rd, gd, bed = map(dv, (A, W, bias, R, gam, bet))
+    rp = dv(_row_partials(R.float())) if res_ln else None
+    C = torch.zeros(M, N, dtype=td, device=d)
+    part = torch.full((M, 4, 2), -7.0, dtype=torch.float32, device=d)
+    rc = lib.ruart_gemm_16_nt_fold(hip.ptr(Ad), K, hip.ptr(Wd), K, hip.ptr(bd), 3, None, 0, None, 1.0, hip.ptr(Rd), N, hip.ptr(rp), N // 256,
+                                   hip.ptr(gd), hip.ptr(bed), hip.ptr(C), N, hip.ptr(part), M, N, K, N, 1e-12, code, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -11 if dt == "fp16" else 2.0 ** -8
+    assert maxerr(C.float(), ref) < 1.5 * ulp * float(ref.abs().max())              # y rounded once to 16 bits
+    want = _row_partials(ref.float())
+    got = part.cpu()
+    nt = N // 256
+    assert maxerr(got[:, :nt, 0], want[:, :nt, 0]) < 5e-4 * max(1.0, float(want[:, :nt, 0].abs().max()))       # the partials come from the fp32 y
+    assert maxerr(got[:, :nt, 1], want[:, :nt, 1]) < 5e-5 * float(want[:, :nt, 1].abs().max())
+    if nt < 4:
+        assert float((got[:, nt:] + 7.0).abs().max()) == 0.0                       # unused slots untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(256, 2304, 768), (512, 3072, 768), (256, 4096, 1024)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_16_fold_consumer(M, N, K, gelu, dt):
+    """kind 0 / 2 of ruart_gemm_16_nt_fold on 16-bit pre-LayerNorm rows y with folded 16-bit weights: rstd (y W'^T - mu c) + d against
+    LayerNorm(y) W^T + b in fp64, and against the plain 16-bit product of the materialised LayerNorm rows: about as accurate."""
+    lib = hip.load()
+    d = dev()
+    code, td = (hip.DT_F16, torch.float16) if dt == "fp16" else (hip.DT_BF16, torch.bfloat16)
+    g = torch.Generator().manual_seed(M + N + K + int(gelu))
+    y = (torch.randn(M, K, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + 0.3 * torch.randn(M, 1, generator=g)).to(td)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    gam, bet = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    mu = y.double().mean(1, keepdim=True)
+    var = ((y.double() - mu) ** 2).mean(1, keepdim=True)
+    x = (y.double() - mu) / torch.sqrt(var + 1e-12) * gam.double() + bet.double()
+    ref = x @ W.double().t() + bias.double()
+    if gelu:
+        ref = O.gelu_erf(ref)
+    wf = (W * gam[None, :]).to(td)                                                  # W' as the matrix cores multiply it
+    dvec = (bias.double() + W.double() @ bet.double()).float()
+    cvec = wf.double().sum(1).float()
+    dv = lambda t: t.to(d)
+    yd, wfd, dd, cd, pd = map(dv, (y, wf, dvec, cvec, _row_partials(y.float())))
+    C = torch.zeros(M, N, dtype=td, device=d)
+    rc = lib.ruart_gemm_16_nt_fold(hip.ptr(yd), K, hip.ptr(wfd), K, hip.ptr(dd), 2 if gelu else 0, hip.ptr(pd), K // 256, hip.ptr(cd), 1.0, None, 0,
+                                   None, 0, None, None, hip.ptr(C), N, None, M, N, K, K, 1e-12, code, hip.stream_ptr())
+    assert rc == 0
+    # the unfolded product of the materialised rows
+    xd, Wd, biasd = dv(x.to(td)), dv(W.to(td)), dv(bias)
+    U = torch.zeros(M, N, dtype=td, device=d)
+    rc = lib.ruart_gemm_16_nt(hip.ptr(xd), K, hip.ptr(Wd), K, hip.ptr(biasd), None, 0, code, hip.ptr(U), N, code, M, N, K,
+                              hip.ACT_GELU if gelu else hip.ACT_NONE, code, hip.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    e_f = float((C.double().cpu() - ref).pow(2).mean().sqrt())
+    e_u = float((U.double().cpu() - ref).pow(2).mean().sqrt())
+    print("fold rms err %.2e | unfolded %s rms %.2e | mean |ref| %.2e" % (e_f, dt, e_u, float(ref.abs().mean())))
+    assert e_f < 2.5 * e_u + 1e-6
 
 
 @pytest.mark.gpu
