@@ -982,8 +982,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float
   flush_pending();
 }
 
+// RUART_ATTN_LONG_WPS: minimum waves per SIMD the register allocator has to leave room for (2: 145 VGPRs, three workgroups per CU;
+// 4: 128 VGPRs with five spilled, four workgroups per CU - A/B builds, tools/r06_attn_long.sh)
+#ifndef RUART_ATTN_LONG_WPS
+#define RUART_ATTN_LONG_WPS 2
+#endif
 template <typename T16>
-__global__ __launch_bounds__(256, 2) void attn_flash_long_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
+__global__ __launch_bounds__(256, RUART_ATTN_LONG_WPS) void attn_flash_long_kernel(const T16* __restrict__ qkv, int ld, T16* __restrict__ ctx, int ldc, int H,
                                                                  const int* __restrict__ bq0, const int* __restrict__ bq1,
                                                                  const int* __restrict__ bk0, const int* __restrict__ bk1,
                                                                  const float* __restrict__ key_bias, int n_long) {
