@@ -765,7 +765,8 @@ def main():
         dist.destroy_process_group()
     torch.cuda.synchronize()
     if getattr(tr.network, "Bert", None) is not None:
-        tr.network.Bert.close(destroy=True)     # the CU-masked run-ahead stream must not outlive the interpreter (hip.destroy_stream)
+        tr.network.Bert.close(destroy=True)     # the CU-masked streams must not outlive the interpreter (hip.destroy_stream)
+    tr._destroy_masked_streams()
 
 
 if __name__ == "__main__":

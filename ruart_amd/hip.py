@@ -261,6 +261,7 @@ def cu_masked_stream(n_cus, device):
     # default prefetch stream then).  The process exit releases the stream; call ruart_stream_destroy yourself to drop one earlier.
     st = torch.cuda.ExternalStream(out.value, device=device)
     st._ruart_handle = out.value            # for destroy_stream()
+    st._ruart_masked = True
     return st
 
 

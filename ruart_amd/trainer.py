@@ -272,6 +272,19 @@ class SDNetTrainer(BaseTrainer):
             bert = getattr(getattr(self, "network", None), "Bert", None)
             if bert is not None:
                 bert.close(destroy=True if final else None)
+            if final:
+                self._destroy_masked_streams()
+
+    def _destroy_masked_streams(self):
+        """``close(final=True)``: the step's CU-masked streams (SDNet.trunk_stream_cus) go the way of the encoder's masked stream."""
+        from . import hip
+        for cache in (self.__dict__.get("_step_streams"), getattr(getattr(self, "network", None), "__dict__", {}).get("_streams")):
+            for key, v in list((cache or {}).items()):
+                sts = v if isinstance(v, tuple) else (v,)
+                if any(getattr(s, "_ruart_masked", False) for s in sts):
+                    del cache[key]
+                    for s in sts:
+                        hip.destroy_stream(s)
 
     def ToCUDA(self, batch):
         """Models/SDNetTrainer.py:208-230.  Index vectors and the packed BERT stream are prepared here, from the host copies,
@@ -333,7 +346,7 @@ class SDNetTrainer(BaseTrainer):
         cache = self.__dict__.setdefault("_step_streams", {})
         st = cache.get(pr)
         if st is None:
-            ncu = int(os.environ.get("RUART_TRUNK_CUS", 0))         # experiments: the trunk's streams limited to n CUs
+            ncu = self.network.trunk_stream_cus()                   # an experiment's CU mask (SDNet.trunk_stream_cus; 0 by default)
             if ncu != 0:
                 from . import hip
                 st = hip.cu_masked_stream(ncu, dev)

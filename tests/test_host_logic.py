@@ -519,7 +519,7 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
     pass (sdnet.SDNet.trunk_stream_priority, bert.Bert.prefetch_cus) - checked on bare objects, no device needed."""
     from ruart_amd.bert import Bert
     from ruart_amd.sdnet import SDNet
-    for k in ("RUART_TRUNK_PRIORITY", "RUART_PREFETCH_CUS_EVAL"):
+    for k in ("RUART_TRUNK_PRIORITY", "RUART_PREFETCH_CUS_EVAL", "RUART_TRUNK_CUS"):
         monkeypatch.delenv(k, raising=False)
 
     class FakeBert:
@@ -532,9 +532,10 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
 
     class FakeNet:
         trunk_stream_priority = SDNet.trunk_stream_priority
+        trunk_stream_cus = SDNet.trunk_stream_cus
 
-        def __init__(self, bert):
-            self.Bert = bert
+        def __init__(self, bert, opt=None):
+            self.Bert, self.opt = bert, opt or {}
 
     assert FakeBert(240, True).prefetch_cus() == 240 and FakeBert(240, False).prefetch_cus() == 0
     # 'auto': the smallest mask with the fewest GEMM tile rounds for the batch's rows (167 / 168 row tiles of the bench batches: 224)
@@ -548,6 +549,11 @@ def test_stream_settings_follow_the_schedule(monkeypatch):
     assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == 1          # fp16c schedule, training: LOW beside the masked pass
     assert FakeNet(FakeBert(240, False)).trunk_stream_priority() == -1        # evaluation: unmasked pass, trunk first
     assert FakeNet(FakeBert(0, True)).trunk_stream_priority() == -1           # plain 16-bit modes: never masked
+    # the step's streams are never CU-masked by default (SDNet.trunk_stream_cus: an experiment's knob; option and environment set it)
+    assert FakeNet(FakeBert(240, True)).trunk_stream_cus() == 0 and FakeNet(FakeBert(240, False)).trunk_stream_cus() == 0
+    assert FakeNet(FakeBert(240, True), {"ruart_trunk_cus": -160}).trunk_stream_cus() == -160
+    monkeypatch.setenv("RUART_TRUNK_CUS", "-128")
+    assert FakeNet(FakeBert(240, True), {"ruart_trunk_cus": 0}).trunk_stream_cus() == -128
     monkeypatch.setenv("RUART_TRUNK_PRIORITY", "-1")
     assert FakeNet(FakeBert(240, True)).trunk_stream_priority() == -1
 
@@ -568,7 +574,8 @@ def test_readback_is_deferred_inside_the_training_loop_only():
         def __init__(self, opt, dev, trained=False, in_loop=False):
             self.opt, self.device, self._in_train_loop = opt, torch.device(dev), in_loop
             bert = type("B", (), {"bert_model": object() if trained else None})()
-            self.network = type("N", (), {"Bert": bert, "train": lambda self_: None, "trunk_stream_priority": lambda self_: 1})()
+            self.network = type("N", (), {"Bert": bert, "train": lambda self_: None, "trunk_stream_priority": lambda self_: 1,
+                                 "trunk_stream_cus": lambda self_: 0})()
 
     assert Fake({}, "cuda").__class__._defer_readback(Fake({}, "cuda")) is False
     assert Fake({}, "cuda", in_loop=True)._defer_readback() is True
