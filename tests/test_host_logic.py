@@ -600,6 +600,7 @@ def test_close_final_decides_the_masked_streams_destruction(monkeypatch):
 
     class Fake:
         close = SDNetTrainer.close
+        _destroy_masked_streams = SDNetTrainer._destroy_masked_streams
         flush_readback = lambda self: None
 
         def __init__(self):
@@ -608,6 +609,18 @@ def test_close_final_decides_the_masked_streams_destruction(monkeypatch):
     Fake().close()
     Fake().close(final=True)
     assert seen == [None, True]
+    # an experiment's CU-masked step streams (SDNet.trunk_stream_cus) go with final=True too; torch's own streams are left alone
+    import ruart_amd.hip as hip_mod
+    gone = []
+    monkeypatch.setattr(hip_mod, "destroy_stream", lambda st: gone.append(st))
+    masked, plain = type("S", (), {"_ruart_masked": True})(), type("S", (), {})()
+    f = Fake()
+    f._step_streams = {1: masked, -1: plain}
+    f.network._streams = {1: (masked, masked), -1: (plain, plain)}
+    f.close()
+    assert gone == [] and len(f._step_streams) == 2
+    f.close(final=True)
+    assert gone == [masked] * 3 and f._step_streams == {-1: plain} and f.network._streams == {-1: (plain, plain)}
     # Bert.close(None) keeps the streams whatever tool library the environment names
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
     monkeypatch.delenv("RUART_DESTROY_STREAMS", raising=False)
