@@ -64,6 +64,11 @@ int ruart_gemm_16c_nt(const void* A16, const void* A8, int lda, const void* W16,
 /* out4 = {SA_LO, SA_HI, SW_HI, SW_LO}: the power-of-two exponents of the e4m3 companions described above, as compiled into this library
  * (activation residual, activation value, weight value, weight residual); 2^-(SA_LO + SW_HI) is the scale of the fp8 product. */
 int ruart_f16c_shifts(int* out4);
+/* Tile form of the fp16c products without a residual (the QKV and intermediate dense sites, Models/Bert/modeling.py:225-227, 261;
+ * ruart_gemm_16c_nt / _ws / _fold kinds 0 and 2): 0 = 256 x 256 tiles, one workgroup of eight waves per CU; 1 = 256 x 128 tiles, TWO
+ * workgroups of four waves per CU, so that one multiplies while the other stores its tile (gemm_corr.hip, gemm_16c_nt_256x128d).  Same
+ * products in the same order per output element: results are bit-identical.  Returns the previous setting. */
+int ruart_gemm_16c_set_dual(int on);
 /* The same product with a chosen subset of the correction terms (same sites; the ablation of tools/corr_ablation.py): corr 3 = both
  * (== ruart_gemm_16c_nt), 1 = only a_lo . w_hi (the activation's rounding residual), 2 = only a_hi . w_lo (the weight's), 0 = none
  * (a plain f16 product through this kernel).  corr 1 / 2 need K % 256 == 0. */

@@ -84,13 +84,16 @@ __device__ __forceinline__ f32x4_t gelu4_as(f32x4_t v) {
 // (CorrFold, fold_row_stats, row16_sum: gemm_shared.h - the plain 16-bit kernel folds its LayerNorms the same way since round 6)
 // EPI: 0 fp32 out; 1 fp32 out + fp32 residual; 2 GELU, split out; 3 fp32 out + (LayerNorm of the) residual, split out, row partials.
 // FOLD (EPI 0 / 2): the A rows are pre-LayerNorm rows, see CorrFold.
-template <int EPI, bool FOLD = false>
+// WN: wave columns of the tile (4: the 256 x 256 tile of eight waves; 2: the 256 x 128 tile of four, gemm_16c_nt_256x128d - EPI 0 / 2 only).
+template <int EPI, bool FOLD = false, int WN = 4>
 __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, int m0, int n0, const float* __restrict__ bias,
                                               const float* __restrict__ R, int ldr, void* __restrict__ C, int ldc,
-                                              unsigned char* __restrict__ C8, int N, int hh0, int hh1, const CorrFold& f) {
+                                              unsigned char* __restrict__ C8, int N, int hh0, int hh1, const CorrFold& f,
+                                              const float2* pre_stats = nullptr) {
+  static_assert(WN == 4 || (WN == 2 && EPI != 3 && EPI != 1), "the 256 x 128 tile carries the QKV / intermediate epilogues only");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  const int wm = WN == 4 ? wave >> 2 : wave >> 1, wn = wave & (WN - 1), fr = lane & 15, fq = lane >> 4;
   constexpr int ERS = 272;
   char* my = smem + wave * (32 * ERS);
   const int rrow = lane >> 4, rcol = (lane & 15) * 4;
@@ -100,15 +103,26 @@ __device__ __forceinline__ void corr_epilogue(f32x4_t (&acc)[4][8], char* smem, 
   f32x4_t cv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, ev = {0.f, 0.f, 0.f, 0.f};
   bool res_ln = false;
   float wsc = 1.f;
+  // (mu, rstd) of the tile's rows -> LDS: from the partials, or - `pre_stats` - the pair thread i < 256 already holds for row m0 + i (the
+  // 256 x 128 kernel finishes them ahead of its K loop, where they cost two registers instead of a spill of the accumulators; in the 256 x 256
+  // kernel the same move measured equal - QKV 282 against 276 us, FF1 408 / 405 - and is not made)
+  auto put_stats = [&](const float* part, int np) {
+    if (pre_stats) {
+      if (threadIdx.x < 256) reinterpret_cast<float2*>(smem + kFoldStatsOff)[threadIdx.x] = *pre_stats;
+      __syncthreads();
+    } else {
+      fold_row_stats(smem, part, np, m0, f.inv_h, f.eps);
+    }
+  };
   if constexpr (FOLD) {
-    fold_row_stats(smem, f.in_part, f.in_np, m0, f.inv_h, f.eps);
+    put_stats(f.in_part, f.in_np);
     cv = *reinterpret_cast<const f32x4_t*>(f.colc + ncol);
     wsc = f.wscale;
   }
   if constexpr (EPI == 3) {
     res_ln = f.rs_part != nullptr;
     if (res_ln) {
-      fold_row_stats(smem, f.rs_part, f.rs_np, m0, f.inv_h, f.eps);
+      put_stats(f.rs_part, f.rs_np);
       gv = *reinterpret_cast<const f32x4_t*>(f.rs_g + ncol);
       ev = *reinterpret_cast<const f32x4_t*>(f.rs_b + ncol);
     }
@@ -504,6 +518,244 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   C8_STAMP(4);
 }
 
+// ---- 256 x 128 tiles, TWO resident workgroups per CU ("dual" form; round 6) -----------------------------------------------------------
+// The stamps of gemm_16c_nt_256p8 say its K loop runs at 85 % of the matrix pipe's time and that what is left of a
+// tile is the part in which the pipe does nothing at all: 2 us of pipeline fill and 5-17 us of epilogue in a 41-55 us tile - the CU has ONE
+// workgroup, and that workgroup is either multiplying or storing.  This form halves the tile along N and the workgroup to four waves (one
+// per SIMD, the same 128 x 64 sub-tile, fragment reads and 32 MFMAs per K-tile as a wave of the 256 x 256 kernel), so that a CU holds two
+// workgroups (2 x 80 KB of LDS, 2 x 256 registers per SIMD lane): while one stores its tile or fills its pipeline the other multiplies, and
+// while both multiply they share each SIMD's matrix pipe the way the two wave groups of the big kernel do - without a barrier between them.
+// Costs: an A K-tile (32 KB) now feeds 128 output columns instead of 256: +50 % operand bytes from L2 per flop.
+//   * LDS (80 KB): A half-tiles (128 rows x 128 B = 16 KB; half h = rows wm*128 + h*64 .. +64 of both wave rows) in a RING OF THREE - half
+//     s = 2t + h of the stream lives in slot s % 3 -, W half-tiles (64 rows = 8 KB; half h = rows wn*64 + h*32 .. +32) double-buffered.
+//   * Phase p of K-tile t:  fragment reads | ONE half-tile prefetch | counted wait | lgkmcnt(0) | s_barrier | 8 (fp8) / 16 (f16) MFMAs.
+//     ONE barrier per phase (no wave group runs a barrier behind here): a slot is restaged in a later phase than its reads, and every wave
+//     completed those reads before the barrier the staging wave has passed; a piece is read in a later phase than the wait that covers
+//     it, behind the barrier every wave reaches after its own wait.
+//       p0: read W-h0(t), A-h0(t)   stage A-h0(t+1) -> the slot of A-h1(t-1)                         quadrant (0, 0)
+//       p1: read W-h1(t)            stage W-h0(t+2) -> its own slot        wait: A-h1(t) landed       quadrant (1, 0)
+//       p2: read A-h1(t)            stage A-h1(t+1) -> the slot of A-h0(t)                            quadrant (1, 1)
+//       p3:                         stage W-h1(t+2) -> its own slot        wait: A-h0(t+1) landed     quadrant (0, 1)
+//     Per wave an A half is 4 LDS-DMA instructions, a W half 2; both waits leave the 8 youngest in flight (vmcnt(8)) and give every piece
+//     >= 3 phases to land, as the big kernel's single wait does.
+// EPI 0 / 2 (QKV, intermediate dense; FOLD or not), both correction products, no tail split.  M % 256 == 0, N % 128 == 0, K % 128 == 0.
+#define DBN 128
+// diagnostic builds: RUART_D_PRIO 0 = s_setprio 1 around every quadrant's MFMAs (as the 256 x 256 kernel), 1 = no priority changes, 2 = static
+// priority by seat; RUART_D_BAR2 1 = a second barrier behind every quadrant (the 256 x 256 kernel's phase shape)
+#ifndef RUART_D_PRIO
+#define RUART_D_PRIO 0
+#endif
+#ifndef RUART_D_BAR2
+#define RUART_D_BAR2 0
+#endif
+#if RUART_D_BAR2
+#define D_BAR2() RUART_BAR()
+#else
+#define D_BAR2()
+#endif
+template <int EPI, bool FOLD = false>
+__global__ __launch_bounds__(256, 2) void gemm_16c_nt_256x128d(const char* __restrict__ A16, const char* __restrict__ A8, int pitch_a,
+                                                               const char* __restrict__ W16, const char* __restrict__ W8, int pitch_w,
+                                                               const float* __restrict__ bias, void* __restrict__ C, int ldc,
+                                                               unsigned char* __restrict__ C8, int M, int N, int K, int order, const CorrFold f
+#ifdef RUART_P8_STAMPS
+                                                               , unsigned long long* __restrict__ stamps
+#endif
+) {
+#ifdef RUART_P8_STAMPS
+#define D8_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0) stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  if (stamps && (threadIdx.x & 63) == 0) {
+    stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 6] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+  }
+#else
+#define D8_STAMP(i)
+#endif
+  D8_STAMP(0);
+#if RUART_D_PRIO == 2
+  // static priority by SEAT (the wave slot on its SIMD: the two workgroups of a CU sit on different slots): one workgroup of the CU always
+  // takes the matrix pipe first, the other fills its gaps
+  if (__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+  constexpr int kHalfA = 128 * CBKB;             // 16 KB
+  constexpr int kHalfW = 64 * CBKB;              // 8 KB
+  constexpr int kWOff = 3 * kHalfA;              // the W slots [D][h] behind the A ring
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 3 * 16 + 4 * 8 = 80 KB, the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / DBN, ntm = M / CBM;
+  int id = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  int tm, tn;
+  corr_tile_of(id, ntm, ntn, order, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm);
+  tn = __builtin_amdgcn_readfirstlane(tn);
+  const int m0 = tm * CBM, n0 = tn * DBN;
+  const int nt = K / 64, NT = 2 * nt;
+  // FOLD: thread i finishes the statistics of row m0 + i here, ahead of the loop (two registers), so that the epilogue does not wait for them
+  float2 row_stat = make_float2(0.f, 1.f);
+  if constexpr (FOLD) row_stat = fold_row_stat_of(f.in_part, f.in_np, m0 + tid, f.inv_h, f.eps);
+
+  // staging: wave w fills local rows 32w .. 32w+31 of an A half (four 1 KB pieces of 8 rows x 128 B, lane-linear) and 16w .. 16w+15 of a
+  // W half (two pieces); the XOR swizzle sits on the SOURCE chunk, one per-lane offset serves both phases (gemm_16c_nt_256p8)
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const unsigned a_lane = (unsigned)(srow * pitch_a + schunk * 16), w_lane = (unsigned)(srow * pitch_w + schunk * 16);
+  const size_t a_row0 = (size_t)(m0 + (wave >> 1) * 128 + (wave & 1) * 32) * pitch_a;
+  const size_t w_row0 = (size_t)(n0 + (wave >> 1) * 64 + (wave & 1) * 16) * pitch_w;
+  const size_t a8r = (size_t)8 * pitch_a, w8r = (size_t)8 * pitch_w, a_h = (size_t)64 * pitch_a, w_h = (size_t)32 * pitch_w;
+  auto stage_a = [&](int slot, int h, int kt) {
+    char* dst = smem + slot * kHalfA + wave * 4096;
+    const char* src = (kt < nt ? A16 + (size_t)kt * CBKB : A8 + (size_t)(kt - nt) * CBKB) + a_row0 + h * a_h;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dma16(src + p * a8r, a_lane, dst + p * 1024);
+  };
+  auto stage_w = [&](int d, int h, int kt) {
+    char* dst = smem + kWOff + (d * 2 + h) * kHalfW + wave * 2048;
+    const char* src = (kt < nt ? W16 + (size_t)kt * CBKB : W8 + (size_t)(kt - nt) * CBKB) + w_row0 + h * w_h;
+    dma16(src, w_lane, dst);
+    dma16(src + w8r, w_lane, dst + 1024);
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  i32x8_t af[4], wf0[2], wf1[2];
+  auto frag = [&](const char* base, int row) {
+    const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(base + lds_off(row, fq));
+    const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(base + lds_off(row, 4 + fq));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_a = [&](int slot) {
+    const char* sa = smem + slot * kHalfA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = frag(sa, wm * 64 + j * 16 + fr);
+  };
+  auto read_w = [&](int d, int h, i32x8_t (&wf)[2]) {
+    const char* sw = smem + kWOff + (d * 2 + h) * kHalfW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i] = frag(sw, wn * 32 + i * 16 + fr);
+  };
+  const int scale_w = 0x01010101 * (127 - RUART_C8_SHIFT), scale_a = 0x7f7f7f7f;
+  auto quad = [&](auto f8tag, int hc, int hr, i32x8_t (&wf)[2]) {
+    constexpr bool F8 = decltype(f8tag)::value;
+#if RUART_D_PRIO == 0
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[hc * 2 + i][hr * 4 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], af[j], acc[hc * 2 + i][hr * 4 + j], RUART_C8_FMT,
+                                                                                         RUART_C8_FMT, 0, scale_w, 0, scale_a);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const i32x4_t w4 = ks ? __builtin_shufflevector(wf[i], wf[i], 4, 5, 6, 7) : __builtin_shufflevector(wf[i], wf[i], 0, 1, 2, 3);
+            const i32x4_t a4 = ks ? __builtin_shufflevector(af[j], af[j], 4, 5, 6, 7) : __builtin_shufflevector(af[j], af[j], 0, 1, 2, 3);
+            acc[hc * 2 + i][hr * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w4), __builtin_bit_cast(f16x8_t, a4),
+                                                                                  acc[hc * 2 + i][hr * 4 + j], 0, 0, 0);
+          }
+    }
+#if RUART_D_PRIO == 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+  int rd = 0;                                     // ring slot of the A half read next (half s -> slot s % 3); the half staged next goes to rd - 1
+  auto ring_next = [](int s) { return s == 2 ? 0 : s + 1; };
+  auto ring_prev = [](int s) { return s == 0 ? 2 : s - 1; };
+  // D: W buffer of this tile; N1 / N2: K-tile t+1 / t+2 exists
+  auto tile = [&](auto f8tag, auto dtag, auto n1tag, auto n2tag, int t) {
+    constexpr int D = decltype(dtag)::value;
+    constexpr bool N1 = decltype(n1tag)::value, N2 = decltype(n2tag)::value;
+    // p0
+    read_w(D, 0, wf0);
+    read_a(rd);
+    if (N1) stage_a(ring_prev(rd), 0, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RUART_BAR();
+    quad(f8tag, 0, 0, wf0);
+    D_BAR2();
+    // p1
+    read_w(D, 1, wf1);
+    if (N2) stage_w(D, 0, t + 2);
+    if (N2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A-h1(t) has landed; W-h1(t+1), A-h0(t+1), W-h0(t+2) may be in flight
+    else if (N1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RUART_BAR();
+    quad(f8tag, 1, 0, wf1);
+    D_BAR2();
+    // p2
+    rd = ring_next(rd);
+    read_a(rd);
+    if (N1) stage_a(ring_prev(rd), 1, t + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RUART_BAR();
+    quad(f8tag, 1, 1, wf1);
+    D_BAR2();
+    // p3
+    if (N2) {
+      stage_w(D, 1, t + 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // K-tile t+1's W-h0, W-h1, A-h0 have landed; W-h0(t+2), A-h1(t+1), W-h1(t+2) may be in flight
+    } else if (N1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    RUART_BAR();
+    quad(f8tag, 0, 1, wf0);
+    D_BAR2();
+    rd = ring_next(rd);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+  stage_w(0, 0, 0);
+  stage_a(0, 0, 0);
+  stage_w(0, 1, 0);
+  stage_w(1, 0, 1);
+  stage_a(1, 1, 0);
+  stage_w(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // K-tile 0's W-h0, A-h0, W-h1 landed (this wave's share)
+  RUART_BAR();
+  D8_STAMP(1);
+#ifdef RUART_P8_STAMPS
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int t = 0; t < nt; t += 2) {                            // the f16 run (the fp8 run follows: every tile prefetches)
+    tile(Ff{}, I0{}, Tt{}, Tt{}, t);
+    tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
+  }
+  D8_STAMP(2);
+  {
+    int t = nt;
+    for (; t + 2 < NT; t += 2) {
+      tile(Tt{}, I0{}, Tt{}, Tt{}, t);
+      tile(Tt{}, I1{}, Tt{}, Tt{}, t + 1);
+    }
+    tile(Tt{}, I0{}, Tt{}, Ff{}, t);
+    tile(Tt{}, I1{}, Ff{}, Ff{}, t + 1);
+  }
+  RUART_BAR();                                                 // every wave is done reading operand tiles
+  D8_STAMP(3);
+#ifdef RUART_P8_STAMPS
+  if (stamps && (threadIdx.x & 63) == 0) stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 5] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
+  corr_epilogue<EPI, FOLD, 2>(acc, smem, m0, n0, bias, nullptr, 0, C, ldc, C8, N, 0, 4, f, FOLD ? &row_stat : nullptr);
+#ifdef RUART_P8_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  D8_STAMP(4);
+}
+
 // Second launch of a tail-split product: tile n_full + blockIdx.x = the sum of its S slices IN SLICE ORDER (deterministic), then the
 // tile's epilogue exactly as the GEMM kernel runs it.
 template <int EPI>
@@ -634,6 +886,31 @@ static void launch_corr(const void* A16, const void* A8, int lda, const void* W1
   }
 }
 
+// The 256 x 128 two-workgroups-per-CU form (gemm_16c_nt_256x128d) for the products whose epilogue it carries: EPI 0 / 2, both correction
+// products, single launch.  ruart_gemm_16c_set_dual(1) routes them here.
+int g_corr_dual = 0;
+extern "C" int ruart_gemm_16c_set_dual(int on) {
+  RUART_ENTRY();
+  const int was = g_corr_dual;
+  g_corr_dual = on != 0;
+  return was;
+}
+template <int EPI, bool FOLD = false>
+static void launch_corr_dual(const void* A16, const void* A8, int lda, const void* W16, const void* W8, int ldw, const float* bias, void* C,
+                             int ldc, void* C8, int M, int N, int K, hipStream_t s, const CorrFold& fold = CorrFold{}) {
+  constexpr int lds = 3 * 128 * CBKB + 4 * 64 * CBKB;   // 80 KB
+  const int order = g_tile_order_auto ? ruart_tile_group_m(M / CBM, N / DBN, K, true) : g_tile_order;
+  auto kern = gemm_16c_nt_256x128d<EPI, FOLD>;
+  static bool done = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)done;
+  hipLaunchKernelGGL(kern, dim3((M / CBM) * (N / DBN)), dim3(256), lds, s, (const char*)A16, (const char*)A8, 2 * lda, (const char*)W16,
+                     (const char*)W8, 2 * ldw, bias, C, ldc, (unsigned char*)C8, M, N, K, order, fold
+#ifdef RUART_P8_STAMPS
+                     , g_p8_stamps
+#endif
+                     );
+}
+
 // ruart_gemm_16c_nt_sel with the tail split (above): tail_ws = ruart_gemm_16c_tail_ws_bytes(M, N, K, cus) bytes of scratch the call
 // may use until it has finished on `stream`, cus = the CU count the plan is made for (the stream's CU mask, or the device's CUs);
 // tail_ws NULL / too small or cus <= 0: the single-launch form.
@@ -655,7 +932,12 @@ extern "C" int ruart_gemm_16c_nt_ws(const void* A16, const void* A8, int lda, co
   }
   hipStream_t s = (hipStream_t)stream;
   void* rec = ruart_prof_begin_(s, M, N, K);
-  if (act == RUART_ACT_GELU)
+  const bool dual = g_corr_dual && corr == 3 && !residual && !(tail_ws && cus > 0);
+  if (dual && act == RUART_ACT_GELU)
+    launch_corr_dual<2>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, C8, M, N, K, s);
+  else if (dual)
+    launch_corr_dual<0>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, nullptr, M, N, K, s);
+  else if (act == RUART_ACT_GELU)
     launch_corr<2>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
   else if (residual)
     launch_corr<1>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, nullptr, M, N, K, corr, tail_ws, tail_ws_bytes, cus, s);
@@ -695,6 +977,14 @@ extern "C" int ruart_gemm_16c_nt_fold(const void* A16, const void* A8, int lda, 
   void* rec = ruart_prof_begin_(s, M, N, K);
   if (kind == 3)
     launch_corr<3>(A16, A8, lda, W16, W8, ldw, bias, residual, ldr, C, ldc, C8, M, N, K, 3, nullptr, 0, 0, s, f);
+  else if (g_corr_dual && kind == 2 && in_part)
+    launch_corr_dual<2, true>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, C8, M, N, K, s, f);
+  else if (g_corr_dual && kind == 2)
+    launch_corr_dual<2>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, C8, M, N, K, s);
+  else if (g_corr_dual && in_part)
+    launch_corr_dual<0, true>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, nullptr, M, N, K, s, f);
+  else if (g_corr_dual)
+    launch_corr_dual<0>(A16, A8, lda, W16, W8, ldw, bias, C, ldc, nullptr, M, N, K, s);
   else if (kind == 2 && in_part)
     launch_corr<2, true>(A16, A8, lda, W16, W8, ldw, bias, nullptr, 0, C, ldc, C8, M, N, K, 3, nullptr, 0, 0, s, f);
   else if (kind == 2)

@@ -133,19 +133,21 @@ constexpr int kFoldSlots = 4;                // partial slots per row (32 bytes:
 constexpr int kFoldStatsOff = 72 * 1024;    // LDS: (mu, rstd) of the tile's 256 rows, beyond the epilogue's staging image (68 KB)
 constexpr int kFoldPartOff = 76 * 1024;     // LDS: [4 column groups][256 rows] (sum, sumsq) of an EPI 3 tile
 
+// (mu, rstd) of one row from its partials
+__device__ __forceinline__ float2 fold_row_stat_of(const float* __restrict__ part, int np, int row, float inv_h, float eps) {
+  const float* p = part + (size_t)row * (2 * kFoldSlots);
+  float s = 0.f, q = 0.f;
+  for (int k = 0; k < np; ++k) {
+    s += p[2 * k];
+    q += p[2 * k + 1];
+  }
+  const float mu = s * inv_h;
+  const float var = fmaxf(q * inv_h - mu * mu, 0.f);
+  return make_float2(mu, 1.0f / sqrtf(var + eps));
+}
 // (mu, rstd) of the tile's rows m0 .. m0 + 255 from their partials -> LDS; every thread of the workgroup calls it
 __device__ __forceinline__ void fold_row_stats(char* smem, const float* __restrict__ part, int np, int m0, float inv_h, float eps) {
-  if (threadIdx.x < 256) {
-    const float* p = part + (size_t)(m0 + threadIdx.x) * (2 * kFoldSlots);
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < np; ++k) {
-      s += p[2 * k];
-      q += p[2 * k + 1];
-    }
-    const float mu = s * inv_h;
-    const float var = fmaxf(q * inv_h - mu * mu, 0.f);
-    reinterpret_cast<float2*>(smem + kFoldStatsOff)[threadIdx.x] = make_float2(mu, 1.0f / sqrtf(var + eps));
-  }
+  if (threadIdx.x < 256) reinterpret_cast<float2*>(smem + kFoldStatsOff)[threadIdx.x] = fold_row_stat_of(part, np, m0 + threadIdx.x, inv_h, eps);
   __syncthreads();
 }
 // sum over the 16 lanes of a DPP row (the lanes that share a tile row in the epilogue); every lane gets the total

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "ruart_gemm_16c_tail_ws_bytes": (c_size_t, [_I, _I, _I, _I]),
     "ruart_gemm_16c_nt_ws": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, c_size_t, _I, _P]),
     "ruart_f16c_shifts": (_I, [POINTER(c_int)]),
+    "ruart_gemm_16c_set_dual": (_I, [_I]),
     "ruart_bert_set_correction": (_I, [_I, _I, _I, _I, ctypes.c_ulonglong]),
     "ruart_rows_layernorm_split": (_I, [_P, _I, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ruart_bert_embed_ln_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
@@ -176,6 +177,8 @@ def load(build_if_missing=True):
         fn.argtypes = args
     if os.environ.get("RUART_GEMM_VARIANT"):             # experiments only: tile variant of the encoder GEMM (default 5)
         lib.ruart_gemm_set_variant(int(os.environ["RUART_GEMM_VARIANT"]))
+    if os.environ.get("RUART_CORR_DUAL"):                # experiments only: the 256 x 128 two-workgroups-per-CU form of the fp16c QKV / intermediate
+        lib.ruart_gemm_16c_set_dual(int(os.environ["RUART_CORR_DUAL"]))        # products (measured 5-8 % slower than the 256 x 256 form)
     _lib = lib
     return lib
 

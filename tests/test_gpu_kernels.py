@@ -1091,6 +1091,51 @@ def test_gemm_16c_fold_producer(M, N, K, res_ln):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1024, 2304, 768), (768, 3072, 768), (512, 768, 3072)])
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("fold", [False, True])
+def test_gemm_16c_dual_form_is_bitwise_the_256x256_form(M, N, K, gelu, fold):
+    """ruart_gemm_16c_set_dual(1): the QKV / intermediate products on 256 x 128 tiles with two resident workgroups per CU
+    (gemm_16c_nt_256x128d) accumulate every output element's products in the order of the 256 x 256 kernel: outputs bit for bit equal,
+    plain and LayerNorm-folded, fp32 and GELU + split epilogues; K = 128 is the shortest K loop (two K-tiles per run: prologue and the two
+    closing tiles only)."""
+    from ruart_amd.bert import split_f16c
+    if fold and not 256 <= K <= 1024:
+        pytest.skip("row partials: one to four 256-column tiles")
+    lib = hip.load()
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K + int(gelu) + 2 * int(fold))
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias, colc = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    A16, A8 = split_f16c(A)
+    W16, W8 = _w8(W)
+    A16d, A8d, W16d, W8d, bd, cd = [t.to(d) for t in (A16, A8, W16, W8, bias, colc)]
+    pd = _row_partials(A).to(d) if fold else None
+    outs = []
+    try:
+        for dual in (0, 1):
+            lib.ruart_gemm_16c_set_dual(dual)
+            C = torch.full((M, N), 3.0, dtype=torch.float16 if gelu else torch.float32, device=d)
+            C8 = torch.full((M, 2 * N), 1, dtype=torch.uint8, device=d) if gelu else None
+            if fold:
+                rc = lib.ruart_gemm_16c_nt_fold(hip.ptr(A16d), hip.ptr(A8d), K, hip.ptr(W16d), hip.ptr(W8d), K, hip.ptr(bd), 2 if gelu else 0, hip.ptr(pd),
+                                                max(K // 256, 1), hip.ptr(cd), 2.0, None, 0, None, 0, None, None, hip.ptr(C), N, None, hip.ptr(C8), None,
+                                                M, N, K, K, 1e-12, hip.stream_ptr())
+            else:
+                rc = lib.ruart_gemm_16c_nt(hip.ptr(A16d), hip.ptr(A8d), K, hip.ptr(W16d), hip.ptr(W8d), K, hip.ptr(bd), None, 0, hip.ptr(C), N,
+                                           hip.ptr(C8), M, N, K, hip.ACT_GELU if gelu else hip.ACT_NONE, hip.stream_ptr())
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            outs.append((C, C8))
+    finally:
+        lib.ruart_gemm_16c_set_dual(0)
+    assert bool(torch.isfinite(outs[1][0].float()).all())
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert not gelu or torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(256, 2304, 768), (512, 3072, 768), (256, 4096, 1024)])
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_16c_fold_consumer(M, N, K, gelu):
