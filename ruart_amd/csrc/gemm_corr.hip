@@ -438,6 +438,13 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
   using I1 = std::integral_constant<int, 1>;
   using Tt = std::true_type;
   using Ff = std::false_type;
+  // MFMA of the two runs.  Diagnostic builds (wrong numbers, right timing): RUART_ABL_MFMA 1 = the fp8 instruction in BOTH runs, 2 = the f16
+  // instruction in both - which of the run's properties makes an f16 K-tile 13 % longer than an fp8 K-tile
+#ifndef RUART_ABL_MFMA
+#define RUART_ABL_MFMA 0
+#endif
+  using FA = std::conditional_t<RUART_ABL_MFMA == 1, Tt, Ff>;
+  using FB = std::conditional_t<RUART_ABL_MFMA == 2, Ff, Tt>;
 
   // K-tiles [kb, ke) of this workgroup: everything, or slice `slice` of S (S even: a slice never straddles the f16 / fp8 boundary)
   int kb = 0, ke = NT;
@@ -477,23 +484,23 @@ __global__ RUART_VGPR_ATTR __launch_bounds__(512, 2) void gemm_16c_nt_256p8(cons
     int t = a0;
     const int body_end = a_last ? a1 - 2 : a1;
     for (; t < body_end; t += 2) {
-      tile(Ff{}, I0{}, Tt{}, Tt{}, t);
-      tile(Ff{}, I1{}, Tt{}, Tt{}, t + 1);
+      tile(FA{}, I0{}, Tt{}, Tt{}, t);
+      tile(FA{}, I1{}, Tt{}, Tt{}, t + 1);
     }
     if (a_last) {
-      tile(Ff{}, I0{}, Tt{}, Ff{}, t);
-      tile(Ff{}, I1{}, Ff{}, Ff{}, t + 1);
+      tile(FA{}, I0{}, Tt{}, Ff{}, t);
+      tile(FA{}, I1{}, Ff{}, Ff{}, t + 1);
     }
   }
   C8_STAMP(2);
   if (b0 < b1) {
     int t = b0;
     for (; t + 2 < b1; t += 2) {
-      tile(Tt{}, I0{}, Tt{}, Tt{}, t);
-      tile(Tt{}, I1{}, Tt{}, Tt{}, t + 1);
+      tile(FB{}, I0{}, Tt{}, Tt{}, t);
+      tile(FB{}, I1{}, Tt{}, Tt{}, t + 1);
     }
-    tile(Tt{}, I0{}, Tt{}, Ff{}, t);
-    tile(Tt{}, I1{}, Ff{}, Ff{}, t + 1);
+    tile(FB{}, I0{}, Tt{}, Ff{}, t);
+    tile(FB{}, I1{}, Ff{}, Ff{}, t + 1);
   }
   if (wave < 4) RUART_BAR();                                  // waves 0-3 pair the lagging group's last barrier
   RUART_BAR();                                                // every wave is done reading operand tiles
