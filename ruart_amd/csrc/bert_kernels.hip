@@ -12,8 +12,6 @@
 // All math is fp32; storage type T of activations is float (validation mode) or bf16.
 #include <stdlib.h>
 #include "common.h"
-#include <atomic>
-#include <algorithm>
 #include <type_traits>
 #include "ruart_hip.h"
 
@@ -765,12 +763,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_split_kernel(const float* _
 // have a whole step to complete.
 // The arithmetic of a (window, head) is the one-head kernel's, instruction for instruction: the outputs are bit-identical.
 // ---------------------------------------------------------------------------------------------
-// RUART_ATTN_MH_WPS: waves per SIMD the register allocator leaves room for (2: 161 VGPRs, three workgroups per CU; 4: A/B builds)
-#ifndef RUART_ATTN_MH_WPS
-#define RUART_ATTN_MH_WPS 2
-#endif
-template <int HPG, bool HM = false>
-__global__ __launch_bounds__(256, RUART_ATTN_MH_WPS) void attn_flash_split_mh_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
+template <int HPG>
+__global__ __launch_bounds__(256, 2) void attn_flash_split_mh_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
                                                                      unsigned char* __restrict__ ctx8, int ldc, int H,
                                                                      const int* __restrict__ bq0, const int* __restrict__ bq1,
                                                                      const int* __restrict__ bk0, const int* __restrict__ bk1,
@@ -805,16 +799,14 @@ __global__ __launch_bounds__(256, RUART_ATTN_MH_WPS) void attn_flash_split_mh_ke
 #ifdef RUART_ABL_ATTN_L2LOADS        // diagnostic build (see the one-head kernel)
       const float* kp = qkv + (size_t)(min(row, tn - 1)) * ld + H + h * 64 + piece * 4;
 #else
-      // (HM: head-major planes [3 * heads][ld rows][64] - a key tile is 16 KB of consecutive bytes; else token rows [ld = 3 H])
-      const float* kp = HM ? qkv + ((size_t)((H >> 6) + h) * ld + (kt + min(row, tn - 1))) * 64 + piece * 4
-                           : qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
+      const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
 #endif
 #ifdef RUART_ABL_ATTN_NOLOADS         // diagnostic build: operands without memory traffic (the kernel's on-chip time)
       kx[i] = (f32x4_t){(float)((size_t)kp & 255), 1.f, 2.f, 3.f} * 0.01f;
       vx[i] = (f32x4_t){(float)((size_t)kp & 127), 3.f, 2.f, 1.f} * 0.01f;
 #else
       kx[i] = ATTN_LD4(kp);
-      vx[i] = ATTN_LD4(HM ? kp + (size_t)(H >> 6) * ld * 64 : kp + H);
+      vx[i] = ATTN_LD4(kp + H);
 #endif
     }
     if (tid < 64) {
@@ -824,7 +816,7 @@ __global__ __launch_bounds__(256, RUART_ATTN_MH_WPS) void attn_flash_split_mh_ke
     }
   };
   auto load_q = [&](int h) {
-    const float* qp = HM ? qkv + ((size_t)h * ld + (qvalid ? tq : q0)) * 64 + g * 8 : qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
+    const float* qp = qkv + (size_t)(qvalid ? tq : q0) * ld + h * 64 + g * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #ifdef RUART_ABL_ATTN_NOLOADS
@@ -986,246 +978,6 @@ __global__ __launch_bounds__(256, RUART_ATTN_MH_WPS) void attn_flash_split_mh_ke
     MH_STAMP(5);
     t = t_n;
     hh = hh_n;
-  }
-  flush_pending();
-}
-
-// ---------------------------------------------------------------------------------------------
-// attn_flash_split_mh_kernel as PERSISTENT workgroups on a work queue (round 6).  The multi-head kernel has its next step's loads in flight
-// under this step's products - but a workgroup lives for HPG = 2 steps, so every second step is a workgroup's first: its operands are
-// fetched with nothing to hide them behind, and its context rows drain with nothing behind them (profiles/r05_attn_split_stamps.log:
-// the kernel's parts ADD, 45 % of the HBM rate in the step).  Here a grid of resident workgroups (3 per CU) draws CHUNKS - one window x CH
-// consecutive heads - from a counter and keeps the same pipeline running ACROSS chunks: the draw for the chunk after this one is issued at
-// the top of a chunk's first step (tid 0, one returning atomic) and published through LDS at that step's end, the next window's
-// parameters are fetched in the chunk's second step, and the last step of a chunk issues the first loads of the next chunk where the
-// multi-head kernel issues nothing.  A workgroup's only exposed fetch is its very first.
-// The queue: g_attn_queue[slot], slot chosen by the host per launch (a ring: concurrent launches on different streams never share one).
-// Every workgroup draws until its first draw >= n_chunks, so a launch makes exactly n_chunks + gridDim.x draws; the workgroup whose draw
-// returns the last of them puts the counter back to zero - every wave reaches that exit, whatever the grid and the chunk count.
-// The arithmetic of a (window, head) is the one-head kernel's, instruction for instruction: the outputs are bit-identical.
-// ---------------------------------------------------------------------------------------------
-constexpr int kAttnQueueSlots = 1024;
-__device__ unsigned g_attn_queue[kAttnQueueSlots];
-template <int CH>
-__global__ __launch_bounds__(256, 2) void attn_flash_split_pw_kernel(const float* __restrict__ qkv, int ld, f16_t* __restrict__ ctx16,
-                                                                     unsigned char* __restrict__ ctx8, int ldc, int H,
-                                                                     const int* __restrict__ bq0, const int* __restrict__ bq1,
-                                                                     const int* __restrict__ bk0, const int* __restrict__ bk1,
-                                                                     const int* __restrict__ tok_lo, const float* __restrict__ key_bias,
-                                                                     int n_blocks, int slot) {
-  constexpr int RS = 144;
-  __shared__ __attribute__((aligned(16))) char Kh[64 * RS];
-  __shared__ __attribute__((aligned(16))) char Kl[64 * RS];
-  __shared__ __attribute__((aligned(16))) char Vh[64 * RS];
-  __shared__ __attribute__((aligned(16))) char Vl[64 * RS];
-  __shared__ __attribute__((aligned(16))) float Bs[64];
-  __shared__ __attribute__((aligned(16))) int Ls[64];
-  __shared__ unsigned s_next;
-  typedef f16x8_t frag_t;
-  const int cpw = (H >> 6) / CH;                             // chunks per window
-  const unsigned n_chunks = (unsigned)n_blocks * (unsigned)cpw;
-  const unsigned last_draw = n_chunks + gridDim.x - 1;
-  unsigned* const counter = g_attn_queue + slot;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, g = lane >> 4;
-  const int prow = lane >> 4, piece = lane & 15;
-  // a draw: tid 0's returning atomic; the workgroup that receives the launch's last draw re-arms the counter
-  auto publish = [&](unsigned v) {
-    if (v == last_draw) *counter = 0u;
-    s_next = v;
-  };
-  unsigned drawn = 0;
-  if (tid == 0) publish(atomicAdd(counter, 1u));
-  __syncthreads();
-  unsigned cur = __builtin_amdgcn_readfirstlane(s_next);
-  if (cur >= n_chunks) return;
-
-  // the window of the current chunk, and of the next one (n*)
-  int b = (int)(cur / (unsigned)cpw), h0 = ((int)cur - b * cpw) * CH;
-  int q0 = bq0[b], q1 = bq1[b], k0 = bk0[b], k1 = bk1[b];
-  int tq = q0 + wave * 16 + fr;
-  bool qvalid = tq < q1;
-  int lo_tok = tok_lo[qvalid ? tq : q0];
-  unsigned nxt = n_chunks;
-  int nh0 = 0, nq0 = 0, nq1 = 0, nk0 = 0, nk1 = 0, ntq = 0, nlo_tok = 0;
-  bool nqvalid = false;
-
-  f32x4_t kx[4], vx[4], qx[4];
-  int ls_v = -1;
-  float bs_v = 0.f;
-  auto load_kv = [&](int h, int kt, int tn) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wave * 16 + i * 4 + prow;
-      const float* kp = qkv + (size_t)(kt + min(row, tn - 1)) * ld + H + h * 64 + piece * 4;      // unconditional (clamped) loads
-      kx[i] = ATTN_LD4(kp);
-      vx[i] = ATTN_LD4(kp + H);
-    }
-    if (tid < 64) {
-      const bool in = tid < tn;
-      ls_v = in ? tok_lo[kt + tid] : -1;
-      bs_v = (in && key_bias) ? key_bias[kt + tid] : 0.f;
-    }
-  };
-  auto load_q = [&](int row, int h) {
-    const float* qp = qkv + (size_t)row * ld + h * 64 + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qx[2 * ks] = ATTN_LD4(qp + ks * 32);
-      qx[2 * ks + 1] = ATTN_LD4(qp + ks * 32 + 4);
-    }
-  };
-  load_q(qvalid ? tq : q0, h0);
-  load_kv(h0, k0, min(64, k1 - k0));
-  frag_t qh[2], ql[2];
-  float m = -1e30f, l = 0.f;
-  f32x4_t o[4];
-  // a finished head's context rows in their stored form, written one step later (attn_flash_split_mh_kernel) - with the row they belong to
-  f16x4_t pend16[4];
-  unsigned pend_lo[4], pend_hi[4];
-  int pend_h = -1, pend_tq = 0;
-  auto flush_pending = [&]() {
-    if (pend_h >= 0) {
-      const size_t col = (size_t)pend_h * 64 + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<f16x4_t*>(ctx16 + (size_t)pend_tq * ldc + col + dt * 16) = pend16[dt];
-        unsigned char* p8 = ctx8 + (size_t)pend_tq * 2 * ldc + col + dt * 16;
-        *reinterpret_cast<unsigned*>(p8) = pend_lo[dt];
-        *reinterpret_cast<unsigned*>(p8 + H) = pend_hi[dt];
-      }
-    }
-    pend_h = -1;
-  };
-
-  for (;;) {                                // one iteration = one chunk
-    const int n_tiles = (k1 - k0 + 63) >> 6, n_steps = n_tiles * CH;        // >= 2
-    int hh = 0, t = 0;
-    for (int j = 0; j < n_steps; ++j) {
-      if (j == 0 && tid == 0) drawn = atomicAdd(counter, 1u);               // the chunk after this one: in flight for a whole step
-      if (j == 1) {
-        // (published before step 0's closing barrier)  The next window's parameters: fetched now, used by this chunk's last step
-        nxt = __builtin_amdgcn_readfirstlane(s_next);
-        if (nxt < n_chunks) {
-          const int nb = (int)(nxt / (unsigned)cpw);
-          nh0 = ((int)nxt - nb * cpw) * CH;
-          nq0 = bq0[nb]; nq1 = bq1[nb]; nk0 = bk0[nb]; nk1 = bk1[nb];
-          ntq = nq0 + wave * 16 + fr;
-          nqvalid = ntq < nq1;
-          nlo_tok = tok_lo[nqvalid ? ntq : nq0];
-        }
-      }
-      const int h = h0 + hh, kt = k0 + t * 64;
-      const bool last_tile = t == n_tiles - 1;
-      if (t == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) split_f16x8(qx[2 * ks], qx[2 * ks + 1], qh[ks], ql[ks]);
-        m = -1e30f;
-        l = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      }
-      {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wave * 16 + i * 4 + prow;
-          f16x4_t kh4, kl4, vh4, vl4;
-          split_f16x4(kx[i], kh4, kl4);
-          split_f16x4(vx[i], vh4, vl4);
-          const int off = row * RS + piece * 8;
-          *reinterpret_cast<f16x4_t*>(Kh + off) = kh4;
-          *reinterpret_cast<f16x4_t*>(Kl + off) = kl4;
-          *reinterpret_cast<f16x4_t*>(Vh + off) = vh4;
-          *reinterpret_cast<f16x4_t*>(Vl + off) = vl4;
-        }
-        if (tid < 64) {
-          Ls[tid] = ls_v;
-          Bs[tid] = bs_v;
-        }
-      }
-      flush_pending();                      // the previous head's rows: ahead of the prefetch in the vmcnt queue
-      // the next step's operands: this chunk's next tile / head, or - at the chunk's last step - the first step of the next chunk
-      const int t_n = last_tile ? 0 : t + 1, hh_n = last_tile ? hh + 1 : hh;
-      if (j + 1 < n_steps) {
-        load_kv(h0 + hh_n, k0 + t_n * 64, min(64, k1 - (k0 + t_n * 64)));
-        if (last_tile) load_q(qvalid ? tq : q0, h + 1);
-      } else if (nxt < n_chunks) {
-        load_kv(nh0, nk0, min(64, nk1 - nk0));
-        load_q(nqvalid ? ntq : nq0, nh0);
-      }
-      __syncthreads();
-
-      f32x4_t sacc[4];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        sacc[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int off = (it * 16 + fr) * RS + (ks * 32 + g * 8) * 2;
-          const frag_t kfh = *reinterpret_cast<const frag_t*>(Kh + off);
-          const frag_t kfl = *reinterpret_cast<const frag_t*>(Kl + off);
-          sacc[it] = mfma_16x16x32(kfl, qh[ks], sacc[it]);        // small terms first
-          sacc[it] = mfma_16x16x32(kfh, ql[ks], sacc[it]);
-          sacc[it] = mfma_16x16x32(kfh, qh[ks], sacc[it]);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const i32x4_t lk = *reinterpret_cast<const i32x4_t*>(&Ls[it * 16 + g * 4]);
-        if (key_bias) sacc[it] += *reinterpret_cast<const f32x4_t*>(&Bs[it * 16 + g * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[it][r] = lk[r] == lo_tok ? sacc[it][r] : -1e30f;
-      }
-      frag_t ph[2];
-      flash_softmax_step<f16_t>(sacc, m, l, o, ph);
-      frag_t pl[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { frag_t v; unsigned u[4]; } hv, ll;
-        hv.v = ph[s2];
-        ll.u[0] = lo2_of(sacc[2 * s2][0], sacc[2 * s2][1], hv.u[0]);
-        ll.u[1] = lo2_of(sacc[2 * s2][2], sacc[2 * s2][3], hv.u[1]);
-        ll.u[2] = lo2_of(sacc[2 * s2 + 1][0], sacc[2 * s2 + 1][1], hv.u[2]);
-        ll.u[3] = lo2_of(sacc[2 * s2 + 1][2], sacc[2 * s2 + 1][3], hv.u[3]);
-        pl[s2] = ll.v;
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int off = (32 * s2 + 4 * g + (fr >> 2)) * RS + (dt * 16 + (fr & 3) * 4) * 2;
-          union { struct { tr16x4_t a, b; } s; frag_t f; } uh, ul;
-          uh.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off));
-          uh.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vh + off + 16 * RS));
-          ul.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off));
-          ul.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(Vl + off + 16 * RS));
-          o[dt] = mfma_16x16x32(ul.f, ph[s2], o[dt]);
-          o[dt] = mfma_16x16x32(uh.f, pl[s2], o[dt]);
-          o[dt] = mfma_16x16x32(uh.f, ph[s2], o[dt]);
-        }
-      if (last_tile) {                      // (uniform) convert now, write at the next step
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const f32x4_t v = o[dt] * inv;
-          const f16x4_t hv = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
-          pend16[dt] = hv;
-          const f32x4_t lo = {v[0] - (float)hv[0], v[1] - (float)hv[1], v[2] - (float)hv[2], v[3] - (float)hv[3]};
-          pend_lo[dt] = pack_fp8x4(lo, (float)(1 << RUART_C8_SA_LO));
-          pend_hi[dt] = pack_fp8x4(v, (float)(1 << RUART_C8_SA_HI));
-        }
-        pend_h = qvalid ? h : -1;
-        pend_tq = tq;
-      }
-      if (j == 0 && tid == 0) publish(drawn);
-      __syncthreads();                      // every wave is done reading this step's images (and sees the published draw)
-      t = t_n;
-      hh = hh_n;
-    }
-    if (nxt >= n_chunks) break;
-    cur = nxt;
-    h0 = nh0; q0 = nq0; q1 = nq1; k0 = nk0; k1 = nk1; tq = ntq; qvalid = nqvalid; lo_tok = nlo_tok;
-    nxt = n_chunks;
   }
   flush_pending();
 }
@@ -1599,39 +1351,16 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
                                           const int* tok_hi, const float* key_bias, void* stream) {
   RUART_ENTRY();
   if (n_heads * 64 != H || n_blocks <= 0 || !ctx16 || !ctx8 || (ldc & 3)) return (int)hipErrorInvalidValue;
-  // ld < 0: the Q / K / V rows in HEAD-MAJOR planes, [3 * n_heads][-ld rows][64] (multi-head workgroup forms only)
-  const bool hm = ld < 0;
-  if (hm) {
-    ld = -ld;
-    if (g_attn_split_valu || g_attn_split_hpg < 2) return (int)hipErrorNotSupported;
-  }
   if (g_attn_split_valu)       // diagnostic: the fp32 VALU kernel (lane = query) instead of the split-f16 MFMA kernel
     hipLaunchKernelGGL((attn_varlen_kernel<float, true>), dim3(n_blocks, n_heads), dim3(64), 0, (hipStream_t)stream, qkv, ld, (float*)nullptr,
                        ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, tok_hi, key_bias, (f16_t*)ctx16, (unsigned char*)ctx8);
   else {
     // heads per workgroup: g_attn_split_hpg (ruart_bert_attention_split_set_heads; 0 = the one-head kernel), lowered to a divisor of n_heads
     int hpg = g_attn_split_hpg;
-    if (hpg < 0 && n_heads % (-hpg) == 0) {
-      // the persistent work-queue form, -hpg heads per chunk: three workgroups per CU of the device (a masked stream starts the rest late;
-      // they find the queue empty), a queue slot of its own per launch
-      static std::atomic<unsigned> seq{0};
-      static int n_cu = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-      const int slot = (int)(seq.fetch_add(1) % (unsigned)kAttnQueueSlots);
-      const unsigned chunks = (unsigned)n_blocks * (unsigned)(n_heads / -hpg), grid = std::min(chunks, (unsigned)(3 * n_cu));
-#define RUART_PW(N) hipLaunchKernelGGL(attn_flash_split_pw_kernel<N>, dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, ld, (f16_t*)ctx16, \
-                                       (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, tok_lo, key_bias, n_blocks, slot)
-      if (hpg == -2) RUART_PW(2); else if (hpg == -3) RUART_PW(3); else if (hpg == -4) RUART_PW(4); else RUART_PW(6);
-#undef RUART_PW
-      RUART_CHECK_LAUNCH();
-      return 0;
-    }
-    if (hpg < 0) hpg = 2;
     while (hpg > 1 && n_heads % hpg) --hpg;
-#define RUART_MH(N) do { if (hm) hipLaunchKernelGGL((attn_flash_split_mh_kernel<N, true>), dim3((unsigned)n_blocks * (unsigned)(n_heads / N)), dim3(256), 0,  \
+#define RUART_MH(N) hipLaunchKernelGGL(attn_flash_split_mh_kernel<N>, dim3((unsigned)n_blocks * (unsigned)(n_heads / N)), dim3(256), 0,  \
                                        (hipStream_t)stream, qkv, ld, (f16_t*)ctx16, (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, \
-                                       tok_lo, key_bias); else hipLaunchKernelGGL((attn_flash_split_mh_kernel<N, false>), dim3((unsigned)n_blocks * (unsigned)(n_heads / N)), dim3(256), 0,  \
-                                       (hipStream_t)stream, qkv, ld, (f16_t*)ctx16, (unsigned char*)ctx8, ldc, H, blk_q0, blk_q1, blk_k0, blk_k1, \
-                                       tok_lo, key_bias); } while (0)
+                                       tok_lo, key_bias)
     switch (hpg) {
       case 2: RUART_MH(2); break;
       case 3: RUART_MH(3); break;
@@ -1652,8 +1381,7 @@ extern "C" int ruart_bert_attention_split(const float* qkv, int ld, void* ctx16,
 
 extern "C" int ruart_bert_attention_split_set_heads(int heads_per_workgroup) {
   RUART_ENTRY();
-  if (heads_per_workgroup > 16 || (heads_per_workgroup < 0 && heads_per_workgroup != -2 && heads_per_workgroup != -3 && heads_per_workgroup != -4 &&
-                                   heads_per_workgroup != -6)) return (int)hipErrorInvalidValue;
+  if (heads_per_workgroup < 0 || heads_per_workgroup > 16) return (int)hipErrorInvalidValue;
   g_attn_split_hpg = heads_per_workgroup;
   return 0;
 }

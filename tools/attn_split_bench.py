@@ -39,24 +39,13 @@ flush = torch.empty(128 << 20, dtype=torch.float32, device=dev)
 print("tokens %d, windows %d, bytes per call %.1f MB" % (T, nb, T * 12288 / 1e6))
 
 
-# head-major copy: planes [3 * NH][Tp][64]
-qkv_hm = qkv.view(Tp, 3 * NH, 64).permute(1, 0, 2).contiguous()
-HM = [False]
-
-
 def call():
-    if HM[0]:
-        hip.check(lib.ruart_bert_attention_split(hip.ptr(qkv_hm), -Tp, hip.ptr(ctx16), hip.ptr(ctx8), H, H, NH, nb, hip.ptr(p.blk[0]), hip.ptr(p.blk[1]),
-                                                 hip.ptr(p.blk[2]), hip.ptr(p.blk[3]), hip.ptr(p.tok_lo), hip.ptr(p.tok_hi), None, hip.stream_ptr()), "attn")
-        return
     hip.check(lib.ruart_bert_attention_split(hip.ptr(qkv), 3 * H, hip.ptr(ctx16), hip.ptr(ctx8), H, H, NH, nb, hip.ptr(p.blk[0]), hip.ptr(p.blk[1]),
                                              hip.ptr(p.blk[2]), hip.ptr(p.blk[3]), hip.ptr(p.tok_lo), hip.ptr(p.tok_hi), None, hip.stream_ptr()), "attn")
 
 
 ref = None
-for hpg in [x for x in a.heads.split(",")]:
-    HM[0] = hpg.endswith("hm")                 # "2hm": the multi-head form on head-major planes
-    hpg = int(hpg.replace("hm", ""))
+for hpg in [int(x) for x in a.heads.split(",")]:
     hip.check(lib.ruart_bert_attention_split_set_heads(hpg), "set_heads")
     ctx16.zero_(); ctx8.zero_()
     call()
@@ -75,5 +64,5 @@ for hpg in [x for x in a.heads.split(",")]:
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     us = ts[len(ts) // 2]
-    print("heads/workgroup %2d%s: %7.1f us  = %.2f TB/s of algorithmic bytes   bit-identical to the first setting: %s  sha1 %s" % (hpg, " head-major" if HM[0] else "", us, T * 12288 / us / 1e6, same, digest), flush=True)
+    print("heads/workgroup %2d: %7.1f us  = %.2f TB/s of algorithmic bytes   bit-identical to the first setting: %s  sha1 %s" % (hpg, us, T * 12288 / us / 1e6, same, digest), flush=True)
 hip.check(lib.ruart_bert_attention_split_set_heads(4), "set_heads")
