@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 2500.0        # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md); sparsity figures are never used
+SUSTAINED_F16_TFLOPS, SUSTAINED_FP8_TFLOPS = 2165.0, 4763.0      # pure MFMA streams at the power cap (tools/r06_mfma_power.hip; a note on the line, not a peak)
 DTYPE = {"fp16": "f16", "bf16": "bf16", "fp32": "f32", "x3": "f32 storage, split-bf16 MFMA",
          "fp16c": "f16 MFMA + block-scaled fp8 (e4m3) MFMA correction, f32 accumulate / residual stream"}
 GEMM_KERNEL = {"fp16": "gemm_16_nt_256p8", "bf16": "gemm_16_nt_256p8", "fp16c": "gemm_16c_nt_256p8"}
@@ -699,7 +700,11 @@ def main():
                         if a.precision == "fp16c" else ""),
                     "alone": {"schedule": "encoder inline (each GEMM alone on the device), same K steps", "achieved": round(ach, 1),
                               "frac": round(ach / PEAK_TFLOPS, 4), "avg_launch_us": round(ms_i * 1e3 / n_i, 2), "launches": n_i},
-                    "gemm_share_of_step": round(ms_i / a.steps / (dt / a.steps * 1e3), 3)}
+                    "gemm_share_of_step": round(ms_i / a.steps / (dt / a.steps * 1e3), 3),
+                    # what `peak` is not: round 6 measured this kernel AT the socket's 1 400 W cap (1.84-1.91 GHz, profiles/r06_gemm_power.log)
+                    "power_note": "peak is the nominal 2.4-GHz figure; NOT measured in this run: a pure f16 16x16x32 MFMA stream on random operands "
+                                  "sustains %.0f TFLOP/s on this chip (fp8 16x16x128: %.0f), and this kernel runs at the socket power cap "
+                                  "(profiles/r06_mfma_power.log, r06_gemm_power.log)" % (SUSTAINED_F16_TFLOPS, SUSTAINED_FP8_TFLOPS)}
             if gsplit:
                 roof["timed_gemm_us"] = gsplit
 
