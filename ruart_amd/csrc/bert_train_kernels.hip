@@ -388,7 +388,11 @@ __global__ __launch_bounds__(256) void mix_rows_bwd_kernel(const f16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-#define LN_BWD_BLOCKS 512
+// workgroups of the LayerNorm backward (a wave walks rows grid-stride, one row in flight): 768 = 12 waves per CU.  Round 6, trained-encoder
+// step, interleaved: 512 44.3-44.9 ms, 768 44.0-44.5, 1024 44.1-44.2; the next row's operands prefetched (158 VGPRs): no gain.
+#ifndef LN_BWD_BLOCKS
+#define LN_BWD_BLOCKS 768
+#endif
 
 extern "C" int ruart_ln_train_fwd(const float* x, int ldx, const void* res16, int ldr, const float* gamma, const float* beta, float eps,
                                   float p, unsigned seed, int post, void* y16, void* pre16, float* stats, int ld16, int rows, int H,
